@@ -1,0 +1,465 @@
+"""CPU oracle for the mean-field-game hot path.  TEST INFRASTRUCTURE ONLY.
+
+This module is a float64 NumPy *restatement* of the reference's algorithm for the
+hot path.  It is the checker for the HIP kernels, never the
+product: only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import it.  The product package
+``discrete_mean_field_game_amd`` must never import anything from ``oracle/``.
+
+Pinning: ``oracle/gen_golden.py`` imports the unmodified reference
+(``/root/reference/mfg_ac2.py``; ``ac_irl.py`` behind a stub ``tensorflow``) in the
+build container and writes ``tests/golden/*.npz``; ``tests/test_oracle_golden.py``
+checks every function below against those vectors, including the reference's own
+known-answer inputs (``test2.py:46-56``, ``:73-88``, ``:105-121``) and seeded
+multi-episode ``train()`` traces.  The TF reward network (``networks.py``) cannot be
+imported here (TensorFlow 1.x is absent) and the reference holds no numeric test
+for it: that part is "parity unpinned" and lives in ``oracle/reward_net_oracle.py``.
+
+Every function is batch-first: ``pi`` is ``(..., d)``, ``P`` is ``(..., d, d)``.  With no
+leading batch dimension each function reduces to the reference's batch-1 math, in
+the reference's operation order, so a seeded batch-1 run reproduces the reference's
+trajectory bit for bit (checked in the golden tests).
+
+Citations are ``file:line`` into the reference repository.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Optional
+
+import numpy as np
+from scipy import special
+from scipy.stats import entropy
+
+ZERO_GAMMA_REPLACEMENT = 1e-20   # mfg_ac2.py:244 / ac_irl.py:539
+ZERO_P_REPLACEMENT = 1e-100      # mfg_ac2.py:369, :556-557
+EPISODE_STEPS = 15               # mfg_ac2.py:478 / ac_irl.py:664
+
+
+# --------------------------------------------------------------------------
+# a5 / a9: integer bookkeeping
+# --------------------------------------------------------------------------
+def num_features(d: int) -> int:
+    """F = d(d+1)/2 + d + 1.  mfg_ac2.py:175."""
+    return (d + 1) * d // 2 + d + 1
+
+
+def feature_index(i: int, j: int, d: int) -> int:
+    """Position of the quadratic feature pi_i*pi_j (i <= j) inside phi(pi).
+
+    The reference enumerates ``itertools.combinations_with_replacement(pi, 2)``
+    (mfg_ac2.py:333), i.e. row-major upper triangle:
+    k(i, j) = i*d - i(i-1)/2 + (j - i).
+    """
+    if i > j:
+        i, j = j, i
+    return i * d - (i * (i - 1)) // 2 + (j - i)
+
+
+def feature_index_table(d: int) -> np.ndarray:
+    """(d, d) int32 table of k(i, j) (symmetric), the index map the kernels use."""
+    k = np.empty((d, d), dtype=np.int32)
+    for i in range(d):
+        for j in range(d):
+            k[i, j] = feature_index(i, j, d)
+    return k
+
+
+def reorder(list_rows):
+    """Stable sort of all rows by decreasing value of the first row.
+
+    mfg_ac2.py:58-81 (``list.sort(reverse=True)`` is stable: ties keep index order).
+    Returns (reordered rows, permutation).
+    """
+    row1 = list(list_rows[0])
+    order = sorted(range(len(row1)), key=lambda i: row1[i], reverse=True)
+    return [[row[j] for j in order] for row in list_rows], order
+
+
+def parse_pi0_line(line: str, d: int):
+    """First line of a trend_distribution_day file -> first d floats.  mfg_ac2.py:198."""
+    return list(map(float, line.strip().split(' ')))[0:d]
+
+
+# --------------------------------------------------------------------------
+# a1: deterministic half of sample_action
+# --------------------------------------------------------------------------
+def calc_alpha(pi, theta, shift):
+    """alpha_ij = ln(1 + exp(theta*(pi_j - pi_i - shift))).  mfg_ac2.py:225-228, ac_irl.py:521-524."""
+    pi = np.asarray(pi, dtype=np.float64)
+    temp = pi[..., None, :] - pi[..., :, None]          # temp_ij = pi_j - pi_i
+    return np.log(1 + np.exp(theta * (temp - shift)))
+
+
+def calc_alpha_deriv(pi, theta, shift):
+    """d alpha_ij / d theta = x / (1 + exp(-theta*x)), x = pi_j - pi_i - shift.
+
+    mfg_ac2.py:232-234, ac_irl.py:573-588.
+    """
+    pi = np.asarray(pi, dtype=np.float64)
+    temp = pi[..., None, :] - pi[..., :, None]
+    numerator = temp - shift
+    denominator = 1 + np.exp((-theta) * numerator)
+    return numerator / denominator
+
+
+# --------------------------------------------------------------------------
+# a2: stochastic half of sample_action
+# --------------------------------------------------------------------------
+def dirichlet_from_gamma(y):
+    """Rows of gamma variates -> row-stochastic P.  mfg_ac2.py:244-249.
+
+    Zeros are replaced by 1e-20 before normalising.  Input is not modified.
+    """
+    y = np.array(y, dtype=np.float64, copy=True)
+    y[y == 0] = ZERO_GAMMA_REPLACEMENT
+    return y / np.sum(y, axis=-1, keepdims=True)
+
+
+def sample_action(pi, theta, shift, alpha_scale, rng=np.random, return_gamma=False):
+    """Reference sampler for ONE trajectory: d sequential vector gamma draws.
+
+    mfg_ac2.py:236-254 / ac_irl.py:526-548.  ``rng`` defaults to the process-global
+    legacy ``np.random`` exactly like the reference, so a caller-side
+    ``np.random.seed`` reproduces the reference's stream.
+    """
+    pi = np.asarray(pi, dtype=np.float64)
+    d = pi.shape[-1]
+    mat_alpha = calc_alpha(pi, theta, shift)
+    y = np.zeros([d, d])
+    for i in range(d):
+        y[i] = rng.gamma(shape=mat_alpha[i, :] * alpha_scale, scale=1)
+    P = dirichlet_from_gamma(y)
+    if return_gamma:
+        return P, y
+    return P
+
+
+# --------------------------------------------------------------------------
+# a3 / a4: transition and reward
+# --------------------------------------------------------------------------
+def transition(P, pi):
+    """pi'_j = sum_i P_ij pi_i.  mfg_ac2.py:497, ac_irl.py:679."""
+    P = np.asarray(P, dtype=np.float64)
+    pi = np.asarray(pi, dtype=np.float64)
+    if P.ndim == 2:
+        return np.transpose(P).dot(pi)
+    return np.einsum('...ij,...i->...j', P, pi)
+
+
+def calc_reward(P, pi):
+    """R = pi . ((P*P) pi - ((P*P) 1) * pi).  mfg_ac2.py:274-279.
+
+    Batch-1 input returns shape (1,) like the reference; batched returns (B,).
+    """
+    P = np.asarray(P, dtype=np.float64)
+    pi = np.asarray(pi, dtype=np.float64)
+    d = pi.shape[-1]
+    if P.ndim == 2:
+        P_squared = P * P
+        v1 = P_squared.dot(pi.reshape(d, 1))
+        v2 = P_squared.dot(np.ones([d, 1])) * pi.reshape(d, 1)
+        return pi.dot(v1 - v2)
+    P_squared = P * P
+    v1 = np.einsum('...ij,...j->...i', P_squared, pi)
+    v2 = np.sum(P_squared, axis=-1) * pi
+    return np.sum(pi * (v1 - v2), axis=-1)
+
+
+def calc_reward_synthetic(P, pi):
+    """mfg_synthetic variant R = -1/2 sum_i pi_i ||P_i||^2.  mfg_synthetic.py:249-265."""
+    P = np.asarray(P, dtype=np.float64)
+    pi = np.asarray(pi, dtype=np.float64)
+    return -0.5 * np.sum(pi * np.sum(P * P, axis=-1), axis=-1)
+
+
+# --------------------------------------------------------------------------
+# a5: features and value
+# --------------------------------------------------------------------------
+def calc_features(pi):
+    """phi(pi) = [pi_i pi_j (i<=j, row-major upper triangle), pi_1..pi_d, 1].
+
+    mfg_ac2.py:325-344 (the docstring at :171 states another order; the code wins).
+    """
+    pi = np.asarray(pi, dtype=np.float64)
+    d = pi.shape[-1]
+    iu, ju = np.triu_indices(d)
+    quad = pi[..., iu] * pi[..., ju]
+    ones = np.ones(pi.shape[:-1] + (1,))
+    return np.concatenate([quad, pi, ones], axis=-1)
+
+
+def calc_value(pi, w):
+    """V(pi; w) = phi(pi) . w.  mfg_ac2.py:290-322."""
+    return calc_features(pi).dot(np.asarray(w, dtype=np.float64))
+
+
+# --------------------------------------------------------------------------
+# a7: score of the product-Dirichlet policy w.r.t. theta
+# --------------------------------------------------------------------------
+def calc_gradient(P, pi, theta, shift, mat_alpha=None, mat_alpha_deriv=None):
+    """g = sum_ij (-psi(alpha_ij) + psi(sum_j alpha_ij) + ln P_ij) * alpha'_ij.
+
+    mfg_ac2.py:347-381 / ac_irl.py:591-624.  alpha is the UNSCALED concentration
+    (no alpha_scale).  The reference reads ``self.mat_alpha`` left behind by the last
+    ``sample_action`` call; pass ``mat_alpha`` to reproduce a stale-alpha call,
+    otherwise it is recomputed from ``pi``.  Zeros of P count as 1e-100 (:369); the
+    input array is not modified here (the reference mutates it in place).
+    """
+    P = np.array(P, dtype=np.float64, copy=True)
+    if mat_alpha is None:
+        mat_alpha = calc_alpha(pi, theta, shift)
+    if mat_alpha_deriv is None:
+        mat_alpha_deriv = calc_alpha_deriv(pi, theta, shift)
+    mat1 = special.digamma(mat_alpha)
+    mat2 = special.digamma(np.ones(mat_alpha.shape) * np.sum(mat_alpha, axis=-1, keepdims=True))
+    P[P == 0] = ZERO_P_REPLACEMENT
+    mat3 = np.log(P)
+    return np.sum((-mat1 + mat2 + mat3) * mat_alpha_deriv, axis=(-2, -1))
+
+
+# --------------------------------------------------------------------------
+# a11: Jensen-Shannon divergence
+# --------------------------------------------------------------------------
+def JSD(P, Q):
+    """0.5*(KL(P||M) + KL(Q||M)), M = (P+Q)/2, zeros -> 1e-100.  mfg_ac2.py:546-563.
+
+    ``scipy.stats.entropy`` renormalises each argument.  Inputs are not modified
+    (the reference replaces zeros in place).
+    """
+    P = np.array(P, dtype=np.float64, copy=True)
+    Q = np.array(Q, dtype=np.float64, copy=True)
+    P[P == 0] = ZERO_P_REPLACEMENT
+    Q[Q == 0] = ZERO_P_REPLACEMENT
+    M = 0.5 * (P + Q)
+    return 0.5 * (entropy(P, M, axis=-1) + entropy(Q, M, axis=-1))
+
+
+# --------------------------------------------------------------------------
+# a6 / a8: learning-rate schedules and one TD / actor-critic update
+# --------------------------------------------------------------------------
+def lr_scales(episode: int, constant, variant: str = 'mfg_ac2'):
+    """Multipliers applied to (lr_critic, lr_actor) in ``episode``.
+
+    mfg_ac2.py:511-522 (episodes 0-indexed) and ac_irl.py:697-708 (1-indexed, same
+    formula written in terms of its own ``episode``).
+    """
+    if constant:
+        return 1.0, 1.0
+    return 1.0 / (episode + 1), 1.0 / ((episode + 1) * np.log(np.log(episode + 20)))
+
+
+def ac_step(pi, P, reward, w, theta, shift, gamma_or_discount, lr_c, lr_a,
+            mat_alpha=None, mat_alpha_deriv=None):
+    """One reference actor-critic update given (pi, P, reward).
+
+    mfg_ac2.py:497-522 / ac_irl.py:679-708.  ``w`` is (F,1).  Returns
+    (pi_next, delta, gradient, w_new, theta_new).
+    """
+    pi_next = transition(P, pi)
+    vec_features_next = calc_features(pi_next)
+    vec_features = calc_features(pi)
+    delta = reward + gamma_or_discount * (vec_features_next.dot(w)) - (vec_features.dot(w))
+    length = len(vec_features)
+    w_new = w + lr_c * delta * vec_features.reshape(length, 1)
+    gradient = calc_gradient(P, pi, theta, shift, mat_alpha, mat_alpha_deriv)
+    theta_new = theta + lr_a * delta * gradient
+    return pi_next, delta, gradient, w_new, theta_new
+
+
+# --------------------------------------------------------------------------
+# a9: train() control flow, batch 1, reference RNG order
+# --------------------------------------------------------------------------
+def train_mfg_ac2(mat_pi0, w, theta, shift, alpha_scale, num_episodes, gamma=1,
+                  constant=0, lr_critic=0.1, lr_actor=0.001, rng=np.random,
+                  reward_fn: Optional[Callable] = None, record=True):
+    """Restatement of ``mfg_ac2.actor_critic.train`` (mfg_ac2.py:448-539), batch 1.
+
+    Consumes ``rng`` in the reference's order: one ``randint`` per episode (:466)
+    then d ``gamma`` vector draws per step (:242).  Returns a dict with the final
+    (theta, w) and per-step traces used for parity fixtures.
+    """
+    mat_pi0 = np.asarray(mat_pi0, dtype=np.float64)
+    d = mat_pi0.shape[1]
+    num_start = mat_pi0.shape[0]
+    w = np.array(w, dtype=np.float64, copy=True).reshape(-1, 1)
+    tr = {'idx_row': [], 'theta': [], 'delta': [], 'reward': [], 'gradient': [],
+          'total_reward': [], 'pi_final': [], 'P': [], 'pi': []}
+    for episode in range(num_episodes):
+        idx_row = rng.randint(num_start)
+        pi = mat_pi0[idx_row, :]
+        total_reward = 0
+        for _ in range(EPISODE_STEPS):
+            P = sample_action(pi, theta, shift, alpha_scale, rng)
+            if reward_fn is None:
+                reward = calc_reward(P, pi)
+            else:
+                reward = reward_fn(pi, P)
+            sc, sa = lr_scales(episode, constant == 1)
+            if record:
+                tr['pi'].append(np.array(pi))
+                tr['P'].append(P.copy())
+            pi_next, delta, gradient, w, theta = ac_step(
+                pi, P, reward, w, theta, shift, gamma, lr_critic * sc, lr_actor * sa)
+            pi = pi_next
+            total_reward += reward
+            if record:
+                tr['theta'].append(np.ravel(theta)[0])
+                tr['delta'].append(np.ravel(delta)[0])
+                tr['reward'].append(np.ravel(reward)[0])
+                tr['gradient'].append(float(gradient))
+        tr['idx_row'].append(idx_row)
+        tr['total_reward'].append(np.ravel(total_reward)[0])
+        tr['pi_final'].append(np.array(pi))
+    out = {k: np.array(v) for k, v in tr.items()}
+    out['idx_row'] = out['idx_row'].astype(np.int64)
+    out['theta_final'] = np.ravel(theta)[0]
+    out['w_final'] = w
+    return out
+
+
+def train_ac_irl(mat_pi0, w, theta, shift, alpha_scale, max_episodes, reward_fn,
+                 stop_criteria=0.01, gamma=1, constant=False, lr_critic=0.1,
+                 lr_actor=0.001, rng=np.random):
+    """Restatement of ``ac_irl.AC_IRL.train`` (ac_irl.py:634-732), batch 1.
+
+    Differences from mfg_ac2 kept on purpose: episodes are 1-indexed (:649), the
+    bootstrap term uses the running ``discount = gamma**t`` (:691, :710), reward
+    comes from ``reward_fn(pi, P)`` (the TF net at :683), early stop on
+    |theta - prev_theta| < stop_criteria (:726).  Returns traces + episodes run.
+    """
+    mat_pi0 = np.asarray(mat_pi0, dtype=np.float64)
+    num_start = mat_pi0.shape[0]
+    w = np.array(w, dtype=np.float64, copy=True).reshape(-1, 1)
+    tr = {'idx_row': [], 'theta': [], 'delta': [], 'reward': [], 'gradient': [], 'total_reward': []}
+    prev_theta = theta
+    episode = 0
+    for episode in range(1, max_episodes + 1):
+        idx_row = rng.randint(num_start)
+        pi = mat_pi0[idx_row, :]
+        discount = 1
+        total_reward = 0
+        for _ in range(EPISODE_STEPS):
+            P = sample_action(pi, theta, shift, alpha_scale, rng)
+            reward = reward_fn(pi, P)
+            sc, sa = lr_scales(episode, constant)
+            pi_next, delta, gradient, w, theta = ac_step(
+                pi, P, reward, w, theta, shift, discount, lr_critic * sc, lr_actor * sa)
+            discount = discount * gamma
+            pi = pi_next
+            total_reward += reward
+            tr['theta'].append(np.ravel(theta)[0])
+            tr['delta'].append(np.ravel(delta)[0])
+            tr['reward'].append(np.ravel(reward)[0])
+            tr['gradient'].append(float(gradient))
+        tr['idx_row'].append(idx_row)
+        tr['total_reward'].append(np.ravel(total_reward)[0])
+        if stop_criteria != -1 and abs(theta - prev_theta) < stop_criteria:
+            break
+        prev_theta = theta
+    out = {k: np.array(v) for k, v in tr.items()}
+    out['idx_row'] = out['idx_row'].astype(np.int64)
+    out['theta_final'] = np.ravel(theta)[0]
+    out['w_final'] = w
+    out['episodes_run'] = episode
+    return out
+
+
+# --------------------------------------------------------------------------
+# a10: trajectory generation
+# --------------------------------------------------------------------------
+def generate_trajectory(pi0, total_hours, theta, shift, alpha_scale, rng=np.random):
+    """mfg_ac2.py:566-592: rows pi^0..pi^{total_hours-1}."""
+    pi = np.asarray(pi0, dtype=np.float64)
+    d = pi.shape[-1]
+    mat = np.zeros([total_hours, d])
+    mat[0] = pi
+    for hour in range(1, total_hours):
+        P = sample_action(pi, theta, shift, alpha_scale, rng)
+        pi = transition(P, pi)
+        mat[hour] = pi
+    return mat
+
+
+def generate_trajectories(n, mat_pi0, theta, shift, alpha_scale, rng=np.random):
+    """ac_irl.py:735-767: list of n trajectories, each 15 (pi, P) pairs."""
+    mat_pi0 = np.asarray(mat_pi0, dtype=np.float64)
+    out = []
+    for _ in range(n):
+        idx_row = rng.randint(mat_pi0.shape[0])
+        pi = mat_pi0[idx_row, :]
+        traj = []
+        for _hour in range(1, 16):
+            P = sample_action(pi, theta, shift, alpha_scale, rng)
+            traj.append((pi, P))
+            pi = transition(P, pi)
+        out.append(traj)
+    return out
+
+
+# --------------------------------------------------------------------------
+# Batched semantics of the new framework (B trajectories in lock-step)
+# --------------------------------------------------------------------------
+def batched_td_pg(pi, pi_next, P, reward, w, theta, shift, gamma_or_discount):
+    """Batched a5-a8 pieces on given inputs: returns delta[B], g[B], G_w[F], G_theta, sum_reward.
+
+    G_w = sum_b delta_b phi(pi_b), G_theta = sum_b delta_b g_b (plain sums; the caller
+    divides by the global batch).  With B = 1 this is exactly the increment the
+    reference applies (mfg_ac2.py:505-522) divided by the learning rate.
+    """
+    w = np.asarray(w, dtype=np.float64).reshape(-1)
+    phi = calc_features(pi)
+    phi_next = calc_features(pi_next)
+    delta = np.asarray(reward, dtype=np.float64) + gamma_or_discount * phi_next.dot(w) - phi.dot(w)
+    g = calc_gradient(P, pi, theta, shift)
+    G_w = np.einsum('b,bf->f', delta, phi)
+    G_theta = float(np.sum(delta * g))
+    return delta, g, G_w, G_theta, float(np.sum(reward))
+
+
+def batched_rollout_given_P(pi0, P_seq, w, theta, shift, gamma=1.0, variant='mfg_ac2',
+                            storage_dtype=np.float32, reward_seq=None):
+    """T-step lock-step rollout with FIXED (theta, w) on given actions P_seq[B,T,d,d].
+
+    Mirrors the fused kernel's 'rollout' mode: pi is rounded to the storage dtype at
+    every step (the kernel keeps pi in fp32 registers), gradients are summed over all
+    B*T transitions.  Returns pi_traj[B,T+1,d], reward[B,T], delta[B,T], g[B,T],
+    G_w[F], G_theta.
+    """
+    pi = np.asarray(pi0, dtype=storage_dtype).astype(np.float64)
+    B, T = P_seq.shape[0], P_seq.shape[1]
+    d = pi.shape[-1]
+    F = num_features(d)
+    traj = np.zeros((B, T + 1, d))
+    traj[:, 0] = pi
+    R = np.zeros((B, T)); D = np.zeros((B, T)); G = np.zeros((B, T))
+    G_w = np.zeros(F); G_theta = 0.0
+    discount = 1.0
+    for t in range(T):
+        P = np.asarray(P_seq[:, t], dtype=np.float64)
+        pi_next = transition(P, pi).astype(storage_dtype).astype(np.float64)
+        r = calc_reward(P, pi) if reward_seq is None else np.asarray(reward_seq[:, t], np.float64)
+        gd = gamma if variant == 'mfg_ac2' else discount
+        delta, g, gw, gt, _ = batched_td_pg(pi, pi_next, P, r, w, theta, shift, gd)
+        R[:, t] = r; D[:, t] = delta; G[:, t] = g
+        G_w += gw; G_theta += gt
+        discount *= gamma
+        pi = pi_next
+        traj[:, t + 1] = pi
+    return traj, R, D, G, G_w, G_theta
+
+
+def cpu_baseline_steps(d, n_steps, theta=8.86349, shift=0.16, alpha_scale=12000, seed=0):
+    """Reference-faithful CPU leg for bench.py: batch 1, sequential, full train() step.
+
+    Runs ``n_steps // 15`` episodes of ``train_mfg_ac2`` on synthetic Dirichlet(1)
+    start states and returns (env_steps_done, seconds).
+    """
+    import time
+    rs = np.random.RandomState(seed)
+    mat_pi0 = rs.dirichlet(np.ones(d), size=64)
+    w = rs.rand(num_features(d), 1)
+    episodes = max(1, n_steps // EPISODE_STEPS)
+    t0 = time.perf_counter()
+    train_mfg_ac2(mat_pi0, w, theta, shift, alpha_scale, episodes, rng=rs, record=False)
+    return episodes * EPISODE_STEPS, time.perf_counter() - t0
