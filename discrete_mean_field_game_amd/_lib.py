@@ -1,0 +1,82 @@
+"""ctypes binding of the C ABI in include/mfg_hip.h (libmfg_hip.so, built in-tree by csrc/Makefile).
+
+There is deliberately NO fallback: if the HIP library is missing or a call fails, an exception is
+raised.  The product path never routes through the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libmfg_hip.so')
+
+MFG_MAX_D = 512
+REWARD_MFG_AC2, REWARD_SYNTHETIC, REWARD_EXTERNAL = 0, 1, 2
+ROLLOUT_WRITE_P, ROLLOUT_TD, ROLLOUT_DISCOUNT_POW = 1, 2, 4
+
+
+class MfgError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ['make', '-C', CSRC]
+    if force:
+        args.append('-B')
+    subprocess.run(args, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return LIB_PATH
+
+
+_p = C.c_void_p
+_i64, _i32, _u64, _u32, _f64, _sz = C.c_int64, C.c_int, C.c_uint64, C.c_uint32, C.c_double, C.c_size_t
+
+# symbol -> (restype, argtypes); mirrors include/mfg_hip.h one to one
+SIGNATURES = {
+    'mfg_last_error': (C.c_char_p, []),
+    'mfg_abi_version': (_i32, []),
+    'mfg_device_info': (_i32, [C.POINTER(C.c_int), C.c_char_p, _i32]),
+    'mfg_feature_index': (_i64, [_i32, _i32, _i32]),
+    'mfg_num_features': (_i64, [_i32]),
+    'mfg_workspace_bytes': (_sz, [_i64, _i32]),
+    'mfg_gather_start': (_i32, [_p, _i64, _p, _i64, _i32, _p, _p]),
+    'mfg_alpha': (_i32, [_p, _i64, _i32, _p, _f64, _p, _p, _p]),
+    'mfg_dirichlet_from_gamma': (_i32, [_p, _i64, _i32, _p, _p]),
+    'mfg_sample_dirichlet': (_i32, [_p, _i64, _i32, _p, _f64, _f64, _u64, _u32, _u64, _p, _p]),
+    'mfg_philox_raw': (_i32, [_u64, _u32, _u32, _u32, _u32, _i64, _p, _p]),
+    'mfg_step_given_P': (_i32, [_p, _p, _i64, _i32, _i32, _p, _p, _p]),
+    'mfg_value': (_i32, [_p, _p, _i64, _i32, _p, _p]),
+    'mfg_features': (_i32, [_p, _i64, _i32, _p, _p]),
+    'mfg_score': (_i32, [_p, _p, _i64, _i32, _p, _f64, _p, _p]),
+    'mfg_td_pg_accumulate': (_i32, [_p, _p, _p, _p, _p, _p, _f64, _f64, _i64, _i32, _p, _p, _p, _i32, _p, _sz, _p]),
+    'mfg_apply_update': (_i32, [_p, _i32, _f64, _f64, _p, _p, _p]),
+    'mfg_rollout': (_i32, [_p, _i64, _i32, _i32, _p, _f64, _f64, _p, _f64, _i32, _u64, _u32, _u64, _i32,
+                           _p, _p, _p, _p, _p, _p, _i32, _p, _sz, _p]),
+    'mfg_jsd': (_i32, [_p, _p, _i64, _i32, _p, _p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libmfg_hip.so (once) and bind every symbol.  Raises MfgError when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MfgError('HIP extension not built: %s is missing (run __graft_entry__.build() / make -C %s)'
+                           % (LIB_PATH, CSRC))
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise MfgError('%s failed (%d): %s' % (what, rc, lib().mfg_last_error().decode()))

@@ -1,0 +1,194 @@
+"""Thin tensor-level wrappers over the C ABI: torch owns device memory and streams, HIP does the math.
+
+Every function takes CUDA(ROCm) tensors, enqueues on torch's current stream and returns tensors.
+Shapes follow include/mfg_hip.h: pi [B,d] fp32, P [B,d,d] fp32, theta / w fp64 device tensors.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk_f32(t, name):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError('%s must be a contiguous float32 CUDA tensor' % name)
+    return t
+
+
+def _chk_f64(t, name):
+    if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+        raise ValueError('%s must be a contiguous float64 CUDA tensor' % name)
+    return t
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def num_features(d: int) -> int:
+    return int(L.lib().mfg_num_features(d))
+
+
+def feature_index(i: int, j: int, d: int) -> int:
+    return int(L.lib().mfg_feature_index(i, j, d))
+
+
+def workspace(N: int, d: int, device) -> torch.Tensor:
+    n = int(L.lib().mfg_workspace_bytes(N, d))
+    return torch.empty(max(n, 8) // 8, dtype=torch.float64, device=device)
+
+
+def gather_start(mat_pi0, idx):
+    _chk_f32(mat_pi0, 'mat_pi0')
+    if idx.dtype != torch.int32 or not idx.is_cuda:
+        raise ValueError('idx must be an int32 CUDA tensor')
+    B, d = idx.numel(), mat_pi0.shape[1]
+    out = torch.empty(B, d, dtype=torch.float32, device=mat_pi0.device)
+    L.check(L.lib().mfg_gather_start(mat_pi0.data_ptr(), mat_pi0.shape[0], idx.data_ptr(), B, d, out.data_ptr(),
+                                     _stream()), 'mfg_gather_start')
+    return out
+
+
+def alpha(pi, theta, shift, want_alpha=True, want_deriv=True):
+    _chk_f32(pi, 'pi'); _chk_f64(theta, 'theta')
+    B, d = pi.shape
+    a = torch.empty(B, d, d, dtype=torch.float64, device=pi.device) if want_alpha else None
+    ad = torch.empty(B, d, d, dtype=torch.float64, device=pi.device) if want_deriv else None
+    L.check(L.lib().mfg_alpha(pi.data_ptr(), B, d, theta.data_ptr(), float(shift), _ptr(a), _ptr(ad), _stream()),
+            'mfg_alpha')
+    return a, ad
+
+
+def dirichlet_from_gamma(y):
+    _chk_f32(y, 'y')
+    B, d = y.shape[0], y.shape[-1]
+    P = torch.empty_like(y)
+    L.check(L.lib().mfg_dirichlet_from_gamma(y.data_ptr(), B, d, P.data_ptr(), _stream()), 'mfg_dirichlet_from_gamma')
+    return P
+
+
+def sample_dirichlet(pi, theta, shift, alpha_scale, seed, step=0, traj_offset=0, out=None):
+    _chk_f32(pi, 'pi'); _chk_f64(theta, 'theta')
+    B, d = pi.shape
+    P = out if out is not None else torch.empty(B, d, d, dtype=torch.float32, device=pi.device)
+    L.check(L.lib().mfg_sample_dirichlet(pi.data_ptr(), B, d, theta.data_ptr(), float(shift), float(alpha_scale),
+                                         int(seed), int(step), int(traj_offset), P.data_ptr(), _stream()),
+            'mfg_sample_dirichlet')
+    return P
+
+
+def philox_raw(seed, first_ctr, c1, c2, c3, n, device):
+    out = torch.empty(n, 4, dtype=torch.int32, device=device)
+    L.check(L.lib().mfg_philox_raw(int(seed), int(first_ctr), int(c1), int(c2), int(c3), n, out.data_ptr(), _stream()),
+            'mfg_philox_raw')
+    return out
+
+
+def step_given_P(pi, P, reward_kind=L.REWARD_MFG_AC2, want_reward=True):
+    _chk_f32(pi, 'pi'); _chk_f32(P, 'P')
+    B, d = pi.shape
+    if P.shape != (B, d, d):
+        raise ValueError('P must be [B,d,d]')
+    pi_next = torch.empty_like(pi)
+    reward = torch.empty(B, dtype=torch.float32, device=pi.device) if want_reward else None
+    L.check(L.lib().mfg_step_given_P(pi.data_ptr(), P.data_ptr(), B, d, int(reward_kind), pi_next.data_ptr(),
+                                     _ptr(reward), _stream()), 'mfg_step_given_P')
+    return pi_next, reward
+
+
+def value(pi, w):
+    _chk_f32(pi, 'pi'); _chk_f64(w, 'w')
+    B, d = pi.shape
+    out = torch.empty(B, dtype=torch.float64, device=pi.device)
+    L.check(L.lib().mfg_value(pi.data_ptr(), w.data_ptr(), B, d, out.data_ptr(), _stream()), 'mfg_value')
+    return out
+
+
+def features(pi):
+    _chk_f32(pi, 'pi')
+    B, d = pi.shape
+    out = torch.empty(B, num_features(d), dtype=torch.float64, device=pi.device)
+    L.check(L.lib().mfg_features(pi.data_ptr(), B, d, out.data_ptr(), _stream()), 'mfg_features')
+    return out
+
+
+def score(pi_alpha, P, theta, shift):
+    _chk_f32(pi_alpha, 'pi'); _chk_f32(P, 'P'); _chk_f64(theta, 'theta')
+    B, d = pi_alpha.shape
+    g = torch.empty(B, dtype=torch.float64, device=P.device)
+    L.check(L.lib().mfg_score(pi_alpha.data_ptr(), P.data_ptr(), B, d, theta.data_ptr(), float(shift), g.data_ptr(),
+                              _stream()), 'mfg_score')
+    return g
+
+
+def td_pg_accumulate(pi, pi_next, P, reward, w, theta, shift, gamma_or_discount, G=None, accumulate=False, ws=None):
+    for t, n in ((pi, 'pi'), (pi_next, 'pi_next'), (P, 'P'), (reward, 'reward')):
+        _chk_f32(t, n)
+    _chk_f64(w, 'w'); _chk_f64(theta, 'theta')
+    B, d = pi.shape
+    F = num_features(d)
+    delta = torch.empty(B, dtype=torch.float64, device=pi.device)
+    g = torch.empty(B, dtype=torch.float64, device=pi.device)
+    if G is None:
+        G = torch.zeros(F + 3, dtype=torch.float64, device=pi.device)
+    if ws is None:
+        ws = workspace(B, d, pi.device)
+    L.check(L.lib().mfg_td_pg_accumulate(pi.data_ptr(), pi_next.data_ptr(), P.data_ptr(), reward.data_ptr(),
+                                         w.data_ptr(), theta.data_ptr(), float(shift), float(gamma_or_discount),
+                                         B, d, delta.data_ptr(), g.data_ptr(), G.data_ptr(), int(accumulate),
+                                         ws.data_ptr(), ws.numel() * 8, _stream()), 'mfg_td_pg_accumulate')
+    return delta, g, G
+
+
+def apply_update(G, d, lr_critic, lr_actor, w, theta):
+    _chk_f64(G, 'G'); _chk_f64(w, 'w'); _chk_f64(theta, 'theta')
+    L.check(L.lib().mfg_apply_update(G.data_ptr(), d, float(lr_critic), float(lr_actor), w.data_ptr(),
+                                     theta.data_ptr(), _stream()), 'mfg_apply_update')
+
+
+def rollout(pi0, T, theta, shift, alpha_scale, w=None, gamma=1.0, reward_kind=L.REWARD_MFG_AC2, seed=0,
+            first_step=0, traj_offset=0, td=True, write_P=False, discount_pow=False, G=None, accumulate=False,
+            ws=None, out=None):
+    """Fused T-step rollout.  Returns dict(pi_traj, reward, delta, g, P, G)."""
+    _chk_f32(pi0, 'pi0'); _chk_f64(theta, 'theta')
+    B, d = pi0.shape
+    dev = pi0.device
+    o = out or {}
+    pi_traj = o.get('pi_traj') if 'pi_traj' in o else torch.empty(B, T + 1, d, dtype=torch.float32, device=dev)
+    reward = o.get('reward') if 'reward' in o else torch.empty(B, T, dtype=torch.float32, device=dev)
+    delta = g = None
+    flags = 0
+    if td:
+        _chk_f64(w, 'w')
+        flags |= L.ROLLOUT_TD
+        delta = o.get('delta') if 'delta' in o else torch.empty(B, T, dtype=torch.float64, device=dev)
+        g = o.get('g') if 'g' in o else torch.empty(B, T, dtype=torch.float64, device=dev)
+        if G is None:
+            G = torch.zeros(num_features(d) + 3, dtype=torch.float64, device=dev)
+        if ws is None:
+            ws = workspace(B * T, d, dev)
+    P = None
+    if write_P:
+        flags |= L.ROLLOUT_WRITE_P
+        P = o.get('P') if 'P' in o else torch.empty(B, T, d, d, dtype=torch.float32, device=dev)
+    if discount_pow:
+        flags |= L.ROLLOUT_DISCOUNT_POW
+    L.check(L.lib().mfg_rollout(pi0.data_ptr(), B, d, T, theta.data_ptr(), float(shift), float(alpha_scale),
+                                _ptr(w) if td else None, float(gamma), int(reward_kind), int(seed), int(first_step),
+                                int(traj_offset), flags, pi_traj.data_ptr(), reward.data_ptr(), _ptr(delta), _ptr(g),
+                                _ptr(P), _ptr(G) if td else None, int(accumulate), _ptr(ws) if td else None,
+                                ws.numel() * 8 if (td and ws is not None) else 0, _stream()), 'mfg_rollout')
+    return {'pi_traj': pi_traj, 'reward': reward, 'delta': delta, 'g': g, 'P': P, 'G': G}
+
+
+def jsd(p, q):
+    _chk_f32(p, 'p'); _chk_f32(q, 'q')
+    B, d = p.shape
+    out = torch.empty(B, dtype=torch.float64, device=p.device)
+    L.check(L.lib().mfg_jsd(p.data_ptr(), q.data_ptr(), B, d, out.data_ptr(), _stream()), 'mfg_jsd')
+    return out

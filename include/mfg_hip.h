@@ -1,0 +1,147 @@
+/*
+ * mfg_hip.h -- C ABI of the MI355X (gfx950) mean-field-game hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI
+ * layer: its hot path is the NumPy body of the methods of mfg_ac2.actor_critic /
+ * ac_irl.AC_IRL.  Each entry point below replaces the batch-1 NumPy math of one of
+ * those methods by one launch over B independent trajectories.  The Python classes
+ * in discrete_mean_field_game_amd/ bind these symbols with ctypes and pass
+ * tensor.data_ptr() of PyTorch-owned device memory.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every pointer is DEVICE memory unless the name ends in _host.
+ *   - row-major; pi is [B,d] fp32, P is [B,d,d] fp32 (P[b][i][j] = prob. i -> j);
+ *     theta and the critic weights w[F] live on the device as fp64 so that updates
+ *     are stream ordered (no host round trip inside a rollout).
+ *   - F = d(d+1)/2 + d + 1; w = [quadratic upper triangle row-major | linear | bias]
+ *     (the order of mfg_ac2.py:325-344).
+ *   - return 0 on success, a negative MFG_E* code otherwise; mfg_last_error() gives
+ *     a thread-local message.  No allocation, no ownership transfer, no implicit
+ *     synchronisation: all work is enqueued on `stream` (a hipStream_t).
+ *   - all accumulations that feed rewards / TD errors / gradients are fp64.
+ */
+#ifndef MFG_HIP_H
+#define MFG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mfg_stream_t; /* hipStream_t */
+
+enum {
+  MFG_OK = 0,
+  MFG_EINVAL = -1,       /* bad argument (null pointer, d < 1, B < 0 ...) */
+  MFG_ELAUNCH = -2,      /* HIP reported a launch/runtime error */
+  MFG_EUNSUPPORTED = -3, /* shape outside the supported range (d > MFG_MAX_D) */
+  MFG_EWORKSPACE = -4    /* workspace too small */
+};
+
+#define MFG_MAX_D 512
+
+/* reward_kind for mfg_step_given_P / mfg_rollout */
+enum {
+  MFG_REWARD_MFG_AC2 = 0,   /* sum_i pi_i sum_j P_ij^2 (pi_j - pi_i)   mfg_ac2.py:257-287 */
+  MFG_REWARD_SYNTHETIC = 1, /* -1/2 sum_i pi_i ||P_i||^2               mfg_synthetic.py:249-265 */
+  MFG_REWARD_EXTERNAL = 2   /* reward supplied by the caller (IRL reward net, ac_irl.py:683) */
+};
+
+/* flags for mfg_rollout */
+enum {
+  MFG_ROLLOUT_WRITE_P = 1,     /* materialise P[B,T,d,d] (IRL / generate_trajectories, ac_irl.py:762) */
+  MFG_ROLLOUT_TD = 2,          /* also compute reward, delta, g per step (train); else env only */
+  MFG_ROLLOUT_DISCOUNT_POW = 4 /* bootstrap with running gamma^t (ac_irl.py:691,710) instead of gamma */
+};
+
+const char* mfg_last_error(void);
+int mfg_abi_version(void);
+
+/* Host-side query: multiprocessor count and gcnArchName of the current device. */
+int mfg_device_info(int* cu_count_host, char* arch_host, int arch_len);
+
+/* Index of the quadratic feature pi_i*pi_j inside phi / w (host helper, integer
+ * bookkeeping of itertools.combinations_with_replacement, mfg_ac2.py:333). */
+int64_t mfg_feature_index(int i, int j, int d);
+int64_t mfg_num_features(int d);
+
+/* Bytes of scratch the gradient reductions need for N transitions of dimension d. */
+size_t mfg_workspace_bytes(int64_t N, int d);
+
+/* a9: pi0[b,:] = mat_pi0[idx[b],:]                       (mfg_ac2.py:466-469) */
+int mfg_gather_start(const float* mat_pi0, int64_t num_start, const int32_t* idx, int64_t B, int d,
+                     float* pi0, mfg_stream_t stream);
+
+/* a1: alpha[b,i,j] = softplus(theta (pi_j - pi_i - shift)) and its theta-derivative
+ * (mfg_ac2.py:219-234; ac_irl.py:573-588).  Outputs fp64 [B,d,d]; either may be NULL. */
+int mfg_alpha(const float* pi, int64_t B, int d, const double* theta, double shift, double* alpha,
+              double* alpha_deriv, mfg_stream_t stream);
+
+/* a2 (normalisation half): P = y / rowsum(y) with zeros -> 1e-20   (mfg_ac2.py:244-249).
+ * Used when gamma variates are injected by the host (batch-1 reference RNG parity). */
+int mfg_dirichlet_from_gamma(const float* y, int64_t B, int d, float* P, mfg_stream_t stream);
+
+/* a1+a2: P[b] ~ prod_i Dirichlet(alpha[b,i,:] * alpha_scale)  (mfg_ac2.py:211-254).
+ * Counter-based RNG: Philox4x32-10 keyed by `seed`, counter = (element i*d+j, step,
+ * global trajectory id traj_offset + b, draw) so results do not depend on launch
+ * geometry or world size. */
+int mfg_sample_dirichlet(const float* pi, int64_t B, int d, const double* theta, double shift,
+                         double alpha_scale, uint64_t seed, uint32_t step, uint64_t traj_offset, float* P,
+                         mfg_stream_t stream);
+
+/* Raw Philox4x32-10 blocks for counters (c0 = first_ctr + n, c1, c2, c3): out[n,4] u32.  Test hook
+ * for bit-exact RNG parity. */
+int mfg_philox_raw(uint64_t seed, uint32_t first_ctr, uint32_t c1, uint32_t c2, uint32_t c3, int64_t n,
+                   uint32_t* out, mfg_stream_t stream);
+
+/* a3+a4: pi_next = P^T pi, reward[b] (fp32) per reward_kind     (mfg_ac2.py:497-499).
+ * reward may be NULL (transition only, ac_irl.py:679). */
+int mfg_step_given_P(const float* pi, const float* P, int64_t B, int d, int reward_kind, float* pi_next,
+                     float* reward, mfg_stream_t stream);
+
+/* a5: value[b] = phi(pi_b) . w (fp64 out)                     (mfg_ac2.py:290-322) */
+int mfg_value(const float* pi, const double* w, int64_t B, int d, double* value, mfg_stream_t stream);
+/* a5: phi[b,:] materialised (fp64 [B,F])                       (mfg_ac2.py:325-344) */
+int mfg_features(const float* pi, int64_t B, int d, double* phi, mfg_stream_t stream);
+
+/* a7: g[b] = sum_ij (-psi(alpha_ij) + psi(sum_j alpha_ij) + ln P_ij) alpha'_ij  (mfg_ac2.py:347-381).
+ * pi_alpha is the state the concentrations are computed from (the reference reads the alpha left
+ * behind by the previous sample_action; pass pi itself for the normal case).  Zeros of P count as
+ * 1e-100 (mfg_ac2.py:369); P is not modified. */
+int mfg_score(const float* pi_alpha, const float* P, int64_t B, int d, const double* theta, double shift,
+              double* g, mfg_stream_t stream);
+
+/* a5-a8 on given transitions: delta[b] = r + gamma_or_discount V(pi') - V(pi), g[b] as mfg_score,
+ * and the batch sums G = [ sum_b delta_b phi(pi_b) (F) | sum_b delta_b g_b | sum_b r_b | B ] (fp64,
+ * F+3 entries; accumulate != 0 adds onto the existing contents of G).  (mfg_ac2.py:501-522) */
+int mfg_td_pg_accumulate(const float* pi, const float* pi_next, const float* P, const float* reward,
+                         const double* w, const double* theta, double shift, double gamma_or_discount,
+                         int64_t B, int d, double* delta, double* g, double* G, int accumulate,
+                         void* workspace, size_t workspace_bytes, mfg_stream_t stream);
+
+/* a6/a8: w += lr_critic * G_w / count ; theta += lr_actor * G_theta / count  (mfg_ac2.py:511-522).
+ * count = G[F+2] (number of transitions summed, after any all-reduce). */
+int mfg_apply_update(const double* G, int d, double lr_critic, double lr_actor, double* w, double* theta,
+                     mfg_stream_t stream);
+
+/* Fused T-step rollout with fixed (theta, w): a1-a5, a7 per step, state kept on chip.
+ *   pi_traj[B,T+1,d] fp32 (pi_traj[:,0] = pi0), reward[B,T] fp32, delta[B,T], g[B,T] fp64,
+ *   P_out[B,T,d,d] fp32 when MFG_ROLLOUT_WRITE_P; G as in mfg_td_pg_accumulate over all B*T
+ *   transitions when MFG_ROLLOUT_TD.  first_step offsets the RNG step counter. */
+int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, double shift,
+                double alpha_scale, const double* w, double gamma, int reward_kind, uint64_t seed,
+                uint32_t first_step, uint64_t traj_offset, int flags, float* pi_traj, float* reward,
+                double* delta, double* g, float* P_out, double* G, int accumulate, void* workspace,
+                size_t workspace_bytes, mfg_stream_t stream);
+
+/* a11: out[b] = JSD(p_b, q_b), zeros -> 1e-100, inputs renormalised like scipy.stats.entropy
+ * (mfg_ac2.py:546-563).  fp64 out. */
+int mfg_jsd(const float* p, const float* q, int64_t B, int d, double* out, mfg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFG_HIP_H */

@@ -1,0 +1,342 @@
+"""-m gpu parity tests: the HIP path (through the C ABI) against the CPU oracle and the reference's
+golden vectors.  Tolerances (BASELINE.json north star): bit exact for integer / index work, <= 1e-5
+relative for fp32 rewards / returns; tighter where the kernel's fp64 accumulation allows.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail('-m gpu tests need a GPU: the HIP path has no CPU fallback')
+    return torch.device('cuda:0')
+
+
+def ops():
+    from discrete_mean_field_game_amd import ops as _ops
+    return _ops
+
+
+def O():
+    from oracle import mfg_oracle
+    return mfg_oracle
+
+
+def t32(x, dev):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32), device=dev)
+
+
+def t64(x, dev):
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64), device=dev)
+
+
+def rel(a, b, floor=0.0):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)) if a.size else 0.0
+
+
+def rand_case(rs, B, d, conc=1.0, pconc=1.0):
+    pi = rs.dirichlet(np.ones(d) * conc, size=B).astype(np.float32)
+    P = rs.dirichlet(np.ones(d) * pconc, size=(B, d)).astype(np.float32)
+    return pi, P
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_library_loaded_and_arch(dev):
+    from discrete_mean_field_game_amd import _lib as L
+    import ctypes as C
+    cu = C.c_int(0)
+    buf = C.create_string_buffer(64)
+    L.check(L.lib().mfg_device_info(C.byref(cu), buf, 64), 'mfg_device_info')
+    assert cu.value > 0 and buf.value.decode().startswith('gfx')
+
+
+def test_philox_bit_exact(dev):
+    from oracle.philox_ref import philox4x32_10
+    seed = 0x9E3779B97F4A7C15
+    out = ops().philox_raw(seed, 12345, 7, 0xDEADBEEF, 0x10002, 4096, dev).cpu().numpy().view(np.uint32)
+    ref = philox4x32_10(np.arange(12345, 12345 + 4096), 7, 0xDEADBEEF, 0x10002, seed & 0xFFFFFFFF, seed >> 32)
+    assert np.array_equal(out, np.stack(ref, axis=1))
+
+
+@pytest.mark.parametrize('d,B', [(3, 1), (3, 257), (4, 1000), (21, 1), (21, 13), (21, 4096), (32, 100), (47, 33),
+                                 (64, 50), (65, 7), (100, 9), (128, 64), (130, 5), (192, 6), (256, 32), (320, 3),
+                                 (512, 2)])
+@pytest.mark.parametrize('kind', [0, 1])
+def test_step_given_P(dev, d, B, kind):
+    rs = np.random.RandomState(d * 1000 + B)
+    pi, P = rand_case(rs, B, d)
+    pn, r = ops().step_given_P(t32(pi, dev), t32(P, dev), reward_kind=kind)
+    ref_pn = O().transition(P, pi)
+    ref_r = O().calc_reward(P, pi) if kind == 0 else O().calc_reward_synthetic(P, pi)
+    assert np.array_equal(pn.cpu().numpy(), ref_pn.astype(np.float32))   # fp64 accumulate, one rounding
+    # fp32 reward: 1e-5 relative (north star); fp64 accumulation gives ~6e-8 + cancellation-free
+    assert rel(r.cpu().numpy(), ref_r, floor=1e-30) < 1e-6
+
+
+def test_step_given_P_transition_only(dev):
+    rs = np.random.RandomState(3)
+    pi, P = rand_case(rs, 100, 21)
+    pn, r = ops().step_given_P(t32(pi, dev), t32(P, dev), want_reward=False)
+    assert r is None
+    assert np.array_equal(pn.cpu().numpy(), O().transition(P, pi).astype(np.float32))
+
+
+def test_reference_kats_on_device(dev):
+    k = np.load(os.path.join(G, 'kat_mfg_ac2.npz'))
+    # test2.py:46-56 reward KAT (P is not stochastic there: exercises the raw formula)
+    pn, r = ops().step_given_P(t32(k['reward_pi'][None], dev), t32(k['reward_P'][None], dev))
+    assert abs(float(r[0]) - (-39.07)) < 1e-5 * 39.07
+    # test2.py:73-88 value KAT
+    v = ops().value(t32(k['value_pi'][None], dev), t64(np.ones(10), dev))
+    assert abs(float(v[0]) - 2.77) < 1e-6
+    f = ops().features(t32(k['value_pi'][None], dev)).cpu().numpy()[0]
+    assert np.allclose(f, k['value_features'], rtol=1e-6)
+    # JSD KAT
+    j = ops().jsd(t32(k['jsd_p'][None], dev), t32(k['jsd_q'][None], dev))
+    assert abs(float(j[0]) - 0.34858446189521375) < 1e-6
+    # test2.py:105-121 gradient three-way KAT (seed 42 P captured from the reference)
+    theta = t64([10.0], dev)
+    g = ops().score(t32(k['grad_pi'][None], dev), t32(k['grad_P'][None], dev), theta, 0.4)
+    g_ref32 = O().calc_gradient(k['grad_P'].astype(np.float32), k['grad_pi'].astype(np.float32), 10.0, 0.4)
+    assert abs(float(g[0]) - g_ref32) < 1e-9 * abs(g_ref32)
+    assert abs(float(g[0]) - (-6.302201890992953)) < 1e-5 * 6.3          # vs fp64 inputs: fp32 storage of P
+    pn, r = ops().step_given_P(t32(k['grad_pi'][None], dev), t32(k['grad_P'][None], dev))
+    assert np.allclose(pn.cpu().numpy()[0], k['grad_pi_next'], rtol=1e-6)
+    assert abs(float(r[0]) - float(k['grad_reward'][0])) < 1e-5 * abs(float(k['grad_reward'][0]))
+
+
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(G, 'functions_cfg*.npz'))))
+def test_golden_functions_on_device(dev, path):
+    """Reference outputs (fp64 inputs) vs the device path on fp32-rounded inputs."""
+    z = np.load(path)
+    d, theta, shift = int(z['d']), float(z['theta']), float(z['shift'])
+    pi, P, w = z['pi'], z['P'], z['w'][:, 0]
+    th = t64([theta], dev)
+    a, ad = ops().alpha(t32(pi, dev), th, shift)
+    pi32 = pi.astype(np.float32)
+    assert rel(a.cpu().numpy(), O().calc_alpha(pi32, theta, shift), 1e-300) < 1e-12
+    assert np.max(np.abs(ad.cpu().numpy() - O().calc_alpha_deriv(pi32, theta, shift))) < 1e-14
+    pn, r = ops().step_given_P(t32(pi, dev), t32(P, dev))
+    assert np.allclose(pn.cpu().numpy(), z['pi_next'], rtol=2e-6, atol=1e-12)
+    v = ops().value(t32(pi, dev), t64(w, dev)).cpu().numpy()
+    assert np.allclose(v, z['value'], rtol=1e-6)
+    f = ops().features(t32(pi, dev)).cpu().numpy()
+    assert np.allclose(f, z['features'], rtol=1e-6, atol=1e-12)
+    # reward / gradient vs the oracle on the identical (fp32-rounded) inputs: the 1e-5 bar
+    P32 = P.astype(np.float32)
+    assert rel(r.cpu().numpy(), O().calc_reward(P32, pi32), 1e-30) < 1e-6
+    g = ops().score(t32(pi, dev), t32(P, dev), th, shift).cpu().numpy()
+    assert rel(g, O().calc_gradient(P32, pi32, theta, shift), 1e-30) < 1e-9
+    # and against the reference's own fp64 outputs (input rounding included)
+    assert rel(g, z['gradient'], 1e-30) < 1e-4
+
+
+@pytest.mark.parametrize('d,B', [(3, 50), (4, 64), (21, 1), (21, 200), (47, 20), (64, 9), (100, 6), (128, 8), (256, 3)])
+def test_td_pg_accumulate(dev, d, B):
+    rs = np.random.RandomState(17 + d + B)
+    pi, P = rand_case(rs, B, d)
+    theta, shift, gamma = 8.86349, 0.16, 0.9
+    w = rs.rand(O().num_features(d))
+    pn, r = ops().step_given_P(t32(pi, dev), t32(P, dev))
+    delta, g, Gv = ops().td_pg_accumulate(t32(pi, dev), pn, t32(P, dev), r, t64(w, dev), t64([theta], dev), shift, gamma)
+    pn_h = pn.cpu().numpy(); r_h = r.cpu().numpy()
+    rd, rg, rGw, rGt, rsum = O().batched_td_pg(pi, pn_h, P, r_h, w, theta, shift, gamma)
+    assert np.max(np.abs(delta.cpu().numpy() - rd)) < 1e-12 * max(1.0, np.max(np.abs(w)) * 4)
+    assert rel(g.cpu().numpy(), rg, 1e-30) < 1e-9
+    Gh = Gv.cpu().numpy()
+    F = O().num_features(d)
+    scale = np.max(np.abs(rGw)) + 1e-300
+    assert np.max(np.abs(Gh[:F] - rGw)) < 1e-11 * scale
+    assert abs(Gh[F] - rGt) < 1e-9 * max(1.0, abs(rGt))
+    assert abs(Gh[F + 1] - rsum) < 1e-9 * max(1e-12, abs(rsum)) + 1e-15
+    assert Gh[F + 2] == B
+    # accumulate=True adds on top
+    _, _, G2 = ops().td_pg_accumulate(t32(pi, dev), pn, t32(P, dev), r, t64(w, dev), t64([theta], dev), shift, gamma,
+                                      G=Gv.clone(), accumulate=True)
+    assert np.allclose(G2.cpu().numpy(), 2 * Gh, rtol=1e-12, atol=1e-300)
+
+
+def test_score_zero_probability_rule(dev):
+    """P == 0 counts as 1e-100 (mfg_ac2.py:369) and P is not modified."""
+    rs = np.random.RandomState(5)
+    pi, P = rand_case(rs, 4, 21)
+    P[:, 3, 5] = 0.0
+    Pd = t32(P, dev)
+    g = ops().score(t32(pi, dev), Pd, t64([8.86349], dev), 0.16).cpu().numpy()
+    assert rel(g, O().calc_gradient(P, pi, 8.86349, 0.16), 1e-30) < 1e-9
+    assert np.array_equal(Pd.cpu().numpy(), P)
+
+
+def test_dirichlet_from_gamma_and_gather(dev):
+    rs = np.random.RandomState(9)
+    y = rs.gamma(2.0, size=(5, 21, 21)).astype(np.float32)
+    y[0, 0, :3] = 0.0
+    P = ops().dirichlet_from_gamma(t32(y, dev)).cpu().numpy()
+    assert np.allclose(P, O().dirichlet_from_gamma(y), rtol=1e-6, atol=0)
+    assert P[0, 0, 0] > 0
+    mat = rs.dirichlet(np.ones(21), size=64).astype(np.float32)
+    idx = rs.randint(64, size=1000).astype(np.int32)
+    out = ops().gather_start(t32(mat, dev), torch.as_tensor(idx, device=dev)).cpu().numpy()
+    assert np.array_equal(out, mat[idx])                                  # index bookkeeping: bit exact
+
+
+def test_jsd_batched(dev):
+    rs = np.random.RandomState(10)
+    for d in (3, 21, 128):
+        p = rs.dirichlet(np.ones(d), size=50).astype(np.float32)
+        q = rs.dirichlet(np.ones(d), size=50).astype(np.float32)
+        p[0, 0] = 0.0
+        out = ops().jsd(t32(p, dev), t32(q, dev)).cpu().numpy()
+        assert np.allclose(out, O().JSD(p, q), rtol=1e-9, atol=1e-15)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Sampler: distributional checks + invariants (RNG bit-parity with MT19937 is impossible by design)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('d', [4, 21, 128])
+def test_sampler_invariants_and_moments(dev, d):
+    rs = np.random.RandomState(d)
+    theta, shift, scale = 8.86349, 0.16, 12000.0
+    pi1 = rs.dirichlet(np.ones(d)).astype(np.float32)
+    B = 4096 if d <= 21 else 256
+    pi = np.repeat(pi1[None], B, 0)
+    P = ops().sample_dirichlet(t32(pi, dev), t64([theta], dev), shift, scale, seed=123, step=3).cpu().numpy().astype(np.float64)
+    assert np.all(P > 0) and np.all(np.isfinite(P))
+    assert np.max(np.abs(P.sum(-1) - 1)) < 5e-7                          # rows are stochastic (test2.py:14-32)
+    al = O().calc_alpha(pi1, theta, shift) * scale
+    mean = al / al.sum(-1, keepdims=True)
+    A = al.sum(-1, keepdims=True)
+    var = mean * (1 - mean) / (A + 1)
+    se = np.sqrt(var / B)
+    zscore = (P.mean(0) - mean) / np.maximum(se, 1e-30)
+    assert np.max(np.abs(zscore)) < 6.0
+    ratio = P.var(0) / np.maximum(var, 1e-300)
+    big = mean > 1e-3
+    assert np.all(ratio[big] > 0.7) and np.all(ratio[big] < 1.4)
+    # determinism + counter semantics
+    P2 = ops().sample_dirichlet(t32(pi, dev), t64([theta], dev), shift, scale, seed=123, step=3).cpu().numpy()
+    assert np.array_equal(P2, P.astype(np.float32))
+    P3 = ops().sample_dirichlet(t32(pi, dev), t64([theta], dev), shift, scale, seed=123, step=4).cpu().numpy()
+    assert not np.array_equal(P3, P2)
+    # world-size invariance: trajectories [B/2, B) drawn as a separate shard with traj_offset
+    h = B // 2
+    Ps = ops().sample_dirichlet(t32(pi[h:], dev), t64([theta], dev), shift, scale, seed=123, step=3,
+                                traj_offset=h).cpu().numpy()
+    assert np.array_equal(Ps, P2[h:])
+
+
+def test_sampler_small_shape_regime(dev):
+    """Shapes < 1 (boosted Marsaglia-Tsang) : one dominant topic makes alpha*scale ~ 0.4."""
+    d = 21
+    pi1 = np.full(d, 0.1 / (d - 1), dtype=np.float32); pi1[0] = 0.9
+    B = 8192
+    pi = np.repeat(pi1[None], B, 0)
+    theta, shift, scale = 8.86349, 0.16, 12000.0
+    P = ops().sample_dirichlet(t32(pi, dev), t64([theta], dev), shift, scale, seed=7).cpu().numpy().astype(np.float64)
+    al = O().calc_alpha(pi1, theta, shift) * scale
+    assert al.min() < 1.0
+    mean = al / al.sum(-1, keepdims=True)
+    var = mean * (1 - mean) / (al.sum(-1, keepdims=True) + 1)
+    z = (P.mean(0) - mean) / np.sqrt(var / B)
+    assert np.max(np.abs(z)) < 6.0
+    assert np.all(P > 0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Fused rollout vs the oracle replaying the SAME sampled actions
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('d,B,T', [(4, 37, 5), (21, 1, 15), (21, 100, 15), (47, 9, 4), (100, 5, 3), (128, 6, 3),
+                                   (256, 2, 2)])
+@pytest.mark.parametrize('discount_pow', [False, True])
+def test_rollout_fused_vs_oracle(dev, d, B, T, discount_pow):
+    rs = np.random.RandomState(31 + d + B)
+    theta, shift, scale, gamma = 8.86349, 0.16, 12000.0, 0.9
+    pi0 = rs.dirichlet(np.ones(d), size=B).astype(np.float32)
+    w = rs.rand(O().num_features(d))
+    out = ops().rollout(t32(pi0, dev), T, t64([theta], dev), shift, scale, w=t64(w, dev), gamma=gamma, seed=99,
+                        first_step=5, traj_offset=1000, td=True, write_P=True, discount_pow=discount_pow)
+    P = out['P'].cpu().numpy()
+    assert np.max(np.abs(P.astype(np.float64).sum(-1) - 1)) < 5e-7
+    traj, R, D, Gs, G_w, G_theta = O().batched_rollout_given_P(
+        pi0, P, w, theta, shift, gamma=gamma, variant='ac_irl' if discount_pow else 'mfg_ac2')
+    assert np.allclose(out['pi_traj'].cpu().numpy(), traj, rtol=3e-7, atol=1e-12)   # <= 2 ulp fp32 per step
+    # oracle replays from the kernel's own fp32 states so that per-step quantities are comparable at 1e-5
+    pt = out['pi_traj'].cpu().numpy().astype(np.float64)
+    r_ref = np.stack([O().calc_reward(P[:, t].astype(np.float64), pt[:, t]) for t in range(T)], 1)
+    assert rel(out['reward'].cpu().numpy(), r_ref, 1e-30) < 1e-6
+    g_ref = np.stack([O().calc_gradient(P[:, t], pt[:, t], theta, shift) for t in range(T)], 1)
+    assert rel(out['g'].cpu().numpy(), g_ref, 1e-30) < 1e-5
+    phi = O().calc_features(pt)
+    V = phi.dot(w)
+    disc = gamma ** np.arange(T) if discount_pow else np.full(T, gamma)
+    r_dev = out['reward'].cpu().numpy().astype(np.float64)
+    d_ref = r_dev + disc[None] * V[:, 1:] - V[:, :-1]
+    assert np.max(np.abs(out['delta'].cpu().numpy() - d_ref)) < 1e-11 * max(1.0, np.abs(V).max())
+    # batch sums
+    Gh = out['G'].cpu().numpy()
+    F = O().num_features(d)
+    dl = out['delta'].cpu().numpy(); gg = out['g'].cpu().numpy()
+    Gw_ref = np.einsum('bt,btf->f', dl, phi[:, :T])
+    assert np.max(np.abs(Gh[:F] - Gw_ref)) < 1e-11 * (np.abs(Gw_ref).max() + 1e-300)
+    assert abs(Gh[F] - np.sum(dl * gg)) < 1e-10 * max(1.0, abs(np.sum(dl * gg)))
+    assert abs(Gh[F + 1] - r_dev.sum()) < 1e-10 * max(1e-9, abs(r_dev.sum()))
+    assert Gh[F + 2] == B * T
+    # the unfused pipeline on the same actions agrees with the fused kernel
+    pn, r1 = ops().step_given_P(out['pi_traj'][:, 0].contiguous(), out['P'][:, 0].contiguous())
+    assert np.array_equal(pn.cpu().numpy(), out['pi_traj'][:, 1].cpu().numpy())
+    assert rel(r1.cpu().numpy(), out['reward'][:, 0].cpu().numpy(), 1e-30) < 1e-6
+    # sampler consistency: the standalone sampler with the same counters draws the same P
+    P0 = ops().sample_dirichlet(t32(pi0, dev), t64([theta], dev), shift, scale, seed=99, step=5, traj_offset=1000)
+    assert np.array_equal(P0.cpu().numpy(), P[:, 0])
+
+
+def test_rollout_env_only_matches_td_rollout(dev):
+    rs = np.random.RandomState(77)
+    d, B, T = 21, 64, 15
+    pi0 = rs.dirichlet(np.ones(d), size=B).astype(np.float32)
+    th = t64([8.86349], dev)
+    w = t64(rs.rand(O().num_features(d)), dev)
+    a = ops().rollout(t32(pi0, dev), T, th, 0.16, 12000.0, w=w, seed=1, td=True)
+    b = ops().rollout(t32(pi0, dev), T, th, 0.16, 12000.0, seed=1, td=False)
+    assert np.array_equal(a['pi_traj'].cpu().numpy(), b['pi_traj'].cpu().numpy())
+    assert np.array_equal(a['reward'].cpu().numpy(), b['reward'].cpu().numpy())
+
+
+def test_apply_update_batch1_equals_reference_increment(dev):
+    """B = 1: G / count is exactly (delta*phi, delta*g), so the update is the reference's (mfg_ac2.py:511-522)."""
+    z = np.load(os.path.join(G, 'train_mfg_ac2_c1_g1.npz'))
+    pi, P = z['pi'][0][None], z['P'][0][None]
+    w0 = z['w0'][:, 0].copy(); theta0 = float(z['theta0'])
+    th = t64([theta0], dev); w = t64(w0, dev)
+    pn, r = ops().step_given_P(t32(pi, dev), t32(P, dev))
+    delta, g, Gv = ops().td_pg_accumulate(t32(pi, dev), pn, t32(P, dev), r, w, th, float(z['shift']), 1.0)
+    ops().apply_update(Gv, 21, 0.1, 0.001, w, th)
+    # reference: theta after the first step of the constant-lr trace
+    assert abs(float(th[0]) - float(z['theta_before'][1])) < 2e-6 * abs(float(z['theta_before'][1]) - theta0) + 1e-12
+    _, d_ref, g_ref, w_ref, th_ref = O().ac_step(pi[0].astype(np.float32).astype(np.float64),
+                                                P[0].astype(np.float32).astype(np.float64),
+                                                float(r[0]), w0.reshape(-1, 1), theta0, float(z['shift']), 1.0, 0.1, 0.001)
+    assert abs(float(th[0]) - float(np.ravel(th_ref)[0])) < 1e-12
+    assert np.max(np.abs(w.cpu().numpy() - w_ref[:, 0])) < 1e-9
+
+
+def test_error_paths(dev):
+    from discrete_mean_field_game_amd import _lib as L
+    pi = torch.zeros(2, 600, device=dev)
+    P = torch.zeros(2, 600, 600, device=dev)
+    with pytest.raises(L.MfgError):
+        ops().step_given_P(pi, P)                                         # d > MFG_MAX_D
+    # B = 0 is a no-op
+    pn, r = ops().step_given_P(torch.zeros(0, 21, device=dev), torch.zeros(0, 21, 21, device=dev))
+    assert pn.shape == (0, 21) and r.shape == (0,)
