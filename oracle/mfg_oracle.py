@@ -414,7 +414,7 @@ def batched_td_pg(pi, pi_next, P, reward, w, theta, shift, gamma_or_discount):
     g = calc_gradient(P, pi, theta, shift)
     G_w = np.einsum('b,bf->f', delta, phi)
     G_theta = float(np.sum(delta * g))
-    return delta, g, G_w, G_theta, float(np.sum(reward))
+    return delta, g, G_w, G_theta, float(np.sum(np.asarray(reward, dtype=np.float64)))
 
 
 def batched_rollout_given_P(pi0, P_seq, w, theta, shift, gamma=1.0, variant='mfg_ac2',

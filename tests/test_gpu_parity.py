@@ -125,7 +125,7 @@ def test_golden_functions_on_device(dev, path):
     th = t64([theta], dev)
     a, ad = ops().alpha(t32(pi, dev), th, shift)
     pi32 = pi.astype(np.float32)
-    assert rel(a.cpu().numpy(), O().calc_alpha(pi32, theta, shift), 1e-300) < 1e-12
+    assert rel(a.cpu().numpy(), O().calc_alpha(pi32, theta, shift), 1e-300) < 1e-9    # reference: log(1+e) (3e-12 rel. rounding at alpha~3e-5), kernel: log1p(e)
     assert np.max(np.abs(ad.cpu().numpy() - O().calc_alpha_deriv(pi32, theta, shift))) < 1e-14
     pn, r = ops().step_given_P(t32(pi, dev), t32(P, dev))
     assert np.allclose(pn.cpu().numpy(), z['pi_next'], rtol=2e-6, atol=1e-12)
@@ -209,7 +209,7 @@ def test_sampler_invariants_and_moments(dev, d):
     rs = np.random.RandomState(d)
     theta, shift, scale = 8.86349, 0.16, 12000.0
     pi1 = rs.dirichlet(np.ones(d)).astype(np.float32)
-    B = 4096 if d <= 21 else 256
+    B = 4096 if d <= 21 else 1024
     pi = np.repeat(pi1[None], B, 0)
     P = ops().sample_dirichlet(t32(pi, dev), t64([theta], dev), shift, scale, seed=123, step=3).cpu().numpy().astype(np.float64)
     assert np.all(P > 0) and np.all(np.isfinite(P))
@@ -221,9 +221,10 @@ def test_sampler_invariants_and_moments(dev, d):
     se = np.sqrt(var / B)
     zscore = (P.mean(0) - mean) / np.maximum(se, 1e-30)
     assert np.max(np.abs(zscore)) < 6.0
-    ratio = P.var(0) / np.maximum(var, 1e-300)
+    ratio = P.var(0, ddof=1) / np.maximum(var, 1e-300)
     big = mean > 1e-3
-    assert np.all(ratio[big] > 0.7) and np.all(ratio[big] < 1.4)
+    tol = 6.5 * np.sqrt(2.0 / (B - 1))                                     # chi-square spread of a sample variance
+    assert np.all(np.abs(ratio[big] - 1) < tol)
     # determinism + counter semantics
     P2 = ops().sample_dirichlet(t32(pi, dev), t64([theta], dev), shift, scale, seed=123, step=3).cpu().numpy()
     assert np.array_equal(P2, P.astype(np.float32))
@@ -239,7 +240,7 @@ def test_sampler_invariants_and_moments(dev, d):
 def test_sampler_small_shape_regime(dev):
     """Shapes < 1 (boosted Marsaglia-Tsang) : one dominant topic makes alpha*scale ~ 0.4."""
     d = 21
-    pi1 = np.full(d, 0.1 / (d - 1), dtype=np.float32); pi1[0] = 0.9
+    pi1 = np.zeros(d, dtype=np.float32); pi1[0] = 1.0                     # one-hot start (test2.py:63-64)
     B = 8192
     pi = np.repeat(pi1[None], B, 0)
     theta, shift, scale = 8.86349, 0.16, 12000.0
@@ -281,7 +282,7 @@ def test_rollout_fused_vs_oracle(dev, d, B, T, discount_pow):
     V = phi.dot(w)
     disc = gamma ** np.arange(T) if discount_pow else np.full(T, gamma)
     r_dev = out['reward'].cpu().numpy().astype(np.float64)
-    d_ref = r_dev + disc[None] * V[:, 1:] - V[:, :-1]
+    d_ref = r_ref + disc[None] * V[:, 1:] - V[:, :-1]                   # the kernel bootstraps with its fp64 reward
     assert np.max(np.abs(out['delta'].cpu().numpy() - d_ref)) < 1e-11 * max(1.0, np.abs(V).max())
     # batch sums
     Gh = out['G'].cpu().numpy()
@@ -324,11 +325,12 @@ def test_apply_update_batch1_equals_reference_increment(dev):
     ops().apply_update(Gv, 21, 0.1, 0.001, w, th)
     # reference: theta after the first step of the constant-lr trace
     assert abs(float(th[0]) - float(z['theta_before'][1])) < 2e-6 * abs(float(z['theta_before'][1]) - theta0) + 1e-12
-    _, d_ref, g_ref, w_ref, th_ref = O().ac_step(pi[0].astype(np.float32).astype(np.float64),
-                                                P[0].astype(np.float32).astype(np.float64),
-                                                float(r[0]), w0.reshape(-1, 1), theta0, float(z['shift']), 1.0, 0.1, 0.001)
-    assert abs(float(th[0]) - float(np.ravel(th_ref)[0])) < 1e-12
-    assert np.max(np.abs(w.cpu().numpy() - w_ref[:, 0])) < 1e-9
+    # oracle on the identical fp32 inputs (pi, P, the kernel's fp32 pi' and reward)
+    pi32, P32 = pi.astype(np.float32), P.astype(np.float32)
+    rd, rg, rGw, rGt, _ = O().batched_td_pg(pi32, pn.cpu().numpy(), P32, r.cpu().numpy(), w0, theta0,
+                                            float(z['shift']), 1.0)
+    assert abs(float(th[0]) - (theta0 + 0.001 * rGt)) < 1e-12
+    assert np.max(np.abs(w.cpu().numpy() - (w0 + 0.1 * rGw))) < 1e-13
 
 
 def test_error_paths(dev):
