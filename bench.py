@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec for batched d-bin population rollouts (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W            (N == 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W    (N > 1, one rank per GPU, RCCL)
+
+One bench "step" = one full training rollout of the forward-RL actor-critic (mfg_ac2.train semantics,
+update_every='rollout') over the rank's trajectory batch, with everything resident in HBM:
+    start-state gather -> fused T-step rollout kernel (Dirichlet action sampling, pi' = P^T pi,
+    reward, value, TD error, score) -> batch gradient sums -> [one RCCL all-reduce of the fused
+    gradient buffer when N > 1] -> (theta, w) update on device.
+value = (ranks * B * T * K) / max-over-ranks wall time between barriers.  Weak scaling: the per-GPU
+batch is fixed (default 65536, the north-star target point d=21, T=15).
+
+The same JSON line carries
+  roofline     : the HBM-bound given-P kernel (transition + reward over materialised actions; the fused
+                 rollout never sends P through HBM), timed live with events on the
+                 launch stream over B*T transitions (P slab > L3), algorithmic bytes 4(d^2+2d+1)/step;
+  fused_kernel : per-launch time of the fused rollout kernel (compute bound: transcendental + RNG);
+  cpu_baseline : the NumPy restatement of the reference loop (oracle/, batch 1, 1 thread) timed on
+                 this box's host cores on a bounded sample (rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable copy rate
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--d', type=int, default=21)
+    ap.add_argument('--T', type=int, default=15)
+    ap.add_argument('--batch', type=int, default=65536, help='trajectories per GPU')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline leg')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(d, budget_s):
+    """Reference-faithful leg: oracle train loop, batch 1, one thread (kind 'port')."""
+    from oracle import mfg_oracle as O
+    # calibrate on a few episodes, then run a bounded sample
+    n, t = O.cpu_baseline_steps(d, 45)
+    rate = n / t
+    steps = int(max(150, min(rate * budget_s, 60000)) // 15 * 15)
+    n, t = O.cpu_baseline_steps(d, steps)
+    return {'value': n / t, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'port',
+            'sample': 'oracle.train_mfg_ac2 (NumPy restatement of mfg_ac2.train, batch 1, 1 thread): %d env-steps '
+                      'of d=%d, T=15 in %.1f s on %d host cores available' % (n, d, t, os.cpu_count() or 1)}
+
+
+def pmc_traffic(kernel_prefix, d, T, B):
+    """HBM bytes per launch of `kernel_prefix` from the newest committed rocprofv3 --pmc summary
+    (profiles/rNN_pmc_traffic.json, written by tools/summarize_pmc.py) if it was taken at this shape."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
+        try:
+            z = json.load(open(path))
+        except Exception:
+            continue
+        sh = z.get('shape', {})
+        if (sh.get('d'), sh.get('T'), sh.get('B')) != (d, T, B):
+            continue
+        for name, e in z.get('kernels', {}).items():
+            if name.startswith(kernel_prefix):
+                return e.get('hbm_bytes_per_launch'), os.path.basename(path)
+    return None, None
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from discrete_mean_field_game_amd import ops, _lib
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    _lib.lib()  # fail loudly if the extension is missing
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    d, T = args.d, args.T
+    B = args.batch if args.scaling == 'weak' else args.batch // world
+    F = ops.num_features(d)
+    theta0, shift, alpha_scale, gamma = 8.86349, 0.16, 12000.0, 1.0      # mfg_ac2.py:832
+    lr_c, lr_a = 0.1, 0.001                                              # mfg_ac2.py:448
+
+    # synthetic workload: 64 Dirichlet(1) start states rounded through '%.3e' text
+    rs = np.random.RandomState(0)
+    mat = rs.dirichlet(np.ones(d), size=64)
+    mat = np.array([[float('%.3e' % v) for v in row] for row in mat], dtype=np.float32)
+    mat_pi0 = torch.as_tensor(mat, device=dev)
+    idx = torch.as_tensor(np.random.RandomState(1234 + rank).randint(64, size=B).astype(np.int32), device=dev)
+    w = torch.as_tensor(np.random.RandomState(1).rand(F), device=dev)    # U[0,1)^F, mfg_ac2.py:176
+    theta = torch.tensor([theta0], dtype=torch.float64, device=dev)
+    G = torch.zeros(F + 3, dtype=torch.float64, device=dev)
+    ws = ops.workspace(B * T, d, dev)
+    bufs = {'pi_traj': torch.empty(B, T + 1, d, device=dev), 'reward': torch.empty(B, T, device=dev),
+            'delta': torch.empty(B, T, dtype=torch.float64, device=dev),
+            'g': torch.empty(B, T, dtype=torch.float64, device=dev)}
+    traj_offset = rank * B
+
+    def one_step(k):
+        pi0 = ops.gather_start(mat_pi0, idx)
+        ops.rollout(pi0, T, theta, shift, alpha_scale, w=w, gamma=gamma, seed=2024, first_step=k * T,
+                    traj_offset=traj_offset, td=True, G=G, ws=ws, out=bufs)
+        if world > 1:
+            dist.all_reduce(G)                                           # one RCCL all-reduce per update
+        sc = 1.0 / (k + 1)
+        sa = 1.0 / ((k + 1) * np.log(np.log(k + 20)))                    # mfg_ac2.py:514,522
+        ops.apply_update(G, d, lr_c * sc, lr_a * sa, w, theta)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        one_step(k)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, args.warmup + args.steps):
+        one_step(k)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te[0])
+    theta_end = float(theta[0])
+    if not np.isfinite(theta_end):
+        sys.exit('non-finite theta after the timed region')
+    value = world * B * T * args.steps / elapsed
+
+    def event_time(fn, n, warm=2):
+        for _ in range(warm):
+            fn()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / n
+
+    out = None
+    if rank == 0:
+        bytes_per_step = 4 * (d * d + 2 * d + 1)                         # SURVEY.md 8d / BASELINE.md 3
+        pi0 = ops.gather_start(mat_pi0, idx)
+        roofline = None
+        fused = None
+        if not args.no_roofline:
+            # materialise the actions of one rollout (B*T transitions, > L3 at the default size)
+            N = B * T
+            r = ops.rollout(pi0, T, theta, shift, alpha_scale, seed=7, traj_offset=traj_offset, td=False, write_P=True)
+            P_all = r['P'].view(N, d, d)
+            pi_all = r['pi_traj'][:, :T].contiguous().view(N, d)
+            n_launch = 20
+            t_step = event_time(lambda: ops.step_given_P(pi_all, P_all), n=n_launch)
+            achieved = N * bytes_per_step / t_step / 1e9
+            traffic, traffic_src = pmc_traffic('k_step_small' if d <= 64 else 'k_step_large', d, T, B)
+            roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                        'kernel': 'k_step_small' if d <= 64 else 'k_step_large',
+                        'leg': 'given-P transition+reward over %d transitions (P slab %.2f GB)' % (N, N * d * d * 4 / 1e9),
+                        'algorithmic_bytes_per_launch': N * bytes_per_step, 'avg_launch_us': t_step * 1e6,
+                        'env_steps_per_s': N / t_step}
+            del P_all, pi_all, r
+            t_f = event_time(lambda: ops.rollout(pi0, T, theta, shift, alpha_scale, w=w, gamma=gamma, seed=7,
+                                                 traj_offset=traj_offset, td=True, G=G, ws=ws, out=bufs), n=5, warm=1)
+            fused = {'kernel': 'k_core_small<SAMPLE,TD>+grad' if d <= 64 else 'k_core_large<SAMPLE,TD>+grad',
+                     'bound': 'valu/transcendental+rng (P stays on chip)', 'avg_launch_ms': t_f * 1e3,
+                     'env_steps_per_s': B * T / t_f, 'hbm_algorithmic_GBs': B * T * bytes_per_step / t_f / 1e9}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(d, args.cpu_seconds)
+        out = {
+            'metric': 'env-steps/sec for batched d-bin population rollouts', 'value': value, 'unit': 'env-steps/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32 storage / f64 accumulate',
+            'data': 'synthetic',
+            'config': {'workload': 'forward-RL actor-critic training rollouts (mfg_ac2.train, update per rollout): '
+                                   'd=%d topics, T=%d, batch=%d trajectories per GPU' % (d, T, B),
+                       'd': d, 'T': T, 'batch_per_gpu': B, 'global_batch': B * world,
+                       'theta0': theta0, 'shift': shift, 'alpha_scale': alpha_scale, 'rng': 'philox4x32-10',
+                       'parallelism': 'trajectory-sharded x%d, 1 all-reduce/update' % world},
+            'theta_end': theta_end,
+            'roofline': roofline, 'fused_kernel': fused, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
