@@ -1,0 +1,326 @@
+"""Drop-in ``AC_IRL`` with the call surface of the reference's ``ac_irl.AC_IRL`` (ac_irl.py:31):
+max-ent IRL (guided cost learning) around the same actor-critic, batched on the GPU.
+
+The NumPy hot-path methods of the reference class are the mfg_ac2 ones minus calc_reward; here they are
+inherited from :class:`discrete_mean_field_game_amd.mfg_ac2.actor_critic` (HIP kernels).  What differs, and
+is kept:
+  * reward of a transition = reward network r(pi, P) (ac_irl.py:683) -> one batched PyTorch forward over
+    [B,d,d] actions per env step; dropout stays active there like in the reference;
+  * TD error bootstraps with the running ``discount = gamma**t`` (ac_irl.py:691, :710);
+  * episodes are 1-indexed in the learning-rate schedule (ac_irl.py:649, :700, :708);
+  * early stop on |theta - prev_theta| < stop_criteria (:726) and the list_policies FIFO (:731);
+  * update_reward / reward_iteration / outerloop (ac_irl.py:804-954) with the loss of :390-413, Adam 1e-4.
+TensorFlow is replaced by PyTorch-ROCm (networks.RewardNet); ``use_tf`` is accepted and means "build the
+reward network".  Disk inputs are optional: pass ``pi0`` / ``pi0_test`` / ``demonstrations`` arrays, or
+let the constructor read the reference's directories when they exist.
+"""
+from __future__ import annotations
+
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+from .mfg_ac2 import EPISODE_STEPS, actor_critic
+from .networks import RewardNet, maxent_irl_loss
+from .parallel import all_reduce_gradients_, current_shard, lr_scales
+
+
+class AC_IRL(actor_critic):
+
+    def __init__(self, theta=8.64, shift=0, alpha_scale=1e4, d=15, lr_reward=1e-4, num_policies=10, c=2e11,
+                 reg='dropout_l1l2', n_fc3=8, n_fc4=4, saved_network=None, use_tf=True, summarize=False, *,
+                 pi0=None, pi0_test=None, demonstrations=None, demonstrations_test=None, batch=1, rng='philox',
+                 seed=0, update_every='step', device=None, group=None, verbose=1):
+        super().__init__(theta=theta, shift=shift, alpha_scale=alpha_scale, d=d, pi0=pi0, batch=batch, rng=rng,
+                         seed=seed, update_every=update_every, device=device, group=group, verbose=verbose)
+        self.summarize = summarize
+        self.theta_initial = theta                      # reset value used by outerloop (ac_irl.py:45, :942)
+        self.lr_reward = lr_reward
+        self.num_policies = num_policies
+        self.c = c
+        self.reg = reg
+        self.n_fc3 = n_fc3
+        self.n_fc4 = n_fc4
+        if pi0_test is not None:
+            self.mat_pi0_test = np.array(pi0_test, dtype=np.float64)[:, 0:d]
+        elif os.path.isdir(os.getcwd() + '/test_normalized_round2'):
+            self.init_pi0_test(path_to_dir=os.getcwd() + '/test_normalized_round2', day_start=22)
+        else:
+            self.mat_pi0_test = self.mat_pi0.copy()
+        self.num_start_samples_test = self.mat_pi0_test.shape[0]
+        if demonstrations is not None:
+            self.list_demonstrations = demonstrations
+        elif os.path.isdir('./actions_2') and os.path.isdir('./train_normalized_round2'):
+            self.list_demonstrations = self.read_demonstrations('./train_normalized_round2', './actions_2', 20, 1)
+        else:
+            self.list_demonstrations = []
+        if demonstrations_test is not None:
+            self.list_demonstrations_test = demonstrations_test
+        elif os.path.isdir('./actions_test_2') and os.path.isdir('./test_normalized_round2'):
+            self.list_demonstrations_test = self.read_demonstrations('./test_normalized_round2', './actions_test_2', 20, 22)
+        else:
+            self.list_demonstrations_test = []
+        self.list_eval_demo_transitions = [pair for traj in self.list_demonstrations for pair in traj]
+        self.list_generated = []                         # D_samp of the IRL algorithm (ac_irl.py:79)
+        self.num_demo_samples = 5
+        self.num_gen_samples = 5
+        self.num_sampled_trajectories = self.num_gen_samples
+        self.list_policies = [theta] * self.num_policies
+        self.reward_update_count = 0
+        self.reward_net = None
+        if use_tf:
+            self.create_network()
+            self.create_training_method()
+            if saved_network:
+                self.reward_net.load_state_dict(torch.load('saved/' + saved_network, map_location=self.device))
+
+    # ------------------------------------------------------------------ data (next rows, ac_irl.py:164-200)
+    def init_pi0_test(self, path_to_dir, day_start=22, verbose=0):
+        rows = []
+        num_files = len(os.listdir(path_to_dir))
+        for num_day in range(day_start, day_start + num_files):
+            with open(path_to_dir + '/trend_distribution_day%d.csv' % num_day, 'r') as f:
+                first = f.readline()
+            rows.append(list(map(float, first.strip().split(' ')))[0:self.d])
+        self.mat_pi0_test = np.array(rows, dtype=np.float64)
+
+    def read_demonstrations(self, state_dir, action_dir, dim_action=20, start_day=1):
+        """list of trajectories, each a list of 15 (state [d], action [d,d]) pairs (ac_irl.py:164-200).
+        State files: 16 rows x >= d; action files: 15 blocks of dim_action rows (blank lines skipped)."""
+        num_file_action = len(os.listdir(action_dir))
+        out = []
+        for idx_day in range(start_day, start_day + num_file_action):
+            states = np.loadtxt(state_dir + '/trend_distribution_day%d.csv' % idx_day, delimiter=' ', ndmin=2)
+            actions = np.loadtxt(action_dir + '/action_day%d.txt' % idx_day, delimiter=' ', ndmin=2)
+            traj = []
+            for hour in range(0, 15):
+                state = states[hour, 0:self.d]
+                action = actions[hour * dim_action:(hour * dim_action + self.d), 0:self.d]
+                traj.append((state, action))
+            out.append(traj)
+        return out
+
+    def get_eval_transitions(self, list_trajectories):
+        """One (s,a) per trajectory: index = trajectory index mod 15 (ac_irl.py:203-219)."""
+        return [traj[idx % 15] for idx, traj in enumerate(list_trajectories)]
+
+    # ------------------------------------------------------------------ reward network (ac_irl.py:232-267, :382-427)
+    def create_network(self):
+        self.reward_net = RewardNet(d=self.d, reg=self.reg, f1=1, k1=5, f2=2, k2=3, n_fc3=self.n_fc3,
+                                    n_fc4=self.n_fc4).to(self.device)
+
+    def create_training_method(self):
+        self.optimizer = torch.optim.Adam(self.reward_net.parameters(), lr=self.lr_reward)
+
+    def _pairs_to_tensors(self, pairs):
+        s = torch.as_tensor(np.array([np.asarray(p[0], dtype=np.float32) for p in pairs]), device=self.device)
+        a = torch.as_tensor(np.array([np.asarray(p[1], dtype=np.float32) for p in pairs]), device=self.device)
+        return s, a
+
+    def reward(self, pi, P):
+        """r(pi, P) from the reward network: [B,d], [B,d,d] -> [B] (ac_irl.py:683)."""
+        with torch.no_grad():
+            return self.reward_net(pi, P).reshape(-1).float().contiguous()
+
+    def calc_alpha_deriv(self, pi):
+        """d alpha / d theta for state pi (ac_irl.py:573-588); stored like the reference."""
+        pi_dev, single = self._pi_dev(pi)
+        _, ad = ops.alpha(pi_dev, self._theta, self.shift, want_alpha=False)
+        ad = ad.cpu().numpy()
+        self._alpha_deriv_host = ad[0] if single else ad
+        return self._alpha_deriv_host
+
+    # ------------------------------------------------------------------ a9 (IRL flavour)
+    def train(self, max_episodes=4000, stop_criteria=0.01, gamma=1, constant=False, lr_critic=0.1, lr_actor=0.001,
+              consecutive=100, file_theta='results/theta.csv', file_pi='results/pi.csv',
+              file_reward='results/reward.csv', write_file=0, write_all=0, reward_fn=None):
+        """Forward actor-critic under the learned reward (ac_irl.py:634-732).  ``reward_fn(pi, P) -> [B]``
+        overrides the reward network (used by the parity tests with a closed-form reward)."""
+        d, T = self.d, EPISODE_STEPS
+        if self.verbose:
+            print('----- Starting train -----')
+        shard = current_shard(self.batch, self.group)
+        F = ops.num_features(d)
+        G = torch.zeros(F + 3, dtype=torch.float64, device=self.device)
+        ws = ops.workspace(shard.local_batch, d, self.device)
+        rfn = reward_fn if reward_fn is not None else self.reward
+        prev_theta = float(self._theta.cpu()[0])
+        list_reward = []
+        episode = 0
+        pi = None
+        for episode in range(1, max_episodes + 1):
+            pi = ops.gather_start(self._mat_pi0_dev, self._draw_start(shard))
+            discount = 1.0
+            total_reward = torch.zeros((), dtype=torch.float64, device=self.device)
+            sc, sa = lr_scales(episode, constant)          # lr/(episode+1) with the 1-indexed episode (:700)
+            for step in range(T):
+                P = self._sample(pi, shard.traj_offset)
+                if write_all:
+                    self._write_all(pi, P, step + 1)
+                pi_next, _ = ops.step_given_P(pi, P, want_reward=False)
+                r = rfn(pi, P)
+                ops.td_pg_accumulate(pi, pi_next, P, r, self._w, self._theta, self.shift, discount, G=G, ws=ws,
+                                     accumulate=(self.update_every == 'rollout' and step > 0))
+                if self.update_every == 'step':
+                    all_reduce_gradients_(G, self.group)
+                    ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta)
+                    total_reward += G[F + 1] / G[F + 2]
+                    self._theta_is_array = True
+                    if self.trace is not None:
+                        self.trace.append(float(self._theta.cpu()[0]))
+                discount = discount * gamma
+                pi = pi_next
+            if self.update_every == 'rollout':
+                all_reduce_gradients_(G, self.group)
+                ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta)
+                total_reward = G[F + 1] / G[F + 2] * T
+                self._theta_is_array = True
+            list_reward.append(total_reward)
+            if episode % consecutive == 0:
+                reward_avg = float(torch.stack(list_reward).sum().cpu()) / consecutive
+                list_reward = []
+                pi_host = pi[0].cpu().numpy().astype(np.float64)
+                if self.verbose:
+                    print('Theta\n', self.theta)
+                    print('pi\n', pi_host)
+                    print('Average reward during previous %d episodes: ' % consecutive, str(reward_avg))
+                if write_file:
+                    self.train_log(np.ravel(self.theta), file_theta, '%.5e')
+                    self.train_log(pi_host, file_pi, '%.3e')
+                    self.train_log(np.array([reward_avg]), file_reward, '%.3e')
+            if stop_criteria != -1:
+                cur = float(self._theta.cpu()[0])
+                if abs(cur - prev_theta) < stop_criteria:
+                    break
+                prev_theta = cur
+        self.list_policies = (self.list_policies + [self.theta])[1:]            # record this policy (:731)
+        self.episodes_run = episode
+        if self.verbose:
+            print('----- Exiting train at episode %d with theta %f -----' % (episode, float(np.ravel(self.theta)[0])))
+
+    # ------------------------------------------------------------------ a10
+    def generate_trajectories(self, n, from_test=False):
+        """n trajectories of 15 (state, action) pairs under the current policy (ac_irl.py:735-767)."""
+        mat_dev = self._mat_pi0_dev
+        num = self.num_start_samples
+        if from_test:
+            mat_dev = torch.as_tensor(np.ascontiguousarray(self.mat_pi0_test, dtype=np.float32), device=self.device)
+            num = self.num_start_samples_test
+        T = 15
+        if self.rng == 'numpy':
+            out = []
+            for _ in range(n):                                 # the reference's interleaved RNG order
+                idx = torch.as_tensor(np.array([np.random.randint(num)], dtype=np.int32), device=self.device)
+                pi = ops.gather_start(mat_dev, idx)
+                traj = []
+                for _h in range(T):
+                    P = self._sample(pi)
+                    traj.append((pi[0].cpu().numpy().astype(np.float64), P[0].cpu().numpy().astype(np.float64)))
+                    pi, _r = ops.step_given_P(pi, P, want_reward=False)
+                out.append(traj)
+            return out
+        idx = torch.as_tensor(np.random.randint(num, size=n).astype(np.int32), device=self.device)
+        pi0 = ops.gather_start(mat_dev, idx)
+        r = ops.rollout(pi0, T, self._theta, self.shift, self.alpha_scale, seed=self.seed, first_step=self._rng_step,
+                        traj_offset=self._gen_offset(n), td=False, write_P=True)
+        self._rng_step += T
+        pis = r['pi_traj'].cpu().numpy().astype(np.float64)
+        Ps = r['P'].cpu().numpy().astype(np.float64)
+        return [[(pis[b, t], Ps[b, t]) for t in range(T)] for b in range(n)]
+
+    def _gen_offset(self, n):
+        off = getattr(self, '_gen_traj_counter', 1 << 40)       # disjoint from the training trajectory ids
+        self._gen_traj_counter = off + n
+        return off
+
+    # ------------------------------------------------------------------ reward learning (ac_irl.py:804-897)
+    def update_reward(self, summary=False, iteration=0):
+        if len(self.list_demonstrations) >= self.num_demo_samples:
+            demo_sampled = random.sample(self.list_demonstrations, self.num_demo_samples)
+        else:
+            demo_sampled = self.list_demonstrations[:]
+        if len(self.list_generated) >= self.num_gen_samples:
+            gen_sampled = random.sample(self.list_generated, self.num_gen_samples)
+        else:
+            gen_sampled = self.list_generated[:]
+        ds, da = self._pairs_to_tensors([pair for traj in demo_sampled for pair in traj])
+        gs, ga = self._pairs_to_tensors([pair for traj in gen_sampled for pair in traj])
+        self.reward_net.train()
+        r_demo = self.reward_net(ds, da)
+        r_gen = self.reward_net(gs, ga)
+        reg = self.reward_net.regularization() if self.reward_net.use_l1l2 else None
+        loss, first, second = maxent_irl_loss(r_demo, r_gen, self.num_demo_samples, len(gen_sampled), reg)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        if self.group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            # replicated reward net: identical batches on every rank -> identical grads; keep ranks in lock-step
+            for p in self.reward_net.parameters():
+                if p.grad is not None and torch.distributed.get_world_size(self.group) > 1:
+                    torch.distributed.all_reduce(p.grad, group=self.group)
+                    p.grad /= torch.distributed.get_world_size(self.group)
+        self.optimizer.step()
+        self.loss_val = float(loss.detach().cpu())
+        self.first_term_val = float(first.detach().cpu())
+        self.second_term_val = float(second.detach().cpu())
+
+    def reward_iteration(self, max_iterations=500, stop_criteria=0.01, iter_check=10):
+        prev_reward_demo_avg = -100
+        if self.verbose:
+            print('----- Starting reward_iteration -----')
+        it = 0
+        for it in range(1, max_iterations + 1):
+            self.reward_update_count += 1
+            if it % iter_check != 0:
+                self.update_reward(summary=False)
+                continue
+            self.update_reward(summary=False, iteration=self.reward_update_count)
+            ds, da = self._pairs_to_tensors(self.list_eval_demo_transitions)
+            gs, ga = self._pairs_to_tensors(self.list_eval_gen_transitions)
+            with torch.no_grad():
+                reward_demo_avg = float(self.reward_net(ds, da).sum().cpu()) / len(self.list_eval_demo_transitions)
+                reward_gen_avg = float(self.reward_net(gs, ga).sum().cpu()) / len(self.list_eval_gen_transitions)
+            if self.verbose:
+                print('Reward iteration %d' % it)
+                print('Reward demo avg %f | Reward gen avg %f' % (reward_demo_avg, reward_gen_avg))
+                print('First %f | Second %f | Loss %f' % (self.first_term_val, self.second_term_val, self.loss_val))
+            if np.isnan(reward_demo_avg) or np.isnan(reward_gen_avg):
+                break
+            if os.path.isdir('results'):
+                with open('results/reward_training.csv', 'a') as f:
+                    f.write('%f,%f\n' % (reward_demo_avg, reward_gen_avg))
+            if stop_criteria != -1 and abs(reward_demo_avg - prev_reward_demo_avg) < stop_criteria:
+                break
+            prev_reward_demo_avg = reward_demo_avg
+        if self.verbose:
+            print('----- Exiting reward_iteration at iter %d -----' % it)
+
+    def outerloop(self, num_iterations=20, num_gen_from_policy=5, max_reward_iterations=100,
+                  max_forward_episodes=200, gamma=1, constant=False, lr_critic=0.1, lr_actor=0.001):
+        """Alternate reward updates and forward solves (ac_irl.py:900-954); returns the final theta."""
+        self.list_generated = self.generate_trajectories(num_gen_from_policy * self.num_policies)
+        self.reward_update_count = 0
+        write = 1 if os.path.isdir('results') else 0
+        if write:
+            with open('results/reward_training.csv', 'w') as f:
+                f.write('reward_demo_avg,reward_gen_avg\n')
+        for it in range(num_iterations):
+            if self.verbose:
+                print('########## Outerloop iteration %d ##########' % it)
+            list_generated = self.generate_trajectories(num_gen_from_policy)
+            self.list_generated = (self.list_generated + list_generated)[num_gen_from_policy:]
+            self.list_eval_gen_transitions = [pair for traj in self.list_generated for pair in traj]
+            self.reward_iteration(max_iterations=max_reward_iterations, stop_criteria=0.0001, iter_check=10)
+            self.theta = self.theta_initial
+            self.train(max_forward_episodes, -1, gamma, constant, lr_critic, lr_actor, consecutive=100,
+                       write_file=write, write_all=0)
+        if os.path.isdir('log'):
+            torch.save(self.reward_net.state_dict(), 'log/model_%s_%d_%d.ckpt' % (self.reg, self.n_fc3, self.n_fc4))
+        if self.verbose:
+            print('********** Final forward training **********')
+        self.theta = self.theta_initial
+        self.train(2000, -1, gamma, constant, lr_critic, lr_actor, consecutive=100, write_file=write, write_all=0)
+        return self.theta

@@ -1,0 +1,453 @@
+"""Drop-in ``actor_critic`` with the call surface of the reference's ``mfg_ac2.actor_critic``
+(mfg_ac2.py:23), running the hot path in HIP kernels over a batch of independent trajectories.
+
+Same constructor / method names, keyword names and defaults as the reference:
+``actor_critic(theta, shift, alpha_scale, d)``, ``sample_action(pi)``, ``calc_reward(P, pi, d)``,
+``calc_features``, ``calc_value``, ``calc_gradient_vectorized``, ``train(...)``, ``generate_trajectory``,
+``JSD``, ``evaluate``, ``gridsearch``, plus the public attributes ``theta, shift, alpha_scale, d, w,
+mat_pi0, num_start_samples, mat_alpha, mat_alpha_deriv``.  Extensions are keyword-only:
+
+  pi0 / path_to_dir : start-state table (array, or a directory of trend_distribution_day%d.csv files;
+                      default cwd/train_normalized_round2 like mfg_ac2.py:39, synthetic if absent)
+  batch             : trajectories stepped in lock-step per episode (reference = 1)
+  rng               : 'philox'  in-kernel counter-based Dirichlet sampler (production path)
+                      'numpy'   gamma variates drawn on the host from the process-global legacy
+                                np.random stream in the reference's exact order (mfg_ac2.py:242, :466),
+                                so a seeded batch-1 run retraces the reference; the math still runs on
+                                the GPU
+  update_every      : 'step' (reference semantics: theta, w move after every env step; batch-mean
+                      gradient) or 'rollout' (one fused T-step kernel + one update per episode)
+  group             : torch.distributed process group; the batch is the GLOBAL batch and is sharded
+                      across ranks, gradients are summed with one all-reduce per update.
+
+There is no CPU fallback: every numeric method calls the C ABI in include/mfg_hip.h.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+from .parallel import all_reduce_gradients_, current_shard, lr_scales
+
+EPISODE_STEPS = 15  # mfg_ac2.py:478
+
+
+def _as_np(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+class actor_critic:
+
+    def __init__(self, theta=8.86349, shift=0.16, alpha_scale=12000, d=21, *, pi0=None, path_to_dir=None,
+                 batch=1, rng='philox', seed=0, update_every='step', reward='mfg_ac2', device=None, group=None,
+                 verbose=1):
+        if rng not in ('philox', 'numpy'):
+            raise ValueError("rng must be 'philox' or 'numpy'")
+        if update_every not in ('step', 'rollout'):
+            raise ValueError("update_every must be 'step' or 'rollout'")
+        if not torch.cuda.is_available():
+            raise L.MfgError('actor_critic needs a ROCm GPU: the HIP hot path has no CPU fallback')
+        L.lib()
+        self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self.shift = shift
+        self.alpha_scale = alpha_scale
+        self.d = d
+        self.rng = rng
+        self.seed = int(seed)
+        self.update_every = update_every
+        self.reward_kind = {'mfg_ac2': L.REWARD_MFG_AC2, 'synthetic': L.REWARD_SYNTHETIC}[reward]
+        self.group = group
+        self.verbose = verbose
+        self.batch = int(batch)
+        self._theta = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self._theta_is_array = False
+        self.theta = theta
+        # critic weights first, start states second: the reference's np.random consumption order (:33, :39)
+        self.w = self.init_w(d)
+        if pi0 is not None:
+            self.mat_pi0 = np.array(pi0, dtype=np.float64)[:, 0:d]
+        else:
+            if path_to_dir is None:
+                path_to_dir = os.getcwd() + '/train_normalized_round2'
+            if os.path.isdir(path_to_dir):
+                self.init_pi0(path_to_dir=path_to_dir)
+            else:
+                rs = np.random.RandomState(0)   # synthetic table: Dirichlet(1) rows via '%.3e' text
+                m = rs.dirichlet(np.ones(d), size=64)
+                self.mat_pi0 = np.array([[float('%.3e' % v) for v in row] for row in m])
+        self.num_start_samples = self.mat_pi0.shape[0]
+        self._single = False
+        self._pi_alpha = None      # state of the last sample_action (hidden coupling of mfg_ac2.py:219-234)
+        self._rng_step = 0         # Philox step counter (advances once per env step)
+        self.trace = None          # set to [] to record theta after every update (parity tests)
+
+    # ------------------------------------------------------------------ state on the device
+    @property
+    def theta(self):
+        v = float(self._theta.cpu()[0])
+        return np.array([v]) if self._theta_is_array else v       # ndarray (1,) after the first update (:520)
+
+    @theta.setter
+    def theta(self, value):
+        self._theta_is_array = isinstance(value, np.ndarray)
+        self._theta.copy_(torch.as_tensor(np.ravel(np.asarray(value, dtype=np.float64))[:1]))
+
+    @property
+    def w(self):
+        return self._w.cpu().numpy().reshape(-1, 1).copy()
+
+    @w.setter
+    def w(self, value):
+        v = np.ascontiguousarray(np.asarray(value, dtype=np.float64).reshape(-1))
+        self._w = torch.as_tensor(v, device=self.device)
+
+    @property
+    def mat_pi0(self):
+        return self._mat_pi0_host
+
+    @mat_pi0.setter
+    def mat_pi0(self, value):
+        self._mat_pi0_host = np.array(value, dtype=np.float64)
+        self._mat_pi0_dev = torch.as_tensor(np.ascontiguousarray(self._mat_pi0_host, dtype=np.float32),
+                                            device=self.device)
+
+    @property
+    def mat_alpha(self):
+        if self._pi_alpha is None:
+            return np.zeros([self.d, self.d])
+        a, _ = ops.alpha(self._pi_alpha, self._theta_at_sample, self.shift, want_deriv=False)
+        a = a.cpu().numpy()
+        return a[0] if self._single else a
+
+    @property
+    def mat_alpha_deriv(self):
+        if self._pi_alpha is None:
+            return np.zeros([self.d, self.d])
+        _, ad = ops.alpha(self._pi_alpha, self._theta_at_sample, self.shift, want_alpha=False)
+        ad = ad.cpu().numpy()
+        return ad[0] if self._single else ad
+
+    # ------------------------------------------------------------------ host helpers (a12)
+    def init_w(self, d):
+        """U[0,1) column vector of F = d(d+1)/2 + d + 1 weights (mfg_ac2.py:165-176)."""
+        num_features = int((d + 1) * d / 2 + d + 1)
+        return np.random.rand(num_features, 1)
+
+    def init_pi0(self, path_to_dir, verbose=0):
+        """First line of every trend_distribution_day%d.csv, truncated to d columns (mfg_ac2.py:179-208)."""
+        rows = []
+        num_files = len(os.listdir(path_to_dir))
+        for num_day in range(1, 1 + num_files):
+            filename = 'trend_distribution_day%d.csv' % num_day
+            with open(path_to_dir + '/' + filename, 'r') as f:
+                first = f.readline()
+            rows.append(list(map(float, first.strip().split(' ')))[0:self.d])
+            if verbose:
+                print(filename)
+        self.mat_pi0 = np.array(rows, dtype=np.float64)
+
+    def reorder(self, list_rows):
+        """Order all rows by decreasing popularity of the first row, stable on ties (mfg_ac2.py:58-81)."""
+        row1 = list_rows[0]
+        order = sorted(range(len(row1)), key=lambda i: row1[i], reverse=True)
+        for i in range(len(list_rows)):
+            list_rows[i] = [list_rows[i][j] for j in order]
+        return list_rows
+
+    def normalize(self, indir='train_round2', outdir='train_normalized_round2', header=True):
+        """Row-normalise every file of indir into outdir as '%.3e' space separated text (mfg_ac2.py:116-137)."""
+        for filename in os.listdir(os.getcwd() + '/' + indir):
+            with open(os.getcwd() + '/' + indir + '/' + filename, 'r') as f:
+                if header:
+                    f.readline()
+                matrix = np.loadtxt(f, delimiter=',')
+            matrix = matrix / np.sum(matrix, axis=1, keepdims=True)
+            with open(os.getcwd() + '/' + outdir + '/' + filename, 'wb') as f:
+                np.savetxt(f, matrix, fmt='%.3e', delimiter=' ')
+
+    # ------------------------------------------------------------------ tensor plumbing
+    def _pi_dev(self, pi):
+        """(d,) or (B,d) array / tensor -> contiguous fp32 [B,d] device tensor, plus 'single' flag."""
+        if isinstance(pi, torch.Tensor):
+            t = pi.to(device=self.device, dtype=torch.float32)
+        else:
+            t = torch.as_tensor(np.asarray(pi, dtype=np.float32), device=self.device)
+        single = t.dim() == 1
+        if single:
+            t = t.unsqueeze(0)
+        return t.contiguous(), single
+
+    def _P_dev(self, P):
+        if isinstance(P, torch.Tensor):
+            t = P.to(device=self.device, dtype=torch.float32)
+        else:
+            t = torch.as_tensor(np.asarray(P, dtype=np.float32), device=self.device)
+        if t.dim() == 2:
+            t = t.unsqueeze(0)
+        return t.contiguous()
+
+    @staticmethod
+    def _out(t, like, single, dtype=np.float64):
+        if isinstance(like, torch.Tensor):
+            return t[0] if single else t
+        a = t.cpu().numpy().astype(dtype)
+        return a[0] if single else a
+
+    # ------------------------------------------------------------------ a1 + a2
+    def _host_gamma(self, pi_dev):
+        """Gamma variates for [B,d] states from the global legacy np.random stream, in the reference's order:
+        trajectory by trajectory, row by row, one vector draw of length d per row (mfg_ac2.py:238-242)."""
+        a, _ = ops.alpha(pi_dev, self._theta, self.shift, want_deriv=False)
+        a = a.cpu().numpy()
+        B, d = a.shape[0], self.d
+        y = np.empty((B, d, d))
+        for b in range(B):
+            for i in range(d):
+                y[b, i] = np.random.gamma(shape=a[b, i, :] * self.alpha_scale, scale=1)
+        return torch.as_tensor(y.astype(np.float32), device=self.device)
+
+    def _sample(self, pi_dev, traj_offset=0):
+        self._pi_alpha = pi_dev
+        self._theta_at_sample = self._theta.clone()
+        if self.rng == 'numpy':
+            return ops.dirichlet_from_gamma(self._host_gamma(pi_dev))
+        P = ops.sample_dirichlet(pi_dev, self._theta, self.shift, self.alpha_scale, self.seed, self._rng_step,
+                                 traj_offset)
+        self._rng_step += 1
+        return P
+
+    def sample_action(self, pi):
+        """P ~ prod_i Dirichlet(alpha_i. * alpha_scale); (d,) -> (d,d), (B,d) -> (B,d,d)  (mfg_ac2.py:211-254)."""
+        pi_dev, single = self._pi_dev(pi)
+        self._single = single
+        return self._out(self._sample(pi_dev), pi, single)
+
+    # ------------------------------------------------------------------ a3 - a5, a7
+    def calc_reward(self, P, pi, d=None):
+        """R = sum_i pi_i sum_j P_ij^2 (pi_j - pi_i); shape (1,) for one trajectory (mfg_ac2.py:257-287)."""
+        pi_dev, single = self._pi_dev(pi)
+        _, r = ops.step_given_P(pi_dev, self._P_dev(P), reward_kind=self.reward_kind)
+        if isinstance(pi, torch.Tensor):
+            return r
+        return r.cpu().numpy().astype(np.float64)          # (1,) when single, like the reference
+
+    def transition(self, P, pi):
+        """pi' = P^T pi (mfg_ac2.py:497)."""
+        pi_dev, single = self._pi_dev(pi)
+        pn, _ = ops.step_given_P(pi_dev, self._P_dev(P), want_reward=False)
+        return self._out(pn, pi, single)
+
+    def calc_features(self, pi):
+        pi_dev, single = self._pi_dev(pi)
+        return self._out(ops.features(pi_dev), pi, single)
+
+    def calc_value(self, pi):
+        pi_dev, single = self._pi_dev(pi)
+        v = ops.value(pi_dev, self._w)
+        if isinstance(pi, torch.Tensor):
+            return v
+        return v.cpu().numpy()                               # (1,) when single (mfg_ac2.py:311)
+
+    def calc_gradient_vectorized(self, P, pi):
+        """Score of the product-Dirichlet policy w.r.t. theta (mfg_ac2.py:347-381).  Like the reference it
+        uses the concentrations of the LAST sample_action call when there is one (hidden state), and
+        replaces zeros of a NumPy ``P`` by 1e-100 in place (:369)."""
+        pi_dev, single = self._pi_dev(pi)
+        pa = self._pi_alpha if (self._pi_alpha is not None and self._pi_alpha.shape == pi_dev.shape) else pi_dev
+        g = ops.score(pa, self._P_dev(P), self._theta, self.shift)
+        if isinstance(P, np.ndarray) and P.dtype == np.float64:
+            P[P == 0] = 1e-100
+        if isinstance(pi, torch.Tensor):
+            return g[0] if single else g
+        g = g.cpu().numpy()
+        return float(g[0]) if single else g
+
+    calc_gradient = calc_gradient_vectorized
+    calc_gradient_basic = calc_gradient_vectorized
+
+    # ------------------------------------------------------------------ logging (mfg_ac2.py:441-445)
+    def train_log(self, vector, filename, str_format):
+        with open(filename, 'a') as f:
+            np.asarray(vector).tofile(f, sep=',', format=str_format)
+            f.write('\n')
+
+    # ------------------------------------------------------------------ a9: train
+    def _draw_start(self, shard):
+        if self.batch == 1:
+            idx = np.array([np.random.randint(self.num_start_samples)])      # the reference's single draw (:466)
+        else:
+            idx = np.random.randint(self.num_start_samples, size=self.batch)
+            idx = idx[shard.traj_offset:shard.traj_offset + shard.local_batch]
+        return torch.as_tensor(idx.astype(np.int32), device=self.device)
+
+    def train(self, num_episodes=4000, gamma=1, constant=0, lr_critic=0.1, lr_actor=0.001, consecutive=100,
+              file_theta='results/theta.csv', file_pi='results/pi.csv', file_reward='results/reward.csv',
+              write_file=0, write_all=0):
+        """Actor-critic training (mfg_ac2.py:448-539) over ``batch`` lock-step trajectories.
+        batch=1, rng='numpy', update_every='step' retraces the reference's seeded run."""
+        d, T = self.d, EPISODE_STEPS
+        shard = current_shard(self.batch, self.group)
+        Bl = shard.local_batch
+        F = ops.num_features(d)
+        G = torch.zeros(F + 3, dtype=torch.float64, device=self.device)
+        ws = ops.workspace(Bl * T, d, self.device)
+        ep_reward = torch.zeros(max(num_episodes, 1), dtype=torch.float64, device=self.device)
+        window_start = 0
+        pi = None
+        for episode in range(num_episodes):
+            if write_all:
+                with open('temp.csv', 'a') as f:
+                    f.write('Episode %d \n\n' % episode)
+            pi = ops.gather_start(self._mat_pi0_dev, self._draw_start(shard))
+            sc, sa = lr_scales(episode, constant == 1)
+            if self.update_every == 'rollout' and self.rng == 'philox':
+                out = ops.rollout(pi, T, self._theta, self.shift, self.alpha_scale, w=self._w, gamma=gamma,
+                                  reward_kind=self.reward_kind, seed=self.seed, first_step=self._rng_step,
+                                  traj_offset=shard.traj_offset, td=True, G=G, ws=ws)
+                self._rng_step += T
+                all_reduce_gradients_(G, self.group)
+                ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta)
+                ep_reward[episode] = G[F + 1] / G[F + 2]
+                pi = out['pi_traj'][:, T].contiguous()
+                self._theta_is_array = True
+                if self.trace is not None:
+                    self.trace.append(float(self._theta.cpu()[0]))
+            else:
+                for step in range(T):
+                    if self.rng == 'philox':
+                        out = ops.rollout(pi, 1, self._theta, self.shift, self.alpha_scale, w=self._w, gamma=gamma,
+                                          reward_kind=self.reward_kind, seed=self.seed, first_step=self._rng_step,
+                                          traj_offset=shard.traj_offset, td=True, G=G, ws=ws,
+                                          accumulate=(self.update_every == 'rollout' and step > 0))
+                        self._rng_step += 1
+                        pi_next = out['pi_traj'][:, 1].contiguous()
+                    else:
+                        P = self._sample(pi, shard.traj_offset)
+                        if write_all:
+                            self._write_all(pi, P, step + 1)
+                        pi_next, r = ops.step_given_P(pi, P, reward_kind=self.reward_kind)
+                        ops.td_pg_accumulate(pi, pi_next, P, r, self._w, self._theta, self.shift, gamma, G=G, ws=ws,
+                                             accumulate=(self.update_every == 'rollout' and step > 0))
+                    if self.update_every == 'step':
+                        all_reduce_gradients_(G, self.group)
+                        ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta)
+                        ep_reward[episode] += G[F + 1] / G[F + 2]
+                        self._theta_is_array = True
+                        if self.trace is not None:
+                            self.trace.append(float(self._theta.cpu()[0]))
+                    pi = pi_next
+                if self.update_every == 'rollout':
+                    all_reduce_gradients_(G, self.group)
+                    ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta)
+                    ep_reward[episode] = G[F + 1] / G[F + 2] * T
+                    self._theta_is_array = True
+                    if self.trace is not None:
+                        self.trace.append(float(self._theta.cpu()[0]))
+            if self.update_every == 'rollout' and self.rng == 'philox':
+                ep_reward[episode] *= T            # mean over B*T transitions -> mean episode return
+            if episode % consecutive == 0:
+                # the reference divides the sum over the window by `consecutive` even at episode 0 (:530-534)
+                reward_avg = float(ep_reward[window_start:episode + 1].sum().cpu()) / consecutive
+                window_start = episode + 1
+                pi_host = pi[0].cpu().numpy().astype(np.float64)
+                if self.verbose:
+                    print('Theta\n', self.theta)
+                    print('pi\n', pi_host)
+                    print('Average reward during previous %d episodes: ' % consecutive, str(reward_avg))
+                if write_file:
+                    self.train_log(np.ravel(self.theta), file_theta, '%.5e')
+                    self.train_log(pi_host, file_pi, '%.3e')
+                    self.train_log(np.array([reward_avg]), file_reward, '%.3e')
+        self._last_pi = pi
+
+    def _write_all(self, pi, P, num_steps):
+        with open('temp.csv', 'ab') as f:
+            np.savetxt(f, np.array(['num_steps = %d' % num_steps]), fmt='%s')
+            np.savetxt(f, np.array(['distribution']), fmt='%s')
+            np.savetxt(f, pi[0].cpu().numpy().reshape(1, self.d), delimiter=',', fmt='%.6f')
+            np.savetxt(f, np.array(['Action']), fmt='%s')
+            np.savetxt(f, P[0].cpu().numpy(), delimiter=',', fmt='%.3f')
+
+    # ------------------------------------------------------------------ a10, a11: evaluation
+    def JSD(self, P, Q):
+        """Jensen-Shannon divergence, zeros -> 1e-100 (mfg_ac2.py:546-563); scalar for 1-D inputs."""
+        p, single = self._pi_dev(P)
+        q, _ = self._pi_dev(Q)
+        if isinstance(P, np.ndarray) and P.dtype == np.float64:
+            P[P == 0] = 1e-100                               # the reference mutates its arguments (:556-557)
+        if isinstance(Q, np.ndarray) and Q.dtype == np.float64:
+            Q[Q == 0] = 1e-100
+        out = ops.jsd(p, q)
+        if isinstance(P, torch.Tensor):
+            return out[0] if single else out
+        out = out.cpu().numpy()
+        return float(out[0]) if single else out
+
+    def generate_trajectory(self, pi0, total_hours):
+        """Rows pi^0 .. pi^{total_hours-1} under the current policy (mfg_ac2.py:566-592);
+        (d,) -> (total_hours, d), (B,d) -> (B, total_hours, d)."""
+        pi_dev, single = self._pi_dev(pi0)
+        T = total_hours - 1
+        if self.rng == 'philox' and T >= 1:
+            out = ops.rollout(pi_dev, T, self._theta, self.shift, self.alpha_scale, seed=self.seed,
+                              first_step=self._rng_step, td=False, reward_kind=self.reward_kind)
+            self._rng_step += T
+            traj = out['pi_traj']
+        else:
+            rows = [pi_dev]
+            pi = pi_dev
+            for _ in range(T):
+                P = self._sample(pi)
+                pi, _r = ops.step_given_P(pi, P, want_reward=False)
+                rows.append(pi)
+            traj = torch.stack(rows, dim=1)
+        return self._out(traj, pi0, single)
+
+    def evaluate(self, theta=8.86349, shift=0.5, alpha_scale=1e4, d=21, episode_length=16,
+                 indir='test_normalized_round2', outfile='eval_mfg_round2/test_eval_fixed_reward.csv',
+                 write_header=0):
+        """L1 / JSD of generated vs empirical trajectories over every file of indir (mfg_ac2.py:595-670).
+        All test trajectories are generated in one batched launch."""
+        self.theta = theta
+        self.shift = shift
+        self.alpha_scale = alpha_scale
+        self.d = d
+        path_to_dir = os.getcwd() + '/' + indir
+        emp = []
+        for filename in os.listdir(path_to_dir):
+            with open(path_to_dir + '/' + filename, 'r') as f:
+                emp.append(np.loadtxt(f, delimiter=' ')[:, 0:d])
+        emp = np.array(emp)[:, :episode_length]                              # [N, L, d]
+        gen = self.generate_trajectory(emp[:, 0], episode_length)           # [N, L, d]
+        diff = np.abs(emp - gen).sum(-1)                                    # L1 per step
+        N, Lh = emp.shape[0], episode_length
+        jsd = self.JSD(emp.reshape(N * Lh, d).copy(), gen.reshape(N * Lh, d).copy()).reshape(N, Lh)
+        res = [diff[:, -1].mean(), diff[:, -1].std(), diff.mean(1).mean(), diff.mean(1).std(),
+               jsd[:, -1].mean(), jsd[:, -1].std(), jsd.mean(1).mean(), jsd.mean(1).std()]
+        with open(outfile, 'a') as f:
+            if write_header:
+                f.write('theta,shift,alpha_scale,mean_l1_final,std_l1_final,mean_l1_mean,std_l1_mean,'
+                        'mean_JSD_final,std_JSD_final,mean_JSD_mean,std_JSD_mean\n')
+            f.write('%f,%f,%f,%.3e,%.3e,%.3e,%.3e,%.3e,%.3e,%.3e,%.3e\n' % ((theta, shift, alpha_scale) + tuple(res)))
+        return res[0], res[2], res[4], res[6]
+
+    def gridsearch(self, theta_range, shift_range, alpha_range, indir, outfile):
+        """Sweep (theta, shift, alpha_scale) and keep the best of each metric (mfg_ac2.py:673-689)."""
+        list_tuples = [[100, 0, 0, 0], [100, 0, 0, 0], [100, 0, 0, 0], [100, 0, 0, 0]]
+        for theta in theta_range:
+            for shift in shift_range:
+                for alpha_scale in alpha_range:
+                    if self.verbose:
+                        print('Theta %f, shift %f, alpha %d' % (theta, shift, alpha_scale))
+                    result = self.evaluate(theta, shift, alpha_scale, d=self.d, indir=indir, outfile=outfile,
+                                           write_header=0)
+                    for idx in range(4):
+                        if result[idx] <= list_tuples[idx][0]:
+                            list_tuples[idx] = [result[idx], theta, shift, alpha_scale]
+        if self.verbose:
+            print(list_tuples)
+        return list_tuples

@@ -1,0 +1,59 @@
+"""Multi-GPU layout of the hot path: the trajectory batch shards across ranks, one all-reduce per update.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+Trajectories are independent given (theta, w), so no P or pi ever crosses GPUs; the only exchange is the
+fused gradient buffer  G = [G_w (F) | G_theta | sum_reward | count]  (fp64, F+3 entries, 2 KB at d=21,
+265 KB at d=256): latency bound, so it is sent as ONE collective per update.
+Every rank then applies the identical update, so (theta, w) stay replicated without a broadcast.
+The RNG is counter based and keyed by the GLOBAL trajectory id (traj_offset + b), so results do not depend
+on the world size.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass(frozen=True)
+class Shard:
+    rank: int
+    world: int
+    global_batch: int
+    local_batch: int
+    traj_offset: int
+
+
+def shard_batch(global_batch: int, rank: int, world: int) -> Shard:
+    """Contiguous split of [0, global_batch) into `world` shards; the first (global_batch % world) ranks
+    get one extra trajectory.  Integer bookkeeping: shards tile the range exactly once."""
+    if world < 1 or not (0 <= rank < world) or global_batch < 0:
+        raise ValueError('bad shard request')
+    base, extra = divmod(global_batch, world)
+    local = base + (1 if rank < extra else 0)
+    offset = rank * base + min(rank, extra)
+    return Shard(rank, world, global_batch, local, offset)
+
+
+def current_shard(global_batch: int, group=None) -> Shard:
+    if dist.is_available() and dist.is_initialized():
+        return shard_batch(global_batch, dist.get_rank(group), dist.get_world_size(group))
+    return shard_batch(global_batch, 0, 1)
+
+
+def all_reduce_gradients_(G: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place SUM of the fused gradient buffer over all ranks (no-op for a single process).
+    The count entry G[F+2] is summed too, so dividing by it afterwards gives the global batch mean."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)
+    return G
+
+
+def lr_scales(episode: int, constant) -> tuple:
+    """(critic, actor) learning-rate multipliers of the reference schedule in `episode`
+    (mfg_ac2.py:511-522: 1/(episode+1) and 1/((episode+1) ln ln(episode+20)); 1, 1 if constant)."""
+    if constant:
+        return 1.0, 1.0
+    return 1.0 / (episode + 1), 1.0 / ((episode + 1) * math.log(math.log(episode + 20)))

@@ -1,0 +1,60 @@
+"""NumPy restatement of the reference's reward network forward pass and IRL loss.  TEST INFRASTRUCTURE.
+
+PARITY UNPINNED: ``networks.py`` / ``ac_irl.py:382-427`` need TensorFlow 1.x (``tf.contrib``), which cannot be
+imported or installed here, and the reference holds no numeric test for the net.  This file therefore
+follows the published semantics of the TF ops named in the reference (networks.py:46-81):
+conv2d SAME stride 1 (cross-correlation, zero padding), ReLU, NHWC flatten, fully_connected, tanh;
+``l1_l2_regularizer()`` = sum|W| + sum W^2 / 2 (scale_l1 = scale_l2 = 1); loss of ac_irl.py:390-413.
+It is used to check the PyTorch module (weights shared), with dropout disabled.
+"""
+import numpy as np
+
+
+def conv2d_same(x, w, b):
+    """x [N,H,W,Cin], w [kh,kw,Cin,Cout] (TF layout), stride 1, SAME zero padding."""
+    N, H, W, Cin = x.shape
+    kh, kw, _, Cout = w.shape
+    ph, pw = kh // 2, kw // 2
+    xp = np.zeros((N, H + 2 * ph, W + 2 * pw, Cin))
+    xp[:, ph:ph + H, pw:pw + W] = x
+    out = np.zeros((N, H, W, Cout))
+    for u in range(kh):
+        for v in range(kw):
+            out += np.einsum('nhwc,co->nhwo', xp[:, u:u + H, v:v + W], w[u, v])
+    return out + b
+
+
+def forward(params, state, action):
+    """params: dict of TF-layout arrays conv1_w [5,5,1,1], conv1_b, conv2_w [3,3,1,2], conv2_b,
+    fc3_w [2d^2,n3], fc3_b, fc4_w [n3+d,n4], fc4_b, out_w [n4,1], out_b.  Returns [N,1]."""
+    N, d = state.shape
+    x = action.reshape(N, d, d, 1).astype(np.float64)
+    x = np.maximum(conv2d_same(x, params['conv1_w'], params['conv1_b']), 0)
+    x = np.maximum(conv2d_same(x, params['conv2_w'], params['conv2_b']), 0)
+    x = x.reshape(N, -1)                                            # NHWC flatten (networks.py:67)
+    x = np.maximum(x.dot(params['fc3_w']) + params['fc3_b'], 0)
+    x = np.concatenate([x, state.astype(np.float64)], axis=1)        # networks.py:72
+    x = np.maximum(x.dot(params['fc4_w']) + params['fc4_b'], 0)
+    return np.tanh(x.dot(params['out_w']) + params['out_b'])
+
+
+def l1_l2(params):
+    return sum(np.abs(params[k]).sum() + 0.5 * (params[k] ** 2).sum() for k in ('fc3_w', 'fc4_w'))
+
+
+def irl_loss(r_demo, r_gen, n_demo, n_traj, reg=0.0, steps=15):
+    first = -1.0 / n_demo * np.sum(r_demo)
+    second = np.log(1.0 / n_traj * np.sum(np.exp(np.reshape(r_gen, (n_traj, steps)).sum(1))))
+    return first + second + reg, first, second
+
+
+def params_from_torch(net):
+    """Convert a networks.RewardNet state to the TF layouts used above."""
+    g = lambda t: t.detach().cpu().double().numpy()
+    return {
+        'conv1_w': g(net.conv1.weight).transpose(2, 3, 1, 0), 'conv1_b': g(net.conv1.bias),
+        'conv2_w': g(net.conv2.weight).transpose(2, 3, 1, 0), 'conv2_b': g(net.conv2.bias),
+        'fc3_w': g(net.fc3.weight).T, 'fc3_b': g(net.fc3.bias),
+        'fc4_w': g(net.fc4.weight).T, 'fc4_b': g(net.fc4.bias),
+        'out_w': g(net.out.weight).T, 'out_b': g(net.out.bias),
+    }

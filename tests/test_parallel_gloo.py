@@ -1,0 +1,96 @@
+"""Multi-rank path on CPU: world_size-2 gloo process groups exercise the product's sharding and the
+single fused all-reduce.  Per-shard gradient sums come from the oracle (test-side checker);
+the HIP kernels themselves are covered by the -m gpu tests."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from discrete_mean_field_game_amd import parallel
+from oracle import mfg_oracle as O
+
+
+def test_shard_batch_tiles_exactly():
+    for B in (0, 1, 7, 8, 65536, 131072, 100003):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                s = parallel.shard_batch(B, r, world)
+                cover.extend(range(s.traj_offset, s.traj_offset + s.local_batch))
+                assert s.local_batch in (B // world, B // world + 1)
+            assert cover == list(range(B))                      # bit-exact index bookkeeping
+    with pytest.raises(ValueError):
+        parallel.shard_batch(8, 2, 2)
+
+
+def test_lr_scales_match_reference_schedule():
+    for ep in (0, 1, 5, 99, 3999):
+        assert parallel.lr_scales(ep, False) == tuple(float(x) for x in O.lr_scales(ep, False))
+        assert parallel.lr_scales(ep, True) == (1.0, 1.0)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, B, d, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(0)                            # same global problem on every rank
+        pi = rs.dirichlet(np.ones(d), size=B)
+        P = rs.dirichlet(np.ones(d), size=(B, d))
+        w = rs.rand(O.num_features(d))
+        theta, shift, gamma = 8.86349, 0.16, 0.9
+        sh = parallel.current_shard(B)
+        assert (sh.rank, sh.world) == (rank, world)
+        sl = slice(sh.traj_offset, sh.traj_offset + sh.local_batch)
+        pn = O.transition(P[sl], pi[sl])
+        r = O.calc_reward(P[sl], pi[sl])
+        delta, g, G_w, G_theta, rsum = O.batched_td_pg(pi[sl], pn, P[sl], r, w, theta, shift, gamma)
+        G = torch.as_tensor(np.concatenate([G_w, [G_theta, rsum, float(sh.local_batch)]]))
+        parallel.all_reduce_gradients_(G)                        # the ONE collective of an update
+        F = O.num_features(d)
+        sc, sa = parallel.lr_scales(3, False)
+        w_new = w + 0.1 * sc * G[:F].numpy() / float(G[F + 2])
+        theta_new = theta + 0.001 * sa * float(G[F]) / float(G[F + 2])
+        q.put((rank, G.numpy().copy(), w_new, theta_new))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_allreduce_equals_single_process():
+    B, d, world = 37, 5, 2                                       # ragged split: 19 + 18
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, d, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rs = np.random.RandomState(0)
+    pi = rs.dirichlet(np.ones(d), size=B); P = rs.dirichlet(np.ones(d), size=(B, d)); w = rs.rand(O.num_features(d))
+    pn = O.transition(P, pi); r = O.calc_reward(P, pi)
+    delta, g, G_w, G_theta, rsum = O.batched_td_pg(pi, pn, P, r, w, 8.86349, 0.16, 0.9)
+    ref = np.concatenate([G_w, [G_theta, rsum, float(B)]])
+    for rank, Gr, w_new, theta_new in res:
+        assert np.allclose(Gr, ref, rtol=1e-12, atol=1e-15)
+        assert Gr[-1] == B
+    # replicated update: both ranks end with bit-identical parameters, no broadcast needed
+    assert np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
+
+
+def test_all_reduce_is_noop_without_process_group():
+    G = torch.arange(6, dtype=torch.float64)
+    assert torch.equal(parallel.all_reduce_gradients_(G.clone()), G)
+    s = parallel.current_shard(10)
+    assert (s.rank, s.world, s.local_batch, s.traj_offset) == (0, 1, 10, 0)
