@@ -15,7 +15,9 @@ LIB_PATH = os.path.join(CSRC, 'libmfg_hip.so')
 
 MFG_MAX_D = 512
 REWARD_MFG_AC2, REWARD_SYNTHETIC, REWARD_EXTERNAL = 0, 1, 2
-ROLLOUT_WRITE_P, ROLLOUT_TD, ROLLOUT_DISCOUNT_POW = 1, 2, 4
+ROLLOUT_WRITE_P, ROLLOUT_TD, ROLLOUT_DISCOUNT_POW, ROLLOUT_F64 = 1, 2, 4, 8
+PRECISION_F64, PRECISION_MIXED = 0, 1
+PRECISIONS = {'f64': PRECISION_F64, 'mixed': PRECISION_MIXED, 0: 0, 1: 1}
 
 
 class MfgError(RuntimeError):
@@ -45,13 +47,14 @@ SIGNATURES = {
     'mfg_gather_start': (_i32, [_p, _i64, _p, _i64, _i32, _p, _p]),
     'mfg_alpha': (_i32, [_p, _i64, _i32, _p, _f64, _p, _p, _p]),
     'mfg_dirichlet_from_gamma': (_i32, [_p, _i64, _i32, _p, _p]),
-    'mfg_sample_dirichlet': (_i32, [_p, _i64, _i32, _p, _f64, _f64, _u64, _u32, _u64, _p, _p]),
+    'mfg_sample_dirichlet': (_i32, [_p, _i64, _i32, _p, _f64, _f64, _u64, _u32, _u64, _i32, _p, _p]),
     'mfg_philox_raw': (_i32, [_u64, _u32, _u32, _u32, _u32, _i64, _p, _p]),
     'mfg_step_given_P': (_i32, [_p, _p, _i64, _i32, _i32, _p, _p, _p]),
     'mfg_value': (_i32, [_p, _p, _i64, _i32, _p, _p]),
     'mfg_features': (_i32, [_p, _i64, _i32, _p, _p]),
-    'mfg_score': (_i32, [_p, _p, _i64, _i32, _p, _f64, _p, _p]),
-    'mfg_td_pg_accumulate': (_i32, [_p, _p, _p, _p, _p, _p, _f64, _f64, _i64, _i32, _p, _p, _p, _i32, _p, _sz, _p]),
+    'mfg_score': (_i32, [_p, _p, _i64, _i32, _p, _f64, _i32, _p, _p]),
+    'mfg_td_pg_accumulate': (_i32, [_p, _p, _p, _p, _p, _p, _f64, _f64, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _sz,
+                                   _p]),
     'mfg_apply_update': (_i32, [_p, _i32, _f64, _f64, _p, _p, _p]),
     'mfg_rollout': (_i32, [_p, _i64, _i32, _i32, _p, _f64, _f64, _p, _f64, _i32, _u64, _u32, _u64, _i32,
                            _p, _p, _p, _p, _p, _p, _i32, _p, _sz, _p]),

@@ -34,9 +34,10 @@ class AC_IRL(actor_critic):
     def __init__(self, theta=8.64, shift=0, alpha_scale=1e4, d=15, lr_reward=1e-4, num_policies=10, c=2e11,
                  reg='dropout_l1l2', n_fc3=8, n_fc4=4, saved_network=None, use_tf=True, summarize=False, *,
                  pi0=None, pi0_test=None, demonstrations=None, demonstrations_test=None, batch=1, rng='philox',
-                 seed=0, update_every='step', device=None, group=None, verbose=1):
+                 seed=0, update_every='step', precision='mixed', device=None, group=None, verbose=1):
         super().__init__(theta=theta, shift=shift, alpha_scale=alpha_scale, d=d, pi0=pi0, batch=batch, rng=rng,
-                         seed=seed, update_every=update_every, device=device, group=group, verbose=verbose)
+                         seed=seed, update_every=update_every, precision=precision, device=device, group=group,
+                         verbose=verbose)
         self.summarize = summarize
         self.theta_initial = theta                      # reset value used by outerloop (ac_irl.py:45, :942)
         self.lr_reward = lr_reward
@@ -164,6 +165,7 @@ class AC_IRL(actor_critic):
                 pi_next, _ = ops.step_given_P(pi, P, want_reward=False)
                 r = rfn(pi, P)
                 ops.td_pg_accumulate(pi, pi_next, P, r, self._w, self._theta, self.shift, discount, G=G, ws=ws,
+                                     precision=self.precision,
                                      accumulate=(self.update_every == 'rollout' and step > 0))
                 if self.update_every == 'step':
                     all_reduce_gradients_(G, self.group)
@@ -226,7 +228,7 @@ class AC_IRL(actor_critic):
         idx = torch.as_tensor(np.random.randint(num, size=n).astype(np.int32), device=self.device)
         pi0 = ops.gather_start(mat_dev, idx)
         r = ops.rollout(pi0, T, self._theta, self.shift, self.alpha_scale, seed=self.seed, first_step=self._rng_step,
-                        traj_offset=self._gen_offset(n), td=False, write_P=True)
+                        traj_offset=self._gen_offset(n), td=False, write_P=True, precision=self.precision)
         self._rng_step += T
         pis = r['pi_traj'].cpu().numpy().astype(np.float64)
         Ps = r['P'].cpu().numpy().astype(np.float64)

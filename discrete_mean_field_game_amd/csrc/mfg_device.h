@@ -52,7 +52,7 @@ __device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5
 
 // ---------------------------------------------------------------------------
 // Gamma(shape a, scale 1), Marsaglia & Tsang (2000) with the U^(1/a) boost for a < 1.
-// fp32; one Philox block = two (normal, uniform) attempts.  Returns > 0 or exactly 0 on
+// fp32; one Philox block per attempt.  Returns > 0 or exactly 0 on
 // underflow (the caller applies the reference's zero replacement).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float gamma_mt(float a, uint64_t seed, uint32_t elem, uint32_t step, uint64_t traj) {
@@ -129,6 +129,42 @@ __device__ __forceinline__ void softplus_sigmoid(double z, double& sp, double& s
   const double e = exp(z);
   sp = log1p(e);
   sg = e / (1.0 + e);
+}
+
+// ---------------------------------------------------------------------------
+// Mixed precision ("MFG_PRECISION_MIXED"): fp32 hardware transcendentals (v_exp_f32 / v_log_f32 /
+// v_rcp_f32, ~1 ulp), fp64 only for the sums.  Measured effect on the score g: ~1e-6 relative.
+// ---------------------------------------------------------------------------
+// alpha = log1p(e^z), sigmoid(z) with z = theta*x given in fp64: the low part of z is folded in so
+// that e carries fp32 (not |z| * 2^-24) relative error; log1p by Kahan's log(u) * e/(u-1).
+__device__ __forceinline__ void softplus_sigmoid_fast(double z, float& sp, float& sg) {
+  const float zh = (float)z;
+  const float zl = (float)(z - (double)zh);
+  float e = __expf(zh);
+  e = fmaf(e, zl, e);
+  const float u = 1.0f + e;
+  sg = e * __builtin_amdgcn_rcpf(u);
+  const float um1 = u - 1.0f;
+  sp = (um1 == 0.0f) ? e : __logf(u) * (e * __builtin_amdgcn_rcpf(um1));
+}
+
+__device__ __forceinline__ float digamma_pos_fast(float x) {
+  float corr = 0.0f;
+  if (x < 8.0f) {
+    float q = x, qp = 1.0f;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const float xk = x + (float)k;
+      qp = fmaf(qp, xk, q);
+      q = q * xk;
+    }
+    corr = qp * __builtin_amdgcn_rcpf(q);
+    x += 8.0f;
+  }
+  const float inv = __builtin_amdgcn_rcpf(x);
+  const float inv2 = inv * inv;
+  const float s = inv2 * (1.0f / 12.0f - inv2 * (1.0f / 120.0f - inv2 * (1.0f / 252.0f)));
+  return __logf(x) - 0.5f * inv - s - corr;
 }
 
 // ---------------------------------------------------------------------------

@@ -15,7 +15,7 @@
 #include <string.h>
 
 #include "../../include/mfg_hip.h"
-#include "mfg_device.h"
+#include "mfg_core.h"
 
 using namespace mfg;
 
@@ -54,8 +54,6 @@ static int num_cus() {
   return cus;
 }
 
-constexpr int BLOCK = 256;
-constexpr int WAVES = BLOCK / WAVE;
 
 // ---------------------------------------------------------------------------------------------
 // trivial kernels: gather, alpha, features, dirichlet_from_gamma, philox_raw, apply_update
@@ -185,20 +183,6 @@ __global__ void k_jsd(const float* __restrict__ p, const float* __restrict__ q, 
 // a5: V(pi) = phi(pi).w, one wavefront per trajectory, lanes own columns c, rows i <= c.
 // w rows are contiguous in k for fixed i, so the loads are coalesced (L2 resident).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double value_wave(const float* pis /*LDS or global, d floats*/, const double* __restrict__ w,
-                                             int d, int lane) {
-  const int Q = d * (d + 1) / 2;
-  double acc = 0.0;
-  for (int c = lane; c < d; c += WAVE) {
-    const double pc = (double)pis[c];
-    double col = 0.0;
-    for (int i = 0; i <= c; ++i) col = fma(w[feat_idx(i, c, d)], (double)pis[i], col);
-    acc = fma(pc, col + w[Q + c], acc);
-  }
-  acc = wave_sum(acc);
-  return acc + w[Q + d];
-}
-
 __global__ void k_value(const float* __restrict__ pi, const double* __restrict__ w, int64_t B, int d,
                         double* __restrict__ out) {
   const int lane = threadIdx.x & (WAVE - 1);
@@ -353,357 +337,6 @@ __global__ __launch_bounds__(BLOCK) void k_step_large(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Core actor-critic kernels: sampling (a1+a2), transition/reward (a3+a4), value (a5), TD error
-// (a6), score (a7) -- T steps with fixed (theta, w), state kept on chip.
-// ---------------------------------------------------------------------------------------------
-struct CoreArgs {
-  const float* pi0;         // [B,d]
-  const float* pi_alpha;    // GIVEN: state the concentrations are computed from (NULL -> pi0)
-  const float* P_in;        // GIVEN: [B,d,d]
-  const float* pi_next_in;  // GIVEN: [B,d] (may be NULL when no delta is wanted)
-  const float* reward_in;   // external reward [B*T] or NULL
-  const double* theta;
-  const double* w;          // NULL -> no value / delta
-  double shift, alpha_scale, gamma;
-  int64_t B;
-  int d, T, reward_kind, discount_pow;
-  uint64_t seed;
-  uint32_t first_step;
-  uint64_t traj_offset;
-  float* pi_traj;     // [B,T+1,d] or NULL
-  float* pi_next_out; // [B,d] final state or NULL
-  float* reward_out;  // [B,T] or NULL
-  double* delta;      // [B,T] or NULL
-  double* g;          // [B,T] or NULL
-  float* P_out;       // [B,T,d,d] or NULL
-};
-
-__device__ __forceinline__ double reward_term(int kind, double pii, double pj, double p) {
-  // contribution of element (i,j) BEFORE the factor pi_i (kind 0) / -0.5 pi_i (kind 1)
-  return kind == MFG_REWARD_MFG_AC2 ? (pj - pii) * p * p : p * p;
-}
-
-// small d: lane = (trajectory t, row i).  LDS per block: tile[TB][d][dp] (gamma variates, then P),
-// pis[TB][d], pin[TB][d], wl[F] (critic weights, fp64).
-template <bool SAMPLE, bool TD>
-__global__ __launch_bounds__(BLOCK) void k_core_small(CoreArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int d = a.d, dd = d * d, dp = d | 1, T = a.T;
-  const int G = WAVE / d, TB = WAVES * G;
-  const int Q = d * (d + 1) / 2, F = Q + d + 1;
-  const bool want_v = TD && a.w != nullptr;
-  double* wl = reinterpret_cast<double*>(smem_raw);                   // [F] (only if want_v)
-  float* tile = reinterpret_cast<float*>(wl + (want_v ? F : 0));      // [TB][d][dp]
-  float* pis = tile + TB * d * dp;                                    // [TB][d]
-  float* pin = pis + TB * d;                                          // [TB][d]
-  float* pal = pin + TB * d;                                          // [TB][d] (GIVEN with pi_alpha)
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-  const int t = lane / d, i = lane - t * d;
-  const int p2 = next_pow2(d);
-  const double theta = *a.theta;
-  const float inv_d = 1.0f / (float)d;
-  if (want_v) {
-    for (int k = tid; k < F; k += BLOCK) wl[k] = a.w[k];
-  }
-  const int64_t ntiles = (a.B + TB - 1) / TB;
-  for (int64_t tileid = blockIdx.x; tileid < ntiles; tileid += gridDim.x) {
-    const int64_t b0 = tileid * TB;
-    const int nb = (int)((a.B - b0) < TB ? (a.B - b0) : TB);
-    const int tl = wv * G + t;
-    const bool valid = (t < G) && (tl < nb);
-    const int tlc = valid ? tl : 0;
-    const int64_t b = b0 + tlc;
-    float pi_i = a.pi0[b * d + i];
-    if (valid && a.pi_traj) a.pi_traj[b * (int64_t)(T + 1) * d + i] = pi_i;
-    double v_cur = 0.0, discount = 1.0;
-    bool have_v = false;
-    for (int s = 0; s < T; ++s) {
-      __syncthreads();
-      if (valid) pis[tlc * d + i] = pi_i;
-      if (!SAMPLE) {
-        // stage the given P tile (flat, coalesced) into the padded LDS tile
-        const int n = nb * dd;
-        const float* src = a.P_in + b0 * dd;
-        for (int k = tid; k < n; k += BLOCK) {
-          const int row = (int)(((float)k + 0.5f) * inv_d);
-          const int colj = k - row * d;
-          tile[row * dp + colj] = src[k];
-        }
-        if (a.pi_next_in)
-          for (int k = tid; k < nb * d; k += BLOCK) pin[k] = a.pi_next_in[b0 * d + k];
-        if (a.pi_alpha)
-          for (int k = tid; k < nb * d; k += BLOCK) pal[k] = a.pi_alpha[b0 * d + k];
-      }
-      __syncthreads();
-      float* trow = tile + (tlc * d + i) * dp;
-      const float* pv = pis + tlc * d;
-      const float* pav = (!SAMPLE && a.pi_alpha) ? pal + tlc * d : pv;
-      const double pai = (double)pav[i];
-      const double pid = (double)pi_i;
-      double A = 0.0, D = 0.0, Ssum = 0.0, gacc = 0.0, racc = 0.0;
-      if (valid) {
-      for (int j = 0; j < d; ++j) {
-        double al = 0.0, ad = 0.0;
-        if (SAMPLE || TD) {
-          const double x = (double)pav[j] - pai - a.shift;
-          double sg;
-          softplus_sigmoid(theta * x, al, sg);
-          ad = x * sg;
-        }
-        double lnv = 0.0;
-        if (SAMPLE) {
-          float y = gamma_mt((float)(al * a.alpha_scale), a.seed, (uint32_t)(i * d + j), a.first_step + (uint32_t)s,
-                             a.traj_offset + (uint64_t)b);
-          if (y == 0.0f) y = ZERO_GAMMA_REPLACEMENT;
-          Ssum += (double)y;
-          trow[j] = y;
-          if (TD) lnv = log((double)y);
-        } else {
-          const double p = (double)trow[j];
-          if (TD) lnv = (p == 0.0) ? LOG_ZERO_P : log(p);
-          racc += reward_term(a.reward_kind, pid, (double)pv[j], p);
-        }
-        if (TD) {
-          A += al;
-          D += ad;
-          gacc = fma(-digamma_pos(al) + lnv, ad, gacc);
-        }
-      }
-      if (SAMPLE) {
-        // normalise the row: P_ij = fl32(y_ij / S_i); the reward uses the stored fp32 P
-        const double invS = 1.0 / Ssum;
-        for (int j = 0; j < d; ++j) {
-          const float p32 = (float)((double)trow[j] * invS);
-          trow[j] = p32;
-          racc += reward_term(a.reward_kind, pid, (double)pv[j], (double)p32);
-        }
-        if (TD) gacc -= log(Ssum) * D;
-      }
-      if (TD) gacc = fma(digamma_pos(A), D, gacc);
-      }  // valid
-      __syncthreads();
-      float pi_n;
-      if (SAMPLE) {
-        // pi'_i = sum_k pi_k P_ki : column read of the tile (consecutive lanes, consecutive banks)
-        double acc = 0.0;
-        const float* tcol = tile + tlc * d * dp + i;
-        for (int k = 0; k < d; ++k) acc = fma((double)tcol[k * dp], (double)pv[k], acc);
-        pi_n = (float)acc;
-        if (valid) pin[tlc * d + i] = pi_n;
-        if (a.P_out) {
-          // coalesced copy-out of the block's P tile
-          const int n = nb * dd;
-          float* dst = a.P_out + (b0 * (int64_t)T) * dd;  // trajectory-major [B,T,d,d]
-          for (int k = tid; k < n; k += BLOCK) {
-            const int row = (int)(((float)k + 0.5f) * inv_d);  // tl*d + i
-            const int colj = k - row * d;
-            const int tl2 = (int)(((float)row + 0.5f) * inv_d);
-            const int ii = row - tl2 * d;
-            dst[((int64_t)tl2 * T + s) * dd + ii * d + colj] = tile[row * dp + colj];
-          }
-        }
-      } else {
-        pi_n = a.pi_next_in ? pin[tlc * d + i] : 0.0f;
-      }
-      double r;
-      if (a.reward_kind == MFG_REWARD_EXTERNAL) {
-        r = a.reward_in ? (double)a.reward_in[b * T + s] : 0.0;
-      } else {
-        r = seg_sum(pid * racc, i, d, p2);
-        if (a.reward_kind == MFG_REWARD_SYNTHETIC) r *= -0.5;
-      }
-      if (valid && i == 0 && a.reward_out) a.reward_out[b * T + s] = (float)r;
-      if (TD) {
-        const double gsum = seg_sum(gacc, i, d, p2);
-        if (valid && i == 0 && a.g) a.g[b * T + s] = gsum;
-        if (want_v) {
-          __syncthreads();  // pin complete
-          if (!have_v) {
-            double col = 0.0;
-            for (int k = 0; k <= i; ++k) col = fma(wl[feat_idx(k, i, d)], (double)pv[k], col);
-            v_cur = seg_sum(pid * (col + wl[Q + i]), i, d, p2) + wl[Q + d];
-            have_v = true;
-          }
-          const float* pn = pin + tlc * d;
-          double col = 0.0;
-          for (int k = 0; k <= i; ++k) col = fma(wl[feat_idx(k, i, d)], (double)pn[k], col);
-          const double v_next = seg_sum((double)pi_n * (col + wl[Q + i]), i, d, p2) + wl[Q + d];
-          const double gd = a.discount_pow ? discount : a.gamma;
-          const double del = r + gd * v_next - v_cur;
-          if (valid && i == 0 && a.delta) a.delta[b * T + s] = del;
-          v_cur = v_next;
-          discount *= a.gamma;
-        }
-      }
-      if (valid && a.pi_traj) a.pi_traj[(b * (int64_t)(T + 1) + s + 1) * d + i] = pi_n;
-      pi_i = pi_n;
-    }
-    if (valid && a.pi_next_out) a.pi_next_out[b * d + i] = pi_i;
-  }
-}
-
-// large d: one wavefront per trajectory, lane owns columns c = lane + 64 m (m < R).
-template <int R, bool SAMPLE, bool TD>
-__global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int d = a.d, T = a.T;
-  const int64_t dd = (int64_t)d * d;
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-  float* pis = smem + wv * 3 * d;  // current state
-  float* pin = pis + d;            // next state
-  float* pal = pin + d;            // state for alpha (GIVEN with pi_alpha)
-  const bool want_v = TD && a.w != nullptr;
-  const double theta = *a.theta;
-  const int64_t nw = (int64_t)gridDim.x * WAVES;
-  for (int64_t b = (int64_t)blockIdx.x * WAVES + wv; b < a.B; b += nw) {
-    float pc[R];
-#pragma unroll
-    for (int m = 0; m < R; ++m) {
-      const int c = lane + m * WAVE;
-      pc[m] = c < d ? a.pi0[b * d + c] : 0.0f;
-      if (c < d && a.pi_traj) a.pi_traj[b * (int64_t)(T + 1) * d + c] = pc[m];
-    }
-    double v_cur = 0.0, discount = 1.0;
-    bool have_v = false;
-    for (int s = 0; s < T; ++s) {
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int m = 0; m < R; ++m) {
-        const int c = lane + m * WAVE;
-        if (c < d) {
-          pis[c] = pc[m];
-          if (!SAMPLE && a.pi_next_in) pin[c] = a.pi_next_in[b * d + c];
-          if (!SAMPLE && a.pi_alpha) pal[c] = a.pi_alpha[b * d + c];
-        }
-      }
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
-      const float* pav = (!SAMPLE && a.pi_alpha) ? pal : pis;
-      double pcd[R], pad[R], acc[R];
-#pragma unroll
-      for (int m = 0; m < R; ++m) {
-        const int c = lane + m * WAVE;
-        pcd[m] = (double)pc[m];
-        pad[m] = c < d ? (double)pav[c] : 0.0;
-        acc[m] = 0.0;
-      }
-      double racc = 0.0, gacc = 0.0, guni = 0.0;
-      const float* Pb = SAMPLE ? nullptr : a.P_in + b * dd;
-      float* Po = (SAMPLE && a.P_out) ? a.P_out + (b * (int64_t)T + s) * dd : nullptr;
-      for (int i = 0; i < d; ++i) {
-        const double pii = (double)pis[i];
-        const double pai = (double)pav[i];
-        float y[R];
-        double Ssum = 0.0, A = 0.0, D = 0.0;
-#pragma unroll
-        for (int m = 0; m < R; ++m) {
-          const int c = lane + m * WAVE;
-          y[m] = 0.0f;
-          if (c < d) {
-            double al = 0.0, ad = 0.0;
-            if (SAMPLE || TD) {
-              const double x = pad[m] - pai - a.shift;
-              double sg;
-              softplus_sigmoid(theta * x, al, sg);
-              ad = x * sg;
-            }
-            double lnv = 0.0;
-            if (SAMPLE) {
-              float yy = gamma_mt((float)(al * a.alpha_scale), a.seed, (uint32_t)(i * d + c),
-                                  a.first_step + (uint32_t)s, a.traj_offset + (uint64_t)b);
-              if (yy == 0.0f) yy = ZERO_GAMMA_REPLACEMENT;
-              y[m] = yy;
-              Ssum += (double)yy;
-              if (TD) lnv = log((double)yy);
-            } else {
-              y[m] = Pb[(int64_t)i * d + c];
-              if (TD) lnv = (y[m] == 0.0f) ? LOG_ZERO_P : log((double)y[m]);
-            }
-            if (TD) {
-              A += al;
-              D += ad;
-              gacc = fma(-digamma_pos(al) + lnv, ad, gacc);
-            }
-          }
-        }
-        double invS = 1.0;
-        if (SAMPLE) {
-          Ssum = wave_sum(Ssum);
-          invS = 1.0 / Ssum;
-        }
-        if (TD) {
-          A = wave_sum(A);
-          D = wave_sum(D);
-          guni += digamma_pos(A) * D;
-          if (SAMPLE) guni -= log(Ssum) * D;
-        }
-#pragma unroll
-        for (int m = 0; m < R; ++m) {
-          const int c = lane + m * WAVE;
-          if (c < d) {
-            const float p32 = SAMPLE ? (float)((double)y[m] * invS) : y[m];
-            const double p = (double)p32;
-            if (Po) Po[(int64_t)i * d + c] = p32;
-            acc[m] = fma(p, pii, acc[m]);
-            racc += pii * reward_term(a.reward_kind, pii, pcd[m], p);
-          }
-        }
-      }
-      // next state
-      float pn[R];
-#pragma unroll
-      for (int m = 0; m < R; ++m) {
-        const int c = lane + m * WAVE;
-        if (SAMPLE) {
-          pn[m] = (float)acc[m];
-          if (c < d) pin[c] = pn[m];
-        } else {
-          pn[m] = (c < d && a.pi_next_in) ? pin[c] : 0.0f;
-        }
-      }
-      double r;
-      if (a.reward_kind == MFG_REWARD_EXTERNAL) {
-        r = a.reward_in ? (double)a.reward_in[b * T + s] : 0.0;
-      } else {
-        r = wave_sum(racc);
-        if (a.reward_kind == MFG_REWARD_SYNTHETIC) r *= -0.5;
-      }
-      if (lane == 0 && a.reward_out) a.reward_out[b * T + s] = (float)r;
-      if (TD) {
-        const double gsum = wave_sum(gacc) + guni;
-        if (lane == 0 && a.g) a.g[b * T + s] = gsum;
-        if (want_v) {
-          __builtin_amdgcn_s_waitcnt(0xc07f);
-          __builtin_amdgcn_wave_barrier();
-          if (!have_v) {
-            v_cur = value_wave(pis, a.w, d, lane);
-            have_v = true;
-          }
-          const double v_next = value_wave(pin, a.w, d, lane);
-          const double gd = a.discount_pow ? discount : a.gamma;
-          const double del = r + gd * v_next - v_cur;
-          if (lane == 0 && a.delta) a.delta[b * T + s] = del;
-          v_cur = v_next;
-          discount *= a.gamma;
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < R; ++m) {
-        const int c = lane + m * WAVE;
-        if (c < d && a.pi_traj) a.pi_traj[(b * (int64_t)(T + 1) + s + 1) * d + c] = pn[m];
-        pc[m] = pn[m];
-      }
-    }
-#pragma unroll
-    for (int m = 0; m < R; ++m) {
-      const int c = lane + m * WAVE;
-      if (c < d && a.pi_next_out) a.pi_next_out[b * d + c] = pc[m];
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // a6/a8 batch sums: G = [ sum_n delta_n phi(pi_n) | sum delta_n g_n | sum r_n | N ].
 // The quadratic block is sum_n delta_n pi_n pi_n^T (upper triangle): each block owns a chunk of
 // samples (staged in LDS) x a chunk of 4*BLOCK outputs; partials go to the workspace and are summed
@@ -849,45 +482,12 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
   return check_launch("grad_reduce");
 }
 
-static size_t core_small_lds(int d, bool want_v) {
-  const int G = WAVE / d, TB = WAVES * G, dp = d | 1;
-  const int64_t F = mfg_num_features(d);
-  return (want_v ? (size_t)F * 8 : 0) + (size_t)TB * d * dp * 4 + 3 * (size_t)TB * d * 4;
-}
-
-template <bool SAMPLE, bool TD>
-static int launch_core(const CoreArgs& a, hipStream_t st) {
-  const int d = a.d;
-  if (d <= WAVE) {
-    const bool want_v = TD && a.w != nullptr;
-    const size_t lds = core_small_lds(d, want_v);
-    const int G = WAVE / d, TB = WAVES * G;
-    int bpc = (int)((160 * 1024) / (lds + 256));
-    if (bpc > 8) bpc = 8;
-    if (bpc < 1) bpc = 1;
-    const int grid = grid_for(a.B, TB, bpc);
-    hipLaunchKernelGGL((k_core_small<SAMPLE, TD>), dim3(grid), dim3(BLOCK), lds, st, a);
-  } else {
-    const int R = (d + WAVE - 1) / WAVE;
-    const size_t lds = (size_t)WAVES * 3 * d * 4;
-    const int grid = grid_for(a.B, WAVES, 8);
-#define CORE_LARGE(RR)                                                                                  \
-  case RR:                                                                                              \
-    hipLaunchKernelGGL((k_core_large<RR, SAMPLE, TD>), dim3(grid), dim3(BLOCK), lds, st, a);             \
-    break;
-    switch (R) {
-      CORE_LARGE(2)
-      CORE_LARGE(3)
-      CORE_LARGE(4)
-      CORE_LARGE(5)
-      CORE_LARGE(6)
-      CORE_LARGE(7)
-      CORE_LARGE(8)
-      default:
-        return fail(MFG_EUNSUPPORTED, "%s: d=%lld > %lld", "core", (long long)d, (long long)MFG_MAX_D);
-    }
-#undef CORE_LARGE
-  }
+static int launch_core(const CoreArgs& a, bool sample, bool td, int precision, hipStream_t st) {
+  int rc;
+  if (a.d <= WAVE) rc = launch_core_small(a, sample, td, precision == MFG_PRECISION_MIXED, num_cus(), st);
+  else if (precision == MFG_PRECISION_MIXED) rc = launch_core_large_mixed(a, sample, td, num_cus(), st);
+  else rc = launch_core_large_f64(a, sample, td, num_cus(), st);
+  if (rc != MFG_OK) return fail(rc, "%s: d=%lld > %lld", "core", (long long)a.d, (long long)MFG_MAX_D);
   return check_launch("core");
 }
 
@@ -897,7 +497,7 @@ static int launch_core(const CoreArgs& a, hipStream_t st) {
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 1; }
+int mfg_abi_version(void) { return 2; }
 
 int mfg_device_info(int* cu_count_host, char* arch_host, int arch_len) {
   int dev = 0;
@@ -1058,9 +658,13 @@ int mfg_jsd(const float* p, const float* q, int64_t B, int d, double* out, mfg_s
   return check_launch("jsd");
 }
 
+#define CHECK_PRECISION() REQUIRE(precision == MFG_PRECISION_F64 || precision == MFG_PRECISION_MIXED, "bad precision")
+
 int mfg_sample_dirichlet(const float* pi, int64_t B, int d, const double* theta, double shift, double alpha_scale,
-                         uint64_t seed, uint32_t step, uint64_t traj_offset, float* P, mfg_stream_t stream) {
+                         uint64_t seed, uint32_t step, uint64_t traj_offset, int precision, float* P,
+                         mfg_stream_t stream) {
   CHECK_BD();
+  CHECK_PRECISION();
   REQUIRE(pi && theta && P, "null pointer");
   CoreArgs a{};
   a.pi0 = pi;
@@ -1076,12 +680,13 @@ int mfg_sample_dirichlet(const float* pi, int64_t B, int d, const double* theta,
   a.first_step = step;
   a.traj_offset = traj_offset;
   a.P_out = P;
-  return launch_core<true, false>(a, S(stream));
+  return launch_core(a, true, false, precision, S(stream));
 }
 
-int mfg_score(const float* pi_alpha, const float* P, int64_t B, int d, const double* theta, double shift, double* g,
-              mfg_stream_t stream) {
+int mfg_score(const float* pi_alpha, const float* P, int64_t B, int d, const double* theta, double shift,
+              int precision, double* g, mfg_stream_t stream) {
   CHECK_BD();
+  CHECK_PRECISION();
   REQUIRE(pi_alpha && P && theta && g, "null pointer");
   CoreArgs a{};
   a.pi0 = pi_alpha;
@@ -1094,14 +699,15 @@ int mfg_score(const float* pi_alpha, const float* P, int64_t B, int d, const dou
   a.T = 1;
   a.reward_kind = MFG_REWARD_EXTERNAL;
   a.g = g;
-  return launch_core<false, true>(a, S(stream));
+  return launch_core(a, false, true, precision, S(stream));
 }
 
 int mfg_td_pg_accumulate(const float* pi, const float* pi_next, const float* P, const float* reward, const double* w,
-                         const double* theta, double shift, double gamma_or_discount, int64_t B, int d, double* delta,
-                         double* g, double* G, int accumulate, void* workspace, size_t workspace_bytes,
-                         mfg_stream_t stream) {
+                         const double* theta, double shift, double gamma_or_discount, int64_t B, int d, int precision,
+                         double* delta, double* g, double* G, int accumulate, void* workspace,
+                         size_t workspace_bytes, mfg_stream_t stream) {
   CHECK_BD();
+  CHECK_PRECISION();
   REQUIRE(pi && pi_next && P && reward && w && theta && delta && g, "null pointer");
   CoreArgs a{};
   a.pi0 = pi;
@@ -1118,7 +724,7 @@ int mfg_td_pg_accumulate(const float* pi, const float* pi_next, const float* P, 
   a.reward_kind = MFG_REWARD_EXTERNAL;
   a.delta = delta;
   a.g = g;
-  int rc = launch_core<false, true>(a, S(stream));
+  int rc = launch_core(a, false, true, precision, S(stream));
   if (rc != MFG_OK || !G) return rc;
   REQUIRE(workspace, "workspace is null");
   return launch_grad(pi, d, delta, g, reward, B, 1, d, G, accumulate, workspace, workspace_bytes, S(stream));
@@ -1164,7 +770,8 @@ int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, 
   a.delta = delta;
   a.g = g;
   a.P_out = (flags & MFG_ROLLOUT_WRITE_P) ? P_out : nullptr;
-  int rc = td ? launch_core<true, true>(a, S(stream)) : launch_core<true, false>(a, S(stream));
+  const int precision = (flags & MFG_ROLLOUT_F64) ? MFG_PRECISION_F64 : MFG_PRECISION_MIXED;
+  int rc = launch_core(a, true, td, precision, S(stream));
   if (rc != MFG_OK || !td || !G) return rc;
   REQUIRE(workspace, "workspace is null");
   return launch_grad(pi_traj, (int64_t)(T + 1) * d, delta, g, reward, B * T, T, d, G, accumulate, workspace,

@@ -15,6 +15,7 @@ mat_pi0, num_start_samples, mat_alpha, mat_alpha_deriv``.  Extensions are keywor
                                 np.random stream in the reference's exact order (mfg_ac2.py:242, :466),
                                 so a seeded batch-1 run retraces the reference; the math still runs on
                                 the GPU
+  precision         : 'mixed' (fp32 hardware transcendentals, fp64 sums; default) or 'f64' (strict)
   update_every      : 'step' (reference semantics: theta, w move after every env step; batch-mean
                       gradient) or 'rollout' (one fused T-step kernel + one update per episode)
   group             : torch.distributed process group; the batch is the GLOBAL batch and is sharded
@@ -43,8 +44,8 @@ def _as_np(x):
 class actor_critic:
 
     def __init__(self, theta=8.86349, shift=0.16, alpha_scale=12000, d=21, *, pi0=None, path_to_dir=None,
-                 batch=1, rng='philox', seed=0, update_every='step', reward='mfg_ac2', device=None, group=None,
-                 verbose=1):
+                 batch=1, rng='philox', seed=0, update_every='step', reward='mfg_ac2', precision='mixed', device=None,
+                 group=None, verbose=1):
         if rng not in ('philox', 'numpy'):
             raise ValueError("rng must be 'philox' or 'numpy'")
         if update_every not in ('step', 'rollout'):
@@ -60,6 +61,9 @@ class actor_critic:
         self.seed = int(seed)
         self.update_every = update_every
         self.reward_kind = {'mfg_ac2': L.REWARD_MFG_AC2, 'synthetic': L.REWARD_SYNTHETIC}[reward]
+        if precision not in ('mixed', 'f64'):
+            raise ValueError("precision must be 'mixed' or 'f64'")
+        self.precision = precision
         self.group = group
         self.verbose = verbose
         self.batch = int(batch)
@@ -216,7 +220,7 @@ class actor_critic:
         if self.rng == 'numpy':
             return ops.dirichlet_from_gamma(self._host_gamma(pi_dev))
         P = ops.sample_dirichlet(pi_dev, self._theta, self.shift, self.alpha_scale, self.seed, self._rng_step,
-                                 traj_offset)
+                                 traj_offset, precision=self.precision)
         self._rng_step += 1
         return P
 
@@ -258,7 +262,7 @@ class actor_critic:
         replaces zeros of a NumPy ``P`` by 1e-100 in place (:369)."""
         pi_dev, single = self._pi_dev(pi)
         pa = self._pi_alpha if (self._pi_alpha is not None and self._pi_alpha.shape == pi_dev.shape) else pi_dev
-        g = ops.score(pa, self._P_dev(P), self._theta, self.shift)
+        g = ops.score(pa, self._P_dev(P), self._theta, self.shift, precision=self.precision)
         if isinstance(P, np.ndarray) and P.dtype == np.float64:
             P[P == 0] = 1e-100
         if isinstance(pi, torch.Tensor):
@@ -307,7 +311,7 @@ class actor_critic:
             if self.update_every == 'rollout' and self.rng == 'philox':
                 out = ops.rollout(pi, T, self._theta, self.shift, self.alpha_scale, w=self._w, gamma=gamma,
                                   reward_kind=self.reward_kind, seed=self.seed, first_step=self._rng_step,
-                                  traj_offset=shard.traj_offset, td=True, G=G, ws=ws)
+                                  traj_offset=shard.traj_offset, td=True, G=G, ws=ws, precision=self.precision)
                 self._rng_step += T
                 all_reduce_gradients_(G, self.group)
                 ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta)
@@ -321,7 +325,7 @@ class actor_critic:
                     if self.rng == 'philox':
                         out = ops.rollout(pi, 1, self._theta, self.shift, self.alpha_scale, w=self._w, gamma=gamma,
                                           reward_kind=self.reward_kind, seed=self.seed, first_step=self._rng_step,
-                                          traj_offset=shard.traj_offset, td=True, G=G, ws=ws,
+                                          traj_offset=shard.traj_offset, td=True, G=G, ws=ws, precision=self.precision,
                                           accumulate=(self.update_every == 'rollout' and step > 0))
                         self._rng_step += 1
                         pi_next = out['pi_traj'][:, 1].contiguous()
@@ -331,6 +335,7 @@ class actor_critic:
                             self._write_all(pi, P, step + 1)
                         pi_next, r = ops.step_given_P(pi, P, reward_kind=self.reward_kind)
                         ops.td_pg_accumulate(pi, pi_next, P, r, self._w, self._theta, self.shift, gamma, G=G, ws=ws,
+                                             precision=self.precision,
                                              accumulate=(self.update_every == 'rollout' and step > 0))
                     if self.update_every == 'step':
                         all_reduce_gradients_(G, self.group)
@@ -394,7 +399,7 @@ class actor_critic:
         T = total_hours - 1
         if self.rng == 'philox' and T >= 1:
             out = ops.rollout(pi_dev, T, self._theta, self.shift, self.alpha_scale, seed=self.seed,
-                              first_step=self._rng_step, td=False, reward_kind=self.reward_kind)
+                              first_step=self._rng_step, td=False, reward_kind=self.reward_kind, precision=self.precision)
             self._rng_step += T
             traj = out['pi_traj']
         else:

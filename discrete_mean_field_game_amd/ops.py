@@ -72,12 +72,13 @@ def dirichlet_from_gamma(y):
     return P
 
 
-def sample_dirichlet(pi, theta, shift, alpha_scale, seed, step=0, traj_offset=0, out=None):
+def sample_dirichlet(pi, theta, shift, alpha_scale, seed, step=0, traj_offset=0, out=None, precision='mixed'):
     _chk_f32(pi, 'pi'); _chk_f64(theta, 'theta')
     B, d = pi.shape
     P = out if out is not None else torch.empty(B, d, d, dtype=torch.float32, device=pi.device)
     L.check(L.lib().mfg_sample_dirichlet(pi.data_ptr(), B, d, theta.data_ptr(), float(shift), float(alpha_scale),
-                                         int(seed), int(step), int(traj_offset), P.data_ptr(), _stream()),
+                                         int(seed), int(step), int(traj_offset), L.PRECISIONS[precision], P.data_ptr(),
+                                         _stream()),
             'mfg_sample_dirichlet')
     return P
 
@@ -117,16 +118,17 @@ def features(pi):
     return out
 
 
-def score(pi_alpha, P, theta, shift):
+def score(pi_alpha, P, theta, shift, precision='mixed'):
     _chk_f32(pi_alpha, 'pi'); _chk_f32(P, 'P'); _chk_f64(theta, 'theta')
     B, d = pi_alpha.shape
     g = torch.empty(B, dtype=torch.float64, device=P.device)
-    L.check(L.lib().mfg_score(pi_alpha.data_ptr(), P.data_ptr(), B, d, theta.data_ptr(), float(shift), g.data_ptr(),
-                              _stream()), 'mfg_score')
+    L.check(L.lib().mfg_score(pi_alpha.data_ptr(), P.data_ptr(), B, d, theta.data_ptr(), float(shift),
+                              L.PRECISIONS[precision], g.data_ptr(), _stream()), 'mfg_score')
     return g
 
 
-def td_pg_accumulate(pi, pi_next, P, reward, w, theta, shift, gamma_or_discount, G=None, accumulate=False, ws=None):
+def td_pg_accumulate(pi, pi_next, P, reward, w, theta, shift, gamma_or_discount, G=None, accumulate=False, ws=None,
+                     precision='mixed'):
     for t, n in ((pi, 'pi'), (pi_next, 'pi_next'), (P, 'P'), (reward, 'reward')):
         _chk_f32(t, n)
     _chk_f64(w, 'w'); _chk_f64(theta, 'theta')
@@ -140,7 +142,8 @@ def td_pg_accumulate(pi, pi_next, P, reward, w, theta, shift, gamma_or_discount,
         ws = workspace(B, d, pi.device)
     L.check(L.lib().mfg_td_pg_accumulate(pi.data_ptr(), pi_next.data_ptr(), P.data_ptr(), reward.data_ptr(),
                                          w.data_ptr(), theta.data_ptr(), float(shift), float(gamma_or_discount),
-                                         B, d, delta.data_ptr(), g.data_ptr(), G.data_ptr(), int(accumulate),
+                                         B, d, L.PRECISIONS[precision], delta.data_ptr(), g.data_ptr(), G.data_ptr(),
+                                         int(accumulate),
                                          ws.data_ptr(), ws.numel() * 8, _stream()), 'mfg_td_pg_accumulate')
     return delta, g, G
 
@@ -153,7 +156,7 @@ def apply_update(G, d, lr_critic, lr_actor, w, theta):
 
 def rollout(pi0, T, theta, shift, alpha_scale, w=None, gamma=1.0, reward_kind=L.REWARD_MFG_AC2, seed=0,
             first_step=0, traj_offset=0, td=True, write_P=False, discount_pow=False, G=None, accumulate=False,
-            ws=None, out=None):
+            ws=None, out=None, precision='mixed'):
     """Fused T-step rollout.  Returns dict(pi_traj, reward, delta, g, P, G)."""
     _chk_f32(pi0, 'pi0'); _chk_f64(theta, 'theta')
     B, d = pi0.shape
@@ -178,6 +181,8 @@ def rollout(pi0, T, theta, shift, alpha_scale, w=None, gamma=1.0, reward_kind=L.
         P = o.get('P') if 'P' in o else torch.empty(B, T, d, d, dtype=torch.float32, device=dev)
     if discount_pow:
         flags |= L.ROLLOUT_DISCOUNT_POW
+    if L.PRECISIONS[precision] == L.PRECISION_F64:
+        flags |= L.ROLLOUT_F64
     L.check(L.lib().mfg_rollout(pi0.data_ptr(), B, d, T, theta.data_ptr(), float(shift), float(alpha_scale),
                                 _ptr(w) if td else None, float(gamma), int(reward_kind), int(seed), int(first_step),
                                 int(traj_offset), flags, pi_traj.data_ptr(), reward.data_ptr(), _ptr(delta), _ptr(g),

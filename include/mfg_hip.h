@@ -50,11 +50,18 @@ enum {
   MFG_REWARD_EXTERNAL = 2   /* reward supplied by the caller (IRL reward net, ac_irl.py:683) */
 };
 
+/* precision of the per-element policy math (softplus / sigmoid / digamma / log):
+ *   F64   every transcendental in fp64 (matches the fp64 oracle to ~1e-12 on identical inputs)
+ *   MIXED fp32 hardware transcendentals, fp64 only for the sums (score g within ~1e-6 relative;
+ *         rewards, transitions, values and TD errors are unaffected: they never use these functions) */
+enum { MFG_PRECISION_F64 = 0, MFG_PRECISION_MIXED = 1 };
+
 /* flags for mfg_rollout */
 enum {
   MFG_ROLLOUT_WRITE_P = 1,     /* materialise P[B,T,d,d] (IRL / generate_trajectories, ac_irl.py:762) */
   MFG_ROLLOUT_TD = 2,          /* also compute reward, delta, g per step (train); else env only */
-  MFG_ROLLOUT_DISCOUNT_POW = 4 /* bootstrap with running gamma^t (ac_irl.py:691,710) instead of gamma */
+  MFG_ROLLOUT_DISCOUNT_POW = 4, /* bootstrap with running gamma^t (ac_irl.py:691,710) instead of gamma */
+  MFG_ROLLOUT_F64 = 8           /* MFG_PRECISION_F64 instead of the default MFG_PRECISION_MIXED */
 };
 
 const char* mfg_last_error(void);
@@ -89,8 +96,8 @@ int mfg_dirichlet_from_gamma(const float* y, int64_t B, int d, float* P, mfg_str
  * global trajectory id traj_offset + b, draw) so results do not depend on launch
  * geometry or world size. */
 int mfg_sample_dirichlet(const float* pi, int64_t B, int d, const double* theta, double shift,
-                         double alpha_scale, uint64_t seed, uint32_t step, uint64_t traj_offset, float* P,
-                         mfg_stream_t stream);
+                         double alpha_scale, uint64_t seed, uint32_t step, uint64_t traj_offset, int precision,
+                         float* P, mfg_stream_t stream);
 
 /* Raw Philox4x32-10 blocks for counters (c0 = first_ctr + n, c1, c2, c3): out[n,4] u32.  Test hook
  * for bit-exact RNG parity. */
@@ -112,14 +119,14 @@ int mfg_features(const float* pi, int64_t B, int d, double* phi, mfg_stream_t st
  * behind by the previous sample_action; pass pi itself for the normal case).  Zeros of P count as
  * 1e-100 (mfg_ac2.py:369); P is not modified. */
 int mfg_score(const float* pi_alpha, const float* P, int64_t B, int d, const double* theta, double shift,
-              double* g, mfg_stream_t stream);
+              int precision, double* g, mfg_stream_t stream);
 
 /* a5-a8 on given transitions: delta[b] = r + gamma_or_discount V(pi') - V(pi), g[b] as mfg_score,
  * and the batch sums G = [ sum_b delta_b phi(pi_b) (F) | sum_b delta_b g_b | sum_b r_b | B ] (fp64,
  * F+3 entries; accumulate != 0 adds onto the existing contents of G).  (mfg_ac2.py:501-522) */
 int mfg_td_pg_accumulate(const float* pi, const float* pi_next, const float* P, const float* reward,
                          const double* w, const double* theta, double shift, double gamma_or_discount,
-                         int64_t B, int d, double* delta, double* g, double* G, int accumulate,
+                         int64_t B, int d, int precision, double* delta, double* g, double* G, int accumulate,
                          void* workspace, size_t workspace_bytes, mfg_stream_t stream);
 
 /* a6/a8: w += lr_critic * G_w / count ; theta += lr_actor * G_theta / count  (mfg_ac2.py:511-522).

@@ -89,11 +89,12 @@ def test_batched_inputs(dev):
 
 
 @pytest.mark.parametrize('name', ['c0_g1', 'c1_g1', 'c0_g09', 'c1_g09'])
-def test_train_retraces_reference_mfg_ac2(dev, name):
+@pytest.mark.parametrize('precision', ['mixed', 'f64'])
+def test_train_retraces_reference_mfg_ac2(dev, name, precision):
     z = np.load(os.path.join(G, 'train_mfg_ac2_%s.npz' % name))
     np.random.seed(int(z['seed']))
     ac = AC(theta=float(z['theta0']), shift=float(z['shift']), alpha_scale=float(z['alpha_scale']), d=21,
-            pi0=z['mat_pi0'], batch=1, rng='numpy', update_every='step')
+            pi0=z['mat_pi0'], batch=1, rng='numpy', update_every='step', precision=precision)
     assert np.array_equal(ac.w, z['w0'])                              # same init_w draw as the reference
     ac.trace = []
     ac.train(num_episodes=int(z['num_episodes']), gamma=float(z['gamma']), constant=int(z['constant']),
@@ -138,7 +139,7 @@ def test_philox_step_mode_matches_oracle_replay(dev):
     rs = np.random.RandomState(3)
     mat = rs.dirichlet(np.ones(d), size=5)
     np.random.seed(11)
-    ac = AC(d=d, pi0=mat, batch=B, rng='philox', seed=77, update_every='step')
+    ac = AC(d=d, pi0=mat, batch=B, rng='philox', seed=77, update_every='step', precision='f64')
     w0 = ac.w[:, 0].copy(); theta0 = float(ac.theta)
     ac.trace = []
     np.random.seed(12)
@@ -151,7 +152,8 @@ def test_philox_step_mode_matches_oracle_replay(dev):
     F = O().num_features(d)
     for t in range(15):
         th = torch.tensor([theta], dtype=torch.float64, device=dev)
-        P = ops.sample_dirichlet(torch.as_tensor(pi, device=dev), th, 0.16, 12000.0, seed=77, step=t).cpu().numpy()
+        P = ops.sample_dirichlet(torch.as_tensor(pi, device=dev), th, 0.16, 12000.0, seed=77, step=t,
+                                 precision='f64').cpu().numpy()
         pn = O().transition(P, pi).astype(np.float32)
         r = O().calc_reward(P.astype(np.float64), pi.astype(np.float64))
         delta, g, G_w, G_theta, _ = O().batched_td_pg(pi, pn, P, r, w, theta, 0.16, 0.9)

@@ -107,9 +107,11 @@ def test_reference_kats_on_device(dev):
     assert abs(float(j[0]) - 0.34858446189521375) < 1e-6
     # test2.py:105-121 gradient three-way KAT (seed 42 P captured from the reference)
     theta = t64([10.0], dev)
-    g = ops().score(t32(k['grad_pi'][None], dev), t32(k['grad_P'][None], dev), theta, 0.4)
+    g = ops().score(t32(k['grad_pi'][None], dev), t32(k['grad_P'][None], dev), theta, 0.4, precision='f64')
     g_ref32 = O().calc_gradient(k['grad_P'].astype(np.float32), k['grad_pi'].astype(np.float32), 10.0, 0.4)
     assert abs(float(g[0]) - g_ref32) < 1e-9 * abs(g_ref32)
+    gm = ops().score(t32(k['grad_pi'][None], dev), t32(k['grad_P'][None], dev), theta, 0.4, precision='mixed')
+    assert abs(float(gm[0]) - g_ref32) < 1e-5 * abs(g_ref32)
     assert abs(float(g[0]) - (-6.302201890992953)) < 1e-5 * 6.3          # vs fp64 inputs: fp32 storage of P
     pn, r = ops().step_given_P(t32(k['grad_pi'][None], dev), t32(k['grad_P'][None], dev))
     assert np.allclose(pn.cpu().numpy()[0], k['grad_pi_next'], rtol=1e-6)
@@ -136,34 +138,39 @@ def test_golden_functions_on_device(dev, path):
     # reward / gradient vs the oracle on the identical (fp32-rounded) inputs: the 1e-5 bar
     P32 = P.astype(np.float32)
     assert rel(r.cpu().numpy(), O().calc_reward(P32, pi32), 1e-30) < 1e-6
-    g = ops().score(t32(pi, dev), t32(P, dev), th, shift).cpu().numpy()
+    g = ops().score(t32(pi, dev), t32(P, dev), th, shift, precision='f64').cpu().numpy()
     assert rel(g, O().calc_gradient(P32, pi32, theta, shift), 1e-30) < 1e-9
+    gm = ops().score(t32(pi, dev), t32(P, dev), th, shift, precision='mixed').cpu().numpy()
+    assert rel(gm, O().calc_gradient(P32, pi32, theta, shift), 1e-30) < 1e-5
     # and against the reference's own fp64 outputs (input rounding included)
-    assert rel(g, z['gradient'], 1e-30) < 1e-4
+    assert rel(g, z['gradient'], 1e-30) < 1e-4 and rel(gm, z['gradient'], 1e-30) < 1e-4
 
 
+@pytest.mark.parametrize('precision,gtol', [('f64', 1e-9), ('mixed', 1e-5)])
 @pytest.mark.parametrize('d,B', [(3, 50), (4, 64), (21, 1), (21, 200), (47, 20), (64, 9), (100, 6), (128, 8), (256, 3)])
-def test_td_pg_accumulate(dev, d, B):
+def test_td_pg_accumulate(dev, d, B, precision, gtol):
     rs = np.random.RandomState(17 + d + B)
     pi, P = rand_case(rs, B, d)
     theta, shift, gamma = 8.86349, 0.16, 0.9
     w = rs.rand(O().num_features(d))
     pn, r = ops().step_given_P(t32(pi, dev), t32(P, dev))
-    delta, g, Gv = ops().td_pg_accumulate(t32(pi, dev), pn, t32(P, dev), r, t64(w, dev), t64([theta], dev), shift, gamma)
+    delta, g, Gv = ops().td_pg_accumulate(t32(pi, dev), pn, t32(P, dev), r, t64(w, dev), t64([theta], dev), shift, gamma,
+                                          precision=precision)
     pn_h = pn.cpu().numpy(); r_h = r.cpu().numpy()
     rd, rg, rGw, rGt, rsum = O().batched_td_pg(pi, pn_h, P, r_h, w, theta, shift, gamma)
     assert np.max(np.abs(delta.cpu().numpy() - rd)) < 1e-12 * max(1.0, np.max(np.abs(w)) * 4)
-    assert rel(g.cpu().numpy(), rg, 1e-30) < 1e-9
+    assert rel(g.cpu().numpy(), rg, 1e-30) < gtol
     Gh = Gv.cpu().numpy()
     F = O().num_features(d)
     scale = np.max(np.abs(rGw)) + 1e-300
     assert np.max(np.abs(Gh[:F] - rGw)) < 1e-11 * scale
-    assert abs(Gh[F] - rGt) < 1e-9 * max(1.0, abs(rGt))
+    assert abs(Gh[F] - float(np.sum(delta.cpu().numpy() * g.cpu().numpy()))) < 1e-11 * max(1.0, abs(rGt))
+    assert abs(Gh[F] - rGt) < gtol * max(1.0, abs(rGt))
     assert abs(Gh[F + 1] - rsum) < 1e-9 * max(1e-12, abs(rsum)) + 1e-15
     assert Gh[F + 2] == B
     # accumulate=True adds on top
     _, _, G2 = ops().td_pg_accumulate(t32(pi, dev), pn, t32(P, dev), r, t64(w, dev), t64([theta], dev), shift, gamma,
-                                      G=Gv.clone(), accumulate=True)
+                                      G=Gv.clone(), accumulate=True, precision=precision)
     assert np.allclose(G2.cpu().numpy(), 2 * Gh, rtol=1e-12, atol=1e-300)
 
 
@@ -173,8 +180,10 @@ def test_score_zero_probability_rule(dev):
     pi, P = rand_case(rs, 4, 21)
     P[:, 3, 5] = 0.0
     Pd = t32(P, dev)
-    g = ops().score(t32(pi, dev), Pd, t64([8.86349], dev), 0.16).cpu().numpy()
+    g = ops().score(t32(pi, dev), Pd, t64([8.86349], dev), 0.16, precision='f64').cpu().numpy()
     assert rel(g, O().calc_gradient(P, pi, 8.86349, 0.16), 1e-30) < 1e-9
+    g = ops().score(t32(pi, dev), Pd, t64([8.86349], dev), 0.16, precision='mixed').cpu().numpy()
+    assert rel(g, O().calc_gradient(P, pi, 8.86349, 0.16), 1e-30) < 1e-5
     assert np.array_equal(Pd.cpu().numpy(), P)
 
 
@@ -204,14 +213,16 @@ def test_jsd_batched(dev):
 # ---------------------------------------------------------------------------------------------------
 # Sampler: distributional checks + invariants (RNG bit-parity with MT19937 is impossible by design)
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('precision', ['mixed', 'f64'])
 @pytest.mark.parametrize('d', [4, 21, 128])
-def test_sampler_invariants_and_moments(dev, d):
+def test_sampler_invariants_and_moments(dev, d, precision):
     rs = np.random.RandomState(d)
     theta, shift, scale = 8.86349, 0.16, 12000.0
     pi1 = rs.dirichlet(np.ones(d)).astype(np.float32)
     B = 4096 if d <= 21 else 1024
     pi = np.repeat(pi1[None], B, 0)
-    P = ops().sample_dirichlet(t32(pi, dev), t64([theta], dev), shift, scale, seed=123, step=3).cpu().numpy().astype(np.float64)
+    P = ops().sample_dirichlet(t32(pi, dev), t64([theta], dev), shift, scale, seed=123, step=3,
+                               precision=precision).cpu().numpy().astype(np.float64)
     assert np.all(P > 0) and np.all(np.isfinite(P))
     assert np.max(np.abs(P.sum(-1) - 1)) < 5e-7                          # rows are stochastic (test2.py:14-32)
     al = O().calc_alpha(pi1, theta, shift) * scale
@@ -226,14 +237,16 @@ def test_sampler_invariants_and_moments(dev, d):
     tol = 6.5 * np.sqrt(2.0 / (B - 1))                                     # chi-square spread of a sample variance
     assert np.all(np.abs(ratio[big] - 1) < tol)
     # determinism + counter semantics
-    P2 = ops().sample_dirichlet(t32(pi, dev), t64([theta], dev), shift, scale, seed=123, step=3).cpu().numpy()
+    P2 = ops().sample_dirichlet(t32(pi, dev), t64([theta], dev), shift, scale, seed=123, step=3,
+                                precision=precision).cpu().numpy()
     assert np.array_equal(P2, P.astype(np.float32))
-    P3 = ops().sample_dirichlet(t32(pi, dev), t64([theta], dev), shift, scale, seed=123, step=4).cpu().numpy()
+    P3 = ops().sample_dirichlet(t32(pi, dev), t64([theta], dev), shift, scale, seed=123, step=4,
+                                precision=precision).cpu().numpy()
     assert not np.array_equal(P3, P2)
     # world-size invariance: trajectories [B/2, B) drawn as a separate shard with traj_offset
     h = B // 2
     Ps = ops().sample_dirichlet(t32(pi[h:], dev), t64([theta], dev), shift, scale, seed=123, step=3,
-                                traj_offset=h).cpu().numpy()
+                                traj_offset=h, precision=precision).cpu().numpy()
     assert np.array_equal(Ps, P2[h:])
 
 
@@ -260,13 +273,15 @@ def test_sampler_small_shape_regime(dev):
 @pytest.mark.parametrize('d,B,T', [(4, 37, 5), (21, 1, 15), (21, 100, 15), (47, 9, 4), (100, 5, 3), (128, 6, 3),
                                    (256, 2, 2)])
 @pytest.mark.parametrize('discount_pow', [False, True])
-def test_rollout_fused_vs_oracle(dev, d, B, T, discount_pow):
+@pytest.mark.parametrize('precision,gtol', [('f64', 1e-9), ('mixed', 1e-5)])
+def test_rollout_fused_vs_oracle(dev, d, B, T, discount_pow, precision, gtol):
     rs = np.random.RandomState(31 + d + B)
     theta, shift, scale, gamma = 8.86349, 0.16, 12000.0, 0.9
     pi0 = rs.dirichlet(np.ones(d), size=B).astype(np.float32)
     w = rs.rand(O().num_features(d))
     out = ops().rollout(t32(pi0, dev), T, t64([theta], dev), shift, scale, w=t64(w, dev), gamma=gamma, seed=99,
-                        first_step=5, traj_offset=1000, td=True, write_P=True, discount_pow=discount_pow)
+                        first_step=5, traj_offset=1000, td=True, write_P=True, discount_pow=discount_pow,
+                        precision=precision)
     P = out['P'].cpu().numpy()
     assert np.max(np.abs(P.astype(np.float64).sum(-1) - 1)) < 5e-7
     traj, R, D, Gs, G_w, G_theta = O().batched_rollout_given_P(
@@ -277,7 +292,7 @@ def test_rollout_fused_vs_oracle(dev, d, B, T, discount_pow):
     r_ref = np.stack([O().calc_reward(P[:, t].astype(np.float64), pt[:, t]) for t in range(T)], 1)
     assert rel(out['reward'].cpu().numpy(), r_ref, 1e-30) < 1e-6
     g_ref = np.stack([O().calc_gradient(P[:, t], pt[:, t], theta, shift) for t in range(T)], 1)
-    assert rel(out['g'].cpu().numpy(), g_ref, 1e-30) < 1e-5
+    assert rel(out['g'].cpu().numpy(), g_ref, 1e-30) < max(gtol, 2e-7)   # ln P from ln y - ln S: fp32 P rounding
     phi = O().calc_features(pt)
     V = phi.dot(w)
     disc = gamma ** np.arange(T) if discount_pow else np.full(T, gamma)
@@ -298,7 +313,8 @@ def test_rollout_fused_vs_oracle(dev, d, B, T, discount_pow):
     assert np.array_equal(pn.cpu().numpy(), out['pi_traj'][:, 1].cpu().numpy())
     assert rel(r1.cpu().numpy(), out['reward'][:, 0].cpu().numpy(), 1e-30) < 1e-6
     # sampler consistency: the standalone sampler with the same counters draws the same P
-    P0 = ops().sample_dirichlet(t32(pi0, dev), t64([theta], dev), shift, scale, seed=99, step=5, traj_offset=1000)
+    P0 = ops().sample_dirichlet(t32(pi0, dev), t64([theta], dev), shift, scale, seed=99, step=5, traj_offset=1000,
+                                precision=precision)
     assert np.array_equal(P0.cpu().numpy(), P[:, 0])
 
 
@@ -321,7 +337,7 @@ def test_apply_update_batch1_equals_reference_increment(dev):
     w0 = z['w0'][:, 0].copy(); theta0 = float(z['theta0'])
     th = t64([theta0], dev); w = t64(w0, dev)
     pn, r = ops().step_given_P(t32(pi, dev), t32(P, dev))
-    delta, g, Gv = ops().td_pg_accumulate(t32(pi, dev), pn, t32(P, dev), r, w, th, float(z['shift']), 1.0)
+    delta, g, Gv = ops().td_pg_accumulate(t32(pi, dev), pn, t32(P, dev), r, w, th, float(z['shift']), 1.0, precision='f64')
     ops().apply_update(Gv, 21, 0.1, 0.001, w, th)
     # reference: theta after the first step of the constant-lr trace
     assert abs(float(th[0]) - float(z['theta_before'][1])) < 2e-6 * abs(float(z['theta_before'][1]) - theta0) + 1e-12
