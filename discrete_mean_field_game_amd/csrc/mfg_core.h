@@ -33,10 +33,15 @@ struct CoreArgs {
   double* delta;       // [B,T] or NULL
   double* g;           // [B,T] or NULL
   float* P_out;        // [B,T,d,d] or NULL
+  double* partial;     // [gridDim.x][F+3] per-block gradient sums (D-specialised small kernels) or NULL
 };
 
 // launchers defined in mfg_core_small.hip / mfg_core_large_*.hip; return 0 or MFG_EUNSUPPORTED
-int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st);
+// *partial_blocks = number of per-block partial rows the kernel writes to a.partial (0 = none written)
+int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st,
+                      int* partial_blocks);
+bool core_small_has_inkernel_grad(int d);
+int core_small_max_blocks(int d, bool want_v, int num_cus, int64_t B);
 int launch_core_large_f64(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st);
 int launch_core_large_mixed(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st);
 
@@ -45,55 +50,49 @@ __device__ __forceinline__ double reward_term(int kind, double pii, double pj, d
   return kind == MFG_REWARD_MFG_AC2 ? (pj - pii) * p * p : p * p;
 }
 
-// One matrix element of the policy: concentration, its theta-derivative, (SAMPLE) a gamma variate or
-// (GIVEN) the stored probability, and the element's share of the row sums / score.
-//   x = pi_j - pi_i - shift.  Returns the gamma variate (SAMPLE) or p_given.
+// Per-element policy quantities: concentration alpha, its theta-derivative alpha', and the gamma
+// sampler state for shape alpha*alpha_scale.  x = pi_j - pi_i - shift.
+template <bool FAST>
+struct PolicyElem {
+  double al_d, ad_d;  // strict mode
+  float al_f, ad_f;   // mixed mode
+  GammaState gs;
+};
+
+// pj / pi: state entries the concentration is computed from (x = pj - pi - shift).
 template <bool SAMPLE, bool TD, bool FAST>
-__device__ __forceinline__ float policy_elem(const CoreArgs& a, double theta, double x, uint32_t elem, uint32_t step,
-                                             uint64_t traj, float p_given, double& A, double& D, double& Ssum,
-                                             double& gacc) {
-  float y = p_given;
+__device__ __forceinline__ void policy_setup(PolicyElem<FAST>& e, const CoreArgs& a, double theta, const ThetaSplit& ts,
+                                             float pj, float pi) {
   if (FAST) {
-    float al = 0.f, sg = 0.f;
-    if (SAMPLE || TD) softplus_sigmoid_fast(theta * x, al, sg);
-    float lnv = 0.f;
-    if (SAMPLE) {
-      y = gamma_mt(al * (float)a.alpha_scale, a.seed, elem, step, traj);
-      if (y == 0.0f) y = ZERO_GAMMA_REPLACEMENT;
-      Ssum += (double)y;
-      if (TD) lnv = __logf(y);
-    } else if (TD) {
-      lnv = (y == 0.0f) ? (float)LOG_ZERO_P : __logf(y);
-    }
-    if (TD) {
-      const float ad = (float)x * sg;
-      A += (double)al;
-      D += (double)ad;
-      gacc = fma((double)(lnv - digamma_pos_fast(al)), (double)ad, gacc);
-    }
+    float x, zh, zl, sg;
+    theta_times_x(ts, pj, pi, x, zh, zl);
+    softplus_sigmoid_fast(zh, zl, e.al_f, sg);
+    e.ad_f = x * sg;
+    if (SAMPLE) gamma_setup(e.gs, e.al_f * (float)a.alpha_scale);
   } else {
-    double al = 0.0, ad = 0.0;
-    if (SAMPLE || TD) {
-      double sg;
-      softplus_sigmoid(theta * x, al, sg);
-      ad = x * sg;
-    }
-    double lnv = 0.0;
-    if (SAMPLE) {
-      y = gamma_mt((float)(al * a.alpha_scale), a.seed, elem, step, traj);
-      if (y == 0.0f) y = ZERO_GAMMA_REPLACEMENT;
-      Ssum += (double)y;
-      if (TD) lnv = log((double)y);
-    } else if (TD) {
-      lnv = (y == 0.0f) ? LOG_ZERO_P : log((double)y);
-    }
-    if (TD) {
-      A += al;
-      D += ad;
-      gacc = fma(-digamma_pos(al) + lnv, ad, gacc);
-    }
+    const double x = (double)pj - (double)pi - a.shift;
+    double sg;
+    softplus_sigmoid(theta * x, e.al_d, sg);
+    e.ad_d = x * sg;
+    if (SAMPLE) gamma_setup(e.gs, (float)(e.al_d * a.alpha_scale));
   }
-  return y;
+}
+
+// Fold one finished element into the row sums / score.  v = gamma variate (SAMPLE) or stored probability.
+template <bool SAMPLE, bool TD, bool FAST>
+__device__ __forceinline__ void policy_accumulate(const PolicyElem<FAST>& e, float v, double& A, double& D, double& gacc) {
+  if (!TD) return;
+  if (FAST) {
+    const float lnv = (!SAMPLE && v == 0.0f) ? (float)LOG_ZERO_P : fast_ln(v);
+    A += (double)e.al_f;
+    D += (double)e.ad_f;
+    gacc = fma((double)(lnv - digamma_pos_fast(e.al_f)), (double)e.ad_f, gacc);
+  } else {
+    const double lnv = (!SAMPLE && v == 0.0f) ? LOG_ZERO_P : log((double)v);
+    A += e.al_d;
+    D += e.ad_d;
+    gacc = fma(-digamma_pos(e.al_d) + lnv, e.ad_d, gacc);
+  }
 }
 
 // V(pi) = phi(pi).w, one wavefront per trajectory, lanes own columns c, rows i <= c.  For fixed i the
@@ -115,10 +114,15 @@ __device__ __forceinline__ double value_wave(const float* pis, const double* __r
 // small d (d <= 64): G = 64/d trajectories per wavefront, lane = (trajectory t, row i).
 // LDS per block: wl[F] (critic weights, fp64), tile[TB][d][dp] (gamma variates, then P), pis / pin / pal [TB][d].
 // ---------------------------------------------------------------------------------------------
-template <bool SAMPLE, bool TD, bool FAST>
-__global__ __launch_bounds__(BLOCK) void k_core_small(CoreArgs a) {
+// D > 0: d is a compile-time constant (row loops unroll, the critic-gradient sums are accumulated in
+// registers inside the kernel); D == 0: generic runtime d.
+// The kernel is latency bound (serial Philox / transcendental chains per lane): 4 waves per SIMD are needed
+// to keep the VALU busy, so the mixed-precision build is capped at 128 VGPRs (no spills at that cap).
+template <bool SAMPLE, bool TD, bool FAST, int D>
+__global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int d = a.d, dd = d * d, dp = d | 1, T = a.T;
+  const int d = D ? D : a.d;
+  const int dd = d * d, dp = d | 1, T = a.T;
   const int G = WAVE / d, TB = WAVES * G;
   const int Q = d * (d + 1) / 2, F = Q + d + 1;
   const bool want_v = TD && a.w != nullptr;
@@ -131,10 +135,22 @@ __global__ __launch_bounds__(BLOCK) void k_core_small(CoreArgs a) {
   const int t = lane / d, i = lane - t * d;
   const int p2 = next_pow2(d);
   const double theta = *a.theta;
+  const ThetaSplit ts = theta_split(theta, a.shift);
   const float inv_d = 1.0f / (float)d;
   if (want_v) {
     for (int k = tid; k < F; k += BLOCK) wl[k] = a.w[k];
   }
+  // in-kernel batch sums: one fp64 accumulator row [F+3] per wavefront in LDS (upper triangle of
+  // sum delta pi pi^T, linear, bias, sum delta g, sum r, count); the wave's G lane groups add in turn.
+  const bool grad = want_v && a.partial != nullptr;
+  const int FO = F + 3;
+  const int nfl = TB * d * dp + 3 * TB * d;
+  double* gacc0 = reinterpret_cast<double*>(tile + nfl + (nfl & 1));
+  double* gacc_w = gacc0 + wv * FO;
+  if (grad) {
+    for (int k = lane; k < FO; k += WAVE) gacc_w[k] = 0.0;
+  }
+  const int kbase = feat_idx(i, i, d);  // k(i,j) = kbase + (j - i)
   const int64_t ntiles = (a.B + TB - 1) / TB;
   for (int64_t tileid = blockIdx.x; tileid < ntiles; tileid += gridDim.x) {
     const int64_t b0 = tileid * TB;
@@ -168,18 +184,43 @@ __global__ __launch_bounds__(BLOCK) void k_core_small(CoreArgs a) {
       float* trow = tile + (tlc * d + i) * dp;
       const float* pv = pis + tlc * d;
       const float* pav = (!SAMPLE && a.pi_alpha) ? pal + tlc * d : pv;
-      const double pai = (double)pav[i];
+      const float pai = pav[i];
       const double pid = (double)pi_i;
-      double A = 0.0, D = 0.0, Ssum = 0.0, gacc = 0.0, racc = 0.0;
+      double A = 0.0, D_ = 0.0, Ssum = 0.0, gacc = 0.0, racc = 0.0;
       if (valid) {
         const uint32_t step = a.first_step + (uint32_t)s;
         const uint64_t traj = a.traj_offset + (uint64_t)b;
-        for (int j = 0; j < d; ++j) {
-          const double x = (double)pav[j] - pai - a.shift;
-          const float pg = SAMPLE ? 0.0f : trow[j];
-          const float y = policy_elem<SAMPLE, TD, FAST>(a, theta, x, (uint32_t)(i * d + j), step, traj, pg, A, D, Ssum, gacc);
-          if (SAMPLE) trow[j] = y;
-          else racc += reward_term(a.reward_kind, pid, (double)pv[j], (double)y);
+        PolicyElem<FAST> pe;
+        if (SAMPLE) {
+          // two matrix elements per iteration (one Philox block, two interleaved dependency chains).
+          // Not unrolled further: the body is ~400 instructions and unrolling blows the register budget.
+          PolicyElem<FAST> pe1;
+#pragma unroll 1
+          for (int j = 0; j < d; j += 2) {
+            const bool has1 = j + 1 < d;
+            policy_setup<SAMPLE, TD, FAST>(pe, a, theta, ts, pav[j], pai);
+            policy_setup<SAMPLE, TD, FAST>(pe1, a, theta, ts, pav[has1 ? j + 1 : j], pai);
+            float y0, y1;
+            gamma_pair(pe.gs, pe1.gs, has1, a.seed, (uint32_t)(i * d + j), step, traj, y0, y1);
+            if (y0 == 0.0f) y0 = ZERO_GAMMA_REPLACEMENT;
+            if (y1 == 0.0f) y1 = ZERO_GAMMA_REPLACEMENT;
+            Ssum += (double)y0;
+            trow[j] = y0;
+            policy_accumulate<SAMPLE, TD, FAST>(pe, y0, A, D_, gacc);
+            if (has1) {
+              Ssum += (double)y1;
+              trow[j + 1] = y1;
+              policy_accumulate<SAMPLE, TD, FAST>(pe1, y1, A, D_, gacc);
+            }
+          }
+        } else {
+#pragma unroll 2
+          for (int j = 0; j < d; ++j) {
+            policy_setup<SAMPLE, TD, FAST>(pe, a, theta, ts, pav[j], pai);
+            const float p = trow[j];
+            policy_accumulate<SAMPLE, TD, FAST>(pe, p, A, D_, gacc);
+            racc += reward_term(a.reward_kind, pid, (double)pv[j], (double)p);
+          }
         }
         if (SAMPLE) {
           // normalise the row: P_ij = fl32(y_ij / S_i); the reward uses the stored fp32 P
@@ -189,9 +230,9 @@ __global__ __launch_bounds__(BLOCK) void k_core_small(CoreArgs a) {
             trow[j] = p32;
             racc += reward_term(a.reward_kind, pid, (double)pv[j], (double)p32);
           }
-          if (TD) gacc -= log(Ssum) * D;
+          if (TD) gacc -= log(Ssum) * D_;
         }
-        if (TD) gacc = fma(digamma_pos(A), D, gacc);
+        if (TD) gacc = fma(digamma_pos(A), D_, gacc);
       }
       __syncthreads();
       float pi_n;
@@ -243,6 +284,22 @@ __global__ __launch_bounds__(BLOCK) void k_core_small(CoreArgs a) {
           const double gd = a.discount_pow ? discount : a.gamma;
           const double del = r + gd * v_next - v_cur;
           if (valid && i == 0 && a.delta) a.delta[b * T + s] = del;
+          if (grad) {
+            const double ad_ = del * pid;
+            for (int grp = 0; grp < G; ++grp) {
+              if (valid && t == grp) {
+                for (int j = i; j < d; ++j) gacc_w[kbase + (j - i)] = fma(ad_, (double)pv[j], gacc_w[kbase + (j - i)]);
+                gacc_w[Q + i] += ad_;
+                if (i == 0) {
+                  gacc_w[Q + d] += del;
+                  gacc_w[Q + d + 1] = fma(del, gsum, gacc_w[Q + d + 1]);
+                  gacc_w[Q + d + 2] += r;
+                  gacc_w[Q + d + 3] += 1.0;
+                }
+              }
+              __builtin_amdgcn_wave_barrier();
+            }
+          }
           v_cur = v_next;
           discount *= a.gamma;
         }
@@ -252,13 +309,24 @@ __global__ __launch_bounds__(BLOCK) void k_core_small(CoreArgs a) {
     }
     if (valid && a.pi_next_out) a.pi_next_out[b * d + i] = pi_i;
   }
+  if (grad) {
+    // fixed-order sum of the block's 4 wavefront rows -> one partial row per block
+    __syncthreads();
+    const double* g0 = gacc0;
+    double* out = a.partial + (int64_t)blockIdx.x * FO;
+    for (int k = tid; k < FO; k += BLOCK) out[k] = ((g0[k] + g0[FO + k]) + g0[2 * FO + k]) + g0[3 * FO + k];
+  }
 }
 
-inline size_t core_small_lds(int d, bool want_v) {
+inline size_t core_small_lds(int d, bool want_v, bool grad) {
   const int G = WAVE / d, TB = WAVES * G, dp = d | 1;
   const size_t F = (size_t)d * (d + 1) / 2 + d + 1;
-  return (want_v ? F * 8 : 0) + (size_t)TB * d * dp * 4 + 3 * (size_t)TB * d * 4;
+  size_t fl = (size_t)TB * d * dp + 3 * (size_t)TB * d;  // floats: tile, pis, pin, pal
+  fl += fl & 1;                                          // keep the fp64 accumulator rows 8-byte aligned
+  return (want_v ? F * 8 : 0) + fl * 4 + (grad ? (size_t)WAVES * (F + 3) * 8 : 0);
 }
+// in-kernel gradient sums are used while the block still fits 2x per CU
+inline bool core_small_grad_fits(int d) { return core_small_lds(d, true, true) <= 72 * 1024; }
 
 // ---------------------------------------------------------------------------------------------
 // large d (d > 64): one wavefront per trajectory, lane owns columns c = lane + 64 m (m < R).
@@ -274,6 +342,7 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
   float* pal = pin + d;            // state for alpha (GIVEN with pi_alpha)
   const bool want_v = TD && a.w != nullptr;
   const double theta = *a.theta;
+  const ThetaSplit ts = theta_split(theta, a.shift);
   const int64_t nw = (int64_t)gridDim.x * WAVES;
   for (int64_t b = (int64_t)blockIdx.x * WAVES + wv; b < a.B; b += nw) {
     float pc[R];
@@ -300,12 +369,13 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
       const float* pav = (!SAMPLE && a.pi_alpha) ? pal : pis;
-      double pcd[R], pad[R], acc[R];
+      double pcd[R], acc[R];
+      float pad[R];
 #pragma unroll
       for (int m = 0; m < R; ++m) {
         const int c = lane + m * WAVE;
         pcd[m] = (double)pc[m];
-        pad[m] = c < d ? (double)pav[c] : 0.0;
+        pad[m] = c < d ? pav[c] : 0.0f;
         acc[m] = 0.0;
       }
       double racc = 0.0, gacc = 0.0, guni = 0.0;
@@ -314,17 +384,49 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
       const uint32_t step = a.first_step + (uint32_t)s;
       for (int i = 0; i < d; ++i) {
         const double pii = (double)pis[i];
-        const double pai = (double)pav[i];
+        const float pai = pav[i];
         float y[R];
         double Ssum = 0.0, A = 0.0, D = 0.0;
+        PolicyElem<FAST> pe;
+        if (SAMPLE) {
+          // this lane's columns c = lane + 64 m, two per iteration (pair counter = element of the first one;
+          // the partner is 64 columns away, so it retries on ITS element id, passed explicitly)
 #pragma unroll
-        for (int m = 0; m < R; ++m) {
-          const int c = lane + m * WAVE;
-          y[m] = 0.0f;
-          if (c < d) {
-            const double x = pad[m] - pai - a.shift;
-            const float pg = SAMPLE ? 0.0f : Pb[(int64_t)i * d + c];
-            y[m] = policy_elem<SAMPLE, TD, FAST>(a, theta, x, (uint32_t)(i * d + c), step, traj, pg, A, D, Ssum, gacc);
+          for (int m = 0; m < R; m += 2) {
+            const int c0 = lane + m * WAVE;
+            const bool has0 = c0 < d;
+            const bool has1 = (m + 1 < R) && (c0 + WAVE < d);
+            PolicyElem<FAST> pe1;
+            y[m] = 0.0f;
+            if (m + 1 < R) y[m + 1] = 0.0f;
+            if (has0) {
+              policy_setup<SAMPLE, TD, FAST>(pe, a, theta, ts, pad[m], pai);
+              policy_setup<SAMPLE, TD, FAST>(pe1, a, theta, ts, pad[(m + 1 < R) ? m + 1 : m], pai);
+              float y0, y1;
+              gamma_pair_strided(pe.gs, pe1.gs, has1, a.seed, (uint32_t)(i * d + c0), (uint32_t)(i * d + c0 + WAVE), step,
+                                 traj, y0, y1);
+              if (y0 == 0.0f) y0 = ZERO_GAMMA_REPLACEMENT;
+              if (y1 == 0.0f) y1 = ZERO_GAMMA_REPLACEMENT;
+              y[m] = y0;
+              Ssum += (double)y0;
+              policy_accumulate<SAMPLE, TD, FAST>(pe, y0, A, D, gacc);
+              if (has1) {
+                if (m + 1 < R) y[m + 1] = y1;
+                Ssum += (double)y1;
+                policy_accumulate<SAMPLE, TD, FAST>(pe1, y1, A, D, gacc);
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int m = 0; m < R; ++m) {
+            const int c = lane + m * WAVE;
+            y[m] = 0.0f;
+            if (c < d) {
+              policy_setup<SAMPLE, TD, FAST>(pe, a, theta, ts, pad[m], pai);
+              y[m] = Pb[(int64_t)i * d + c];
+              policy_accumulate<SAMPLE, TD, FAST>(pe, y[m], A, D, gacc);
+            }
           }
         }
         double invS = 1.0;

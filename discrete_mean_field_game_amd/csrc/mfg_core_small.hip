@@ -1,31 +1,56 @@
-// Instantiations of the packed small-d core kernel (d <= 64), both precisions.
+// Instantiations of the packed small-d core kernel (d <= 64): generic runtime d plus compile-time
+// specialisations for the reference's two problem sizes (d = 21: mfg_ac2.py:25, d = 15: ac_irl.py:33).
 #include "mfg_core.h"
 
 namespace mfg {
 
-template <bool SAMPLE, bool TD, bool FAST>
+template <bool SAMPLE, bool TD, bool FAST, int D>
 static void go(const CoreArgs& a, int grid, size_t lds, hipStream_t st) {
-  hipLaunchKernelGGL((k_core_small<SAMPLE, TD, FAST>), dim3(grid), dim3(BLOCK), lds, st, a);
+  hipLaunchKernelGGL((k_core_small<SAMPLE, TD, FAST, D>), dim3(grid), dim3(BLOCK), lds, st, a);
 }
 
-int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st) {
-  const int d = a.d;
-  const bool want_v = td && a.w != nullptr;
-  const size_t lds = core_small_lds(d, want_v);
+template <int D>
+static void dispatch(const CoreArgs& a, bool sample, bool td, bool fast, int grid, size_t lds, hipStream_t st) {
+  if (fast) {
+    if (sample && td) go<true, true, true, D>(a, grid, lds, st);
+    else if (sample) go<true, false, true, D>(a, grid, lds, st);
+    else go<false, true, true, D>(a, grid, lds, st);
+  } else {
+    if (sample && td) go<true, true, false, D>(a, grid, lds, st);
+    else if (sample) go<true, false, false, D>(a, grid, lds, st);
+    else go<false, true, false, D>(a, grid, lds, st);
+  }
+}
+
+bool core_small_has_inkernel_grad(int d) { return core_small_grad_fits(d); }
+
+static int blocks_for(size_t lds, int d, int num_cus, int64_t B) {
   const int G = WAVE / d, TB = WAVES * G;
   int bpc = (int)((160 * 1024) / (lds + 256));
   if (bpc > 8) bpc = 8;
   if (bpc < 1) bpc = 1;
-  const int grid = core_grid(a.B, TB, bpc, num_cus);
-  if (fast) {
-    if (sample && td) go<true, true, true>(a, grid, lds, st);
-    else if (sample) go<true, false, true>(a, grid, lds, st);
-    else go<false, true, true>(a, grid, lds, st);
-  } else {
-    if (sample && td) go<true, true, false>(a, grid, lds, st);
-    else if (sample) go<true, false, false>(a, grid, lds, st);
-    else go<false, true, false>(a, grid, lds, st);
-  }
+  return core_grid(B, TB, bpc, num_cus);
+}
+
+int core_small_max_blocks(int d, bool want_v, int num_cus, int64_t B) {
+  // upper bound over the with / without in-kernel-gradient LDS footprints
+  const int a = blocks_for(core_small_lds(d, want_v, false), d, num_cus, B);
+  const int b = blocks_for(core_small_lds(d, want_v, want_v && core_small_grad_fits(d)), d, num_cus, B);
+  return a > b ? a : b;
+}
+
+int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st,
+                      int* partial_blocks) {
+  const int d = a.d;
+  const bool want_v = td && a.w != nullptr;
+  const bool grad = want_v && a.partial != nullptr;
+  if (grad && !core_small_grad_fits(d)) return MFG_EINVAL;  // caller must not request it (API checks)
+  const size_t lds = core_small_lds(d, want_v, grad);
+  const int grid = blocks_for(lds, d, num_cus, a.B);
+  if (partial_blocks) *partial_blocks = grad ? grid : 0;
+  if (d == 21) dispatch<21>(a, sample, td, fast, grid, lds, st);
+  else if (d == 15) dispatch<15>(a, sample, td, fast, grid, lds, st);
+  else dispatch<0>(a, sample, td, fast, grid, lds, st);
   return MFG_OK;
 }
 

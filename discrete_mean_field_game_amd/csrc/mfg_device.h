@@ -47,54 +47,96 @@ __device__ __forceinline__ u32x4 philox_elem(uint64_t seed, uint32_t elem, uint3
   return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
-// (0,1) open interval from the top 24 bits.
-__device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * 5.9604644775390625e-8f; }
+// (0,1] from the top 24 bits (the +0.5 keeps log(u) finite).
+__device__ __forceinline__ float u01(uint32_t r) { return fmaf((float)(r >> 8), 5.9604644775390625e-8f, 2.98023223876953125e-8f); }
+
+// Raw hardware transcendentals (v_log_f32 / v_exp_f32: base 2, ~1 ulp, no denormal fix-ups: every
+// argument below is a normal number).
+__device__ __forceinline__ float fast_ln(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 
 // ---------------------------------------------------------------------------
-// Gamma(shape a, scale 1), Marsaglia & Tsang (2000) with the U^(1/a) boost for a < 1.
-// fp32; one Philox block per attempt.  Returns > 0 or exactly 0 on
-// underflow (the caller applies the reference's zero replacement).
+// Gamma(shape a, scale 1), Marsaglia & Tsang (2000) with the U^(1/a) boost for a < 1.  fp32.
+// Matrix elements are sampled in PAIRS (j, j+1) of one row: one Philox block gives the two Box-Muller
+// normals (cos / sin of the same radius) and the two acceptance uniforms, which halves the RNG cost
+// and gives the compiler two independent dependency chains to interleave (the kernels are latency
+// bound).  Counters: pair block = (elem of the first element, block 0); a rejected element retries on
+// its own counter (its elem, block 1, 2, ...); boost uniforms (shape < 1 only) come from block 0xFFFF of
+// the pair counter.  Acceptance is > 99 % at the shapes of the reference policy, so retries are rare.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float gamma_mt(float a, uint64_t seed, uint32_t elem, uint32_t step, uint64_t traj) {
-  const bool small = a < 1.0f;
-  const float a1 = small ? a + 1.0f : a;
-  const float dd = a1 - (1.0f / 3.0f);
-  const float c = rsqrtf(9.0f * dd);
-  float v = 1.0f;
-  float boost_u = 1.0f;
-  // One Philox block per attempt: normal = Box-Muller(r.x, r.y), accept uniform = r.z; r.w of block 0
-  // is the boost uniform.  Acceptance is > 95 % so the loop almost never iterates.
-  for (uint32_t block = 0; block < 64; ++block) {
-    const u32x4 r = philox_elem(seed, elem, step, traj, block);
-    if (block == 0) boost_u = u01(r.w);
-    const float x = sqrtf(-2.0f * __logf(u01(r.x))) * __builtin_amdgcn_cosf(u01(r.y));
-    const float u = u01(r.z);
-    const float t = c * x;
-    if (t <= -1.0f) continue;
-    // eps = v - 1 with v = (1+t)^3, formed without cancellation
-    const float eps = t * (3.0f + t * (3.0f + t));
-    const float x2 = x * x;
-    bool acc = u < 1.0f - 0.0331f * x2 * x2;
-    if (!acc) {
-      // log(v) - eps: series for small eps (large shapes), direct otherwise
-      float lme;
-      if (fabsf(eps) < 0.125f) {
-        const float e2 = eps * eps;
-        lme = e2 * (-0.5f + eps * (1.0f / 3.0f + eps * (-0.25f + eps * (0.2f + eps * (-1.0f / 6.0f +
-              eps * (1.0f / 7.0f + eps * (-0.125f)))))));
-      } else {
-        lme = __logf(1.0f + eps) - eps;
-      }
-      acc = __logf(u) < 0.5f * x2 + dd * lme;
+struct GammaState {
+  float a, dd, c;
+  bool small;
+};
+
+__device__ __forceinline__ void gamma_setup(GammaState& g, float a) {
+  g.a = a;
+  g.small = a < 1.0f;
+  const float a1 = g.small ? a + 1.0f : a;
+  g.dd = a1 - (1.0f / 3.0f);
+  g.c = __builtin_amdgcn_rsqf(9.0f * g.dd);
+}
+
+// Marsaglia-Tsang acceptance for normal x and uniform u; v = (1 + c x)^3.
+__device__ __forceinline__ bool mt_accept(const GammaState& g, float x, float u, float& v) {
+  const float t = g.c * x;
+  const float eps = t * (3.0f + t * (3.0f + t));  // v - 1, formed without cancellation
+  const float x2 = x * x;
+  v = 1.0f + eps;
+  bool acc = u < 1.0f - 0.0331f * x2 * x2;
+  if (!acc) {
+    // log(v) - eps: series for small eps (large shapes), direct otherwise
+    float lme;
+    if (fabsf(eps) < 0.125f) {
+      const float e2 = eps * eps;
+      lme = e2 * (-0.5f + eps * (1.0f / 3.0f + eps * (-0.25f + eps * (0.2f + eps * (-1.0f / 6.0f +
+            eps * (1.0f / 7.0f + eps * (-0.125f)))))));
+    } else {
+      lme = fast_ln(v) - eps;
     }
-    if (acc) {
-      v = 1.0f + eps;
-      break;
-    }
+    acc = fast_ln(u) < 0.5f * x2 + g.dd * lme;
   }
-  float y = dd * v;
-  if (small) y *= __powf(boost_u, 1.0f / a);
-  return y;
+  return acc && (t > -1.0f);
+}
+
+__device__ __forceinline__ float box_muller_radius(uint32_t r) {
+  return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(r)));  // sqrt(-2 ln u)
+}
+
+// Rare path: element `elem` was rejected on the pair block; retry on its own counter.
+__device__ __forceinline__ float gamma_retry(const GammaState& g, uint64_t seed, uint32_t elem, uint32_t step, uint64_t traj) {
+  float v = 1.0f;
+  for (uint32_t block = 1; block < 64; ++block) {
+    const u32x4 r = philox_elem(seed, elem, step, traj, block);
+    const float x = box_muller_radius(r.x) * __builtin_amdgcn_cosf(u01(r.y));
+    if (mt_accept(g, x, u01(r.z), v)) return v;
+  }
+  return 1.0f;  // never reached in practice
+}
+
+// Gamma variates for elements elem0 and elem1 (the second one only if has1); the pair block is keyed by elem0.
+__device__ __forceinline__ void gamma_pair_strided(const GammaState& g0, const GammaState& g1, bool has1, uint64_t seed,
+                                                   uint32_t elem0, uint32_t elem1, uint32_t step, uint64_t traj, float& y0,
+                                                   float& y1) {
+  const u32x4 r = philox_elem(seed, elem0, step, traj, 0);
+  const float rad = box_muller_radius(r.x);
+  const float ang = u01(r.y);
+  float v0, v1;
+  const bool ok0 = mt_accept(g0, rad * __builtin_amdgcn_cosf(ang), u01(r.z), v0);
+  const bool ok1 = mt_accept(g1, rad * __builtin_amdgcn_sinf(ang), u01(r.w), v1);
+  if (!ok0) v0 = gamma_retry(g0, seed, elem0, step, traj);
+  if (has1 && !ok1) v1 = gamma_retry(g1, seed, elem1, step, traj);
+  y0 = g0.dd * v0;
+  y1 = g1.dd * v1;
+  if (g0.small || (has1 && g1.small)) {
+    const u32x4 rb = philox_elem(seed, elem0, step, traj, 0xFFFFu);
+    if (g0.small) y0 *= __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01(rb.x)) * __builtin_amdgcn_rcpf(g0.a));
+    if (g1.small) y1 *= __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01(rb.y)) * __builtin_amdgcn_rcpf(g1.a));
+  }
+}
+__device__ __forceinline__ void gamma_pair(const GammaState& g0, const GammaState& g1, bool has1, uint64_t seed,
+                                           uint32_t elem0, uint32_t step, uint64_t traj, float& y0, float& y1) {
+  gamma_pair_strided(g0, g1, has1, seed, elem0, elem0 + 1u, step, traj, y0, y1);
 }
 
 // ---------------------------------------------------------------------------
@@ -135,17 +177,37 @@ __device__ __forceinline__ void softplus_sigmoid(double z, double& sp, double& s
 // Mixed precision ("MFG_PRECISION_MIXED"): fp32 hardware transcendentals (v_exp_f32 / v_log_f32 /
 // v_rcp_f32, ~1 ulp), fp64 only for the sums.  Measured effect on the score g: ~1e-6 relative.
 // ---------------------------------------------------------------------------
-// alpha = log1p(e^z), sigmoid(z) with z = theta*x given in fp64: the low part of z is folded in so
-// that e carries fp32 (not |z| * 2^-24) relative error; log1p by Kahan's log(u) * e/(u-1).
-__device__ __forceinline__ void softplus_sigmoid_fast(double z, float& sp, float& sg) {
-  const float zh = (float)z;
-  const float zl = (float)(z - (double)zh);
-  float e = __expf(zh);
+// alpha = log1p(e^z), sigmoid(z) for z = zh + zl (zl = low-order part of theta*x, so that e carries fp32
+// relative error instead of |z| * 2^-24).  log1p: 2 atanh(e/(2+e)) series below e = 1/4 (no reliance on
+// the hardware log near 1), log(1+e) above.
+__device__ __forceinline__ void softplus_sigmoid_fast(float zh, float zl, float& sp, float& sg) {
+  float e = fast_exp(zh);
   e = fmaf(e, zl, e);
   const float u = 1.0f + e;
   sg = e * __builtin_amdgcn_rcpf(u);
-  const float um1 = u - 1.0f;
-  sp = (um1 == 0.0f) ? e : __logf(u) * (e * __builtin_amdgcn_rcpf(um1));
+  const float s = e * __builtin_amdgcn_rcpf(2.0f + e);
+  const float s2 = s * s;
+  const float ser = 2.0f * s * fmaf(s2, fmaf(s2, fmaf(s2, fmaf(s2, 1.0f / 9.0f, 1.0f / 7.0f), 0.2f), 1.0f / 3.0f), 1.0f);
+  sp = (e < 0.25f) ? ser : fast_ln(u);
+}
+
+// Split-constant helper: z = theta * (pj - pi - shift) evaluated in fp32 with the rounding of the
+// product and of the constants carried in zl.
+struct ThetaSplit {
+  float th, tl, sh, c0;  // theta = th + tl, shift = sh + sl, c0 = th * sl
+};
+__device__ __forceinline__ ThetaSplit theta_split(double theta, double shift) {
+  ThetaSplit t;
+  t.th = (float)theta;
+  t.tl = (float)(theta - (double)t.th);
+  t.sh = (float)shift;
+  t.c0 = t.th * (float)(shift - (double)t.sh);
+  return t;
+}
+__device__ __forceinline__ void theta_times_x(const ThetaSplit& t, float pj, float pi, float& x, float& zh, float& zl) {
+  x = (pj - pi) - t.sh;
+  zh = t.th * x;
+  zl = fmaf(t.th, x, -zh) + fmaf(t.tl, x, -t.c0);
 }
 
 __device__ __forceinline__ float digamma_pos_fast(float x) {
@@ -164,7 +226,7 @@ __device__ __forceinline__ float digamma_pos_fast(float x) {
   const float inv = __builtin_amdgcn_rcpf(x);
   const float inv2 = inv * inv;
   const float s = inv2 * (1.0f / 12.0f - inv2 * (1.0f / 120.0f - inv2 * (1.0f / 252.0f)));
-  return __logf(x) - 0.5f * inv - s - corr;
+  return fast_ln(x) - 0.5f * inv - s - corr;
 }
 
 // ---------------------------------------------------------------------------

@@ -430,12 +430,34 @@ __global__ __launch_bounds__(BLOCK) void k_grad_partial(GradArgs a) {
   }
 }
 
-__global__ void k_reduce_partials(const double* __restrict__ partial, int64_t nsb, int64_t FO, int accumulate,
-                                  double* __restrict__ G) {
-  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < FO; k += (int64_t)gridDim.x * blockDim.x) {
-    double s = 0.0;
-    for (int64_t p = 0; p < nsb; ++p) s += partial[p * FO + k];
-    G[k] = accumulate ? G[k] + s : s;
+// Sum nsb partial rows in a fixed order: block = 16 slices (waves) x 64 outputs (lanes, coalesced);
+// slice s adds rows s, s+16, ... ; the 16 slice sums are combined in slice order through LDS.
+constexpr int RP_SLICES = 16;
+__global__ __launch_bounds__(RP_SLICES* WAVE) void k_reduce_partials(const double* __restrict__ partial, int64_t nsb, int64_t FO,
+                                                                    int accumulate, double* __restrict__ G) {
+  __shared__ double red[RP_SLICES][WAVE];
+  const int lane = threadIdx.x & (WAVE - 1), sl = threadIdx.x / WAVE;
+  const int64_t k = (int64_t)blockIdx.x * WAVE + lane;
+  double s = 0.0;
+  if (k < FO) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t p = sl;
+    for (; p + 3 * RP_SLICES < nsb; p += 4 * RP_SLICES) {
+      s0 += partial[p * FO + k];
+      s1 += partial[(p + RP_SLICES) * FO + k];
+      s2 += partial[(p + 2 * RP_SLICES) * FO + k];
+      s3 += partial[(p + 3 * RP_SLICES) * FO + k];
+    }
+    for (; p < nsb; p += RP_SLICES) s0 += partial[p * FO + k];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  red[sl][lane] = s;
+  __syncthreads();
+  if (sl == 0 && k < FO) {
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < RP_SLICES; ++q) tot += red[q][lane];
+    G[k] = accumulate ? G[k] + tot : tot;
   }
 }
 
@@ -477,14 +499,15 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
   GradArgs a{pi, stride_b, delta, g, reward, N, T, d, chunk, nsb, (double*)ws};
   const size_t lds = (size_t)chunk * 3 * 8 + (size_t)chunk * d * 4;
   hipLaunchKernelGGL(k_grad_partial, dim3((unsigned)nsb, (unsigned)nob), dim3(BLOCK), lds, st, a);
-  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + 255) / 256)), dim3(256), 0, st, (const double*)ws, nsb, FO,
-                     accumulate, G);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
+                     (const double*)ws, nsb, FO, accumulate, G);
   return check_launch("grad_reduce");
 }
 
-static int launch_core(const CoreArgs& a, bool sample, bool td, int precision, hipStream_t st) {
+static int launch_core(const CoreArgs& a, bool sample, bool td, int precision, hipStream_t st, int* partial_blocks = nullptr) {
   int rc;
-  if (a.d <= WAVE) rc = launch_core_small(a, sample, td, precision == MFG_PRECISION_MIXED, num_cus(), st);
+  if (partial_blocks) *partial_blocks = 0;
+  if (a.d <= WAVE) rc = launch_core_small(a, sample, td, precision == MFG_PRECISION_MIXED, num_cus(), st, partial_blocks);
   else if (precision == MFG_PRECISION_MIXED) rc = launch_core_large_mixed(a, sample, td, num_cus(), st);
   else rc = launch_core_large_f64(a, sample, td, num_cus(), st);
   if (rc != MFG_OK) return fail(rc, "%s: d=%lld > %lld", "core", (long long)a.d, (long long)MFG_MAX_D);
@@ -528,7 +551,26 @@ size_t mfg_workspace_bytes(int64_t N, int d) {
   int chunk, nob;
   int64_t nsb;
   grad_geometry(N, d, &chunk, &nsb, &nob);
-  return (size_t)(nsb * (mfg_num_features(d) + 3) * 8);
+  int64_t rows = nsb;
+  if (d <= WAVE && core_small_has_inkernel_grad(d)) {
+    const int64_t blocks = core_small_max_blocks(d, true, num_cus(), N);
+    if (blocks > rows) rows = blocks;
+  }
+  return (size_t)(rows * (mfg_num_features(d) + 3) * 8);
+}
+
+// Per-block partial rows written by a D-specialised core kernel -> G
+static int reduce_core_partials(const void* ws, int blocks, int d, double* G, int accumulate, hipStream_t st) {
+  const int64_t FO = mfg_num_features(d) + 3;
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
+                     (const double*)ws, (int64_t)blocks, FO, accumulate, G);
+  return check_launch("reduce_core_partials");
+}
+
+static bool inkernel_grad_ok(int d, int64_t B, void* ws, size_t ws_bytes) {
+  if (d > WAVE || !core_small_has_inkernel_grad(d) || !ws) return false;
+  const int64_t blocks = core_small_max_blocks(d, true, num_cus(), B);
+  return ws_bytes >= (size_t)(blocks * (mfg_num_features(d) + 3) * 8);
 }
 
 #define CHECK_BD()                                        \
@@ -724,9 +766,12 @@ int mfg_td_pg_accumulate(const float* pi, const float* pi_next, const float* P, 
   a.reward_kind = MFG_REWARD_EXTERNAL;
   a.delta = delta;
   a.g = g;
-  int rc = launch_core(a, false, true, precision, S(stream));
+  if (G && inkernel_grad_ok(d, B, workspace, workspace_bytes)) a.partial = (double*)workspace;
+  int pblocks = 0;
+  int rc = launch_core(a, false, true, precision, S(stream), &pblocks);
   if (rc != MFG_OK || !G) return rc;
   REQUIRE(workspace, "workspace is null");
+  if (pblocks > 0) return reduce_core_partials(workspace, pblocks, d, G, accumulate, S(stream));
   return launch_grad(pi, d, delta, g, reward, B, 1, d, G, accumulate, workspace, workspace_bytes, S(stream));
 }
 
@@ -771,9 +816,12 @@ int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, 
   a.g = g;
   a.P_out = (flags & MFG_ROLLOUT_WRITE_P) ? P_out : nullptr;
   const int precision = (flags & MFG_ROLLOUT_F64) ? MFG_PRECISION_F64 : MFG_PRECISION_MIXED;
-  int rc = launch_core(a, true, td, precision, S(stream));
+  if (td && G && inkernel_grad_ok(d, B, workspace, workspace_bytes)) a.partial = (double*)workspace;
+  int pblocks = 0;
+  int rc = launch_core(a, true, td, precision, S(stream), &pblocks);
   if (rc != MFG_OK || !td || !G) return rc;
   REQUIRE(workspace, "workspace is null");
+  if (pblocks > 0) return reduce_core_partials(workspace, pblocks, d, G, accumulate, S(stream));
   return launch_grad(pi_traj, (int64_t)(T + 1) * d, delta, g, reward, B * T, T, d, G, accumulate, workspace,
                      workspace_bytes, S(stream));
 }

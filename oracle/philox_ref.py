@@ -49,4 +49,4 @@ def philox_elem(seed, elem, step, traj, block):
 
 def u01(r):
     """(0,1] float32 from the top 24 bits (csrc/mfg_device.h::u01)."""
-    return ((r >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
+    return ((r >> np.uint32(8)).astype(np.float64) * 2.0 ** -24 + 2.0 ** -25).astype(np.float32)   # one fma rounding

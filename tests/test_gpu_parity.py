@@ -306,7 +306,7 @@ def test_rollout_fused_vs_oracle(dev, d, B, T, discount_pow, precision, gtol):
     Gw_ref = np.einsum('bt,btf->f', dl, phi[:, :T])
     assert np.max(np.abs(Gh[:F] - Gw_ref)) < 1e-11 * (np.abs(Gw_ref).max() + 1e-300)
     assert abs(Gh[F] - np.sum(dl * gg)) < 1e-10 * max(1.0, abs(np.sum(dl * gg)))
-    assert abs(Gh[F + 1] - r_dev.sum()) < 1e-10 * max(1e-9, abs(r_dev.sum()))
+    assert abs(Gh[F + 1] - r_ref.sum()) < 2e-7 * np.abs(r_ref).sum() + 1e-18      # fp64 (in-kernel) or fp32-rounded rewards
     assert Gh[F + 2] == B * T
     # the unfused pipeline on the same actions agrees with the fused kernel
     pn, r1 = ops().step_given_P(out['pi_traj'][:, 0].contiguous(), out['P'][:, 0].contiguous())

@@ -20,3 +20,4 @@ def test_u01_never_zero():
     u = u01(r)
     assert u.dtype == np.float32 and u.min() > 0 and u.max() <= 1
     assert u[0] == np.float32(2.0 ** -25) and u[2] == np.float32(0.5) and u[3] == np.float32(1.5 * 2.0 ** -24)
+    assert u[1] == np.float32(1.0)
