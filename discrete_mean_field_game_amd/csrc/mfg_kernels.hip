@@ -196,17 +196,107 @@ __global__ void k_value(const float* __restrict__ pi, const double* __restrict__
 
 // ---------------------------------------------------------------------------------------------
 // a3+a4, small d: HBM-bound.  Block = 4 waves, tile = 4*G consecutive trajectories whose P slab
-// (contiguous in HBM) is copied flat with 16-byte loads into LDS; lane = (trajectory, column j)
-// accumulates pi'_j and the column's share of the reward in fp64, one segmented reduction at the end.
+// (contiguous in HBM) is copied flat with 16-byte loads into LDS; lane = (trajectory, column j).
+// Per element the lane does: cvt, p^2, and three fp64 FMAs
+//     pi'_j += p pi_i,   s1_j += pi_i p^2,   s2_j += pi_i^2 p^2        (reward_j = pi_j s1_j - s2_j)
+// with (pi_i, pi_i^2) staged once per tile as fp64 pairs in LDS (one broadcast 16-byte read per row).
+// D > 0: compile-time d (rows unrolled, immediate LDS offsets); D == 0: runtime d.
 // ---------------------------------------------------------------------------------------------
-template <int KIND>
-__global__ __launch_bounds__(BLOCK) void k_step_small(const float* __restrict__ pi, const float* __restrict__ P,
-                                                      int64_t B, int d, int vec_ok, float* __restrict__ pi_next,
+// The P slab of the NEXT tile is prefetched into registers (PER 16-byte loads per thread, all in flight
+// together) while the current tile is consumed from LDS, so each block keeps ~a tile of HBM traffic in
+// flight at all times (the un-pipelined version spent 83 % of its wave cycles waiting: SQ_WAIT_ANY).
+#ifndef MFG_STEP_UNROLL
+#define MFG_STEP_UNROLL 3
+#endif
+#ifndef MFG_STEP_WAVES
+#define MFG_STEP_WAVES 6
+#endif
+template <int KIND, int D, int PER>
+__global__ __launch_bounds__(BLOCK, (PER <= 6 ? MFG_STEP_WAVES : 4)) void k_step_small(const float* __restrict__ pi, const float* __restrict__ P,
+                                                      int64_t B, int d_rt, float* __restrict__ pi_next,
                                                       float* __restrict__ reward) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int d = D ? D : d_rt;
   const int G = WAVE / d, TB = WAVES * G, dd = d * d;
-  float* tP = smem;                 // [TB][d][d]
-  float* tPi = smem + TB * dd;      // [TB][d]
+  double2* tQ = reinterpret_cast<double2*>(smem);     // [TB][d] (pi, pi^2) fp64
+  float* tP = reinterpret_cast<float*>(tQ + TB * d);  // [TB][d][d]
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  const int t = lane / d, j = lane - t * d;
+  const int p2 = next_pow2(d);
+  const int64_t ntiles = (B + TB - 1) / TB;
+  float4 pre[PER];
+  float prepi = 0.0f;
+  // prefetch of tile TT into registers (a macro, not a lambda: capturing pre[] by reference sends it to scratch)
+#define MFG_STEP_PREFETCH(TT)                                                  \
+  {                                                                            \
+    const int64_t pb0 = (TT) * TB;                                             \
+    const int pnb = (int)((B - pb0) < TB ? (B - pb0) : TB);                    \
+    const int pn4 = (pnb * dd) >> 2;                                           \
+    const float4* s4 = reinterpret_cast<const float4*>(P + pb0 * dd);          \
+    _Pragma("unroll") for (int u = 0; u < PER; ++u) {                          \
+      const int k = tid + u * BLOCK;                                           \
+      pre[u] = (k < pn4) ? s4[k] : make_float4(0.f, 0.f, 0.f, 0.f);            \
+    }                                                                          \
+    prepi = (tid < pnb * d) ? pi[pb0 * d + tid] : 0.0f;                        \
+  }
+  if ((int64_t)blockIdx.x < ntiles) MFG_STEP_PREFETCH((int64_t)blockIdx.x)
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t b0 = tile * TB;
+    const int nb = (int)((B - b0) < TB ? (B - b0) : TB);
+    const int n = nb * dd, n4 = n >> 2;
+    float4* d4 = reinterpret_cast<float4*>(tP);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int k = tid + u * BLOCK;
+      if (k < n4) d4[k] = pre[u];
+    }
+    for (int k = (n4 << 2) + tid; k < n; k += BLOCK) tP[k] = P[b0 * dd + k];  // ragged last tile only
+    if (tid < nb * d) {
+      const double v = (double)prepi;
+      tQ[tid] = make_double2(v, v * v);
+    }
+    __syncthreads();
+    if (tile + gridDim.x < ntiles) MFG_STEP_PREFETCH(tile + gridDim.x)
+    const int tl = wv * G + t;
+    const bool valid = (t < G) && (tl < nb);
+    const int tlc = valid ? tl : 0;
+    const float* colp = tP + tlc * dd + j;
+    const double2* qv = tQ + tlc * d;
+    double acc = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll MFG_STEP_UNROLL
+    for (int i = 0; i < (D ? D : d); ++i) {
+      const double p = (double)colp[i * d];
+      const double2 q = qv[i];
+      acc = fma(p, q.x, acc);
+      if (KIND != MFG_REWARD_EXTERNAL) {
+        const double pp = p * p;
+        s1 = fma(q.x, pp, s1);
+        if (KIND == MFG_REWARD_MFG_AC2) s2 = fma(q.y, pp, s2);
+      }
+    }
+    double racc = 0.0;
+    if (KIND == MFG_REWARD_MFG_AC2) racc = fma(qv[j].x, s1, -s2);
+    if (KIND == MFG_REWARD_SYNTHETIC) racc = -0.5 * s1;
+    if (KIND != MFG_REWARD_EXTERNAL) racc = seg_sum(racc, j, d, p2);
+    if (valid) {
+      pi_next[(b0 + tl) * d + j] = (float)acc;
+      if (KIND != MFG_REWARD_EXTERNAL && j == 0) reward[b0 + tl] = (float)racc;
+    }
+    __syncthreads();
+  }
+}
+
+#undef MFG_STEP_PREFETCH
+
+// Fallback for a P pointer that is not 16-byte aligned: scalar staging, no prefetch.
+template <int KIND>
+__global__ __launch_bounds__(BLOCK) void k_step_small_unaligned(const float* __restrict__ pi, const float* __restrict__ P,
+                                                                int64_t B, int d, float* __restrict__ pi_next,
+                                                                float* __restrict__ reward) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int G = WAVE / d, TB = WAVES * G, dd = d * d;
+  double2* tQ = reinterpret_cast<double2*>(smem);
+  float* tP = reinterpret_cast<float*>(tQ + TB * d);
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
   const int t = lane / d, j = lane - t * d;
   const int p2 = next_pow2(d);
@@ -214,43 +304,110 @@ __global__ __launch_bounds__(BLOCK) void k_step_small(const float* __restrict__ 
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t b0 = tile * TB;
     const int nb = (int)((B - b0) < TB ? (B - b0) : TB);
-    const int n = nb * dd;
-    const float* src = P + b0 * dd;
-    if (vec_ok) {
-      const int n4 = n >> 2;
-      const float4* s4 = reinterpret_cast<const float4*>(src);
-      float4* d4 = reinterpret_cast<float4*>(tP);
-      for (int k = tid; k < n4; k += BLOCK) d4[k] = s4[k];
-      for (int k = (n4 << 2) + tid; k < n; k += BLOCK) tP[k] = src[k];
-    } else {
-      for (int k = tid; k < n; k += BLOCK) tP[k] = src[k];
+    for (int k = tid; k < nb * dd; k += BLOCK) tP[k] = P[b0 * dd + k];
+    for (int k = tid; k < nb * d; k += BLOCK) {
+      const double v = (double)pi[b0 * d + k];
+      tQ[k] = make_double2(v, v * v);
     }
-    for (int k = tid; k < nb * d; k += BLOCK) tPi[k] = pi[b0 * d + k];
     __syncthreads();
     const int tl = wv * G + t;
     const bool valid = (t < G) && (tl < nb);
     const int tlc = valid ? tl : 0;
-    const float* rowp = tP + tlc * dd + j;
-    const float* pv = tPi + tlc * d;
-    const double pj = (double)pv[j];
-    double acc = 0.0, racc = 0.0;
-#pragma unroll 4
+    const float* colp = tP + tlc * dd + j;
+    const double2* qv = tQ + tlc * d;
+    double acc = 0.0, s1 = 0.0, s2 = 0.0;
     for (int i = 0; i < d; ++i) {
-      const double p = (double)rowp[i * d];
-      const double pii = (double)pv[i];
-      acc = fma(p, pii, acc);
-      if (KIND == MFG_REWARD_MFG_AC2) racc = fma(pii * (pj - pii), p * p, racc);
-      if (KIND == MFG_REWARD_SYNTHETIC) racc = fma(pii, p * p, racc);
+      const double p = (double)colp[i * d];
+      const double2 q = qv[i];
+      const double pp = p * p;
+      acc = fma(p, q.x, acc);
+      s1 = fma(q.x, pp, s1);
+      s2 = fma(q.y, pp, s2);
     }
-    if (KIND != MFG_REWARD_EXTERNAL) {
-      racc = seg_sum(racc, j, d, p2);
-      if (KIND == MFG_REWARD_SYNTHETIC) racc *= -0.5;
-    }
+    double racc = 0.0;
+    if (KIND == MFG_REWARD_MFG_AC2) racc = fma(qv[j].x, s1, -s2);
+    if (KIND == MFG_REWARD_SYNTHETIC) racc = -0.5 * s1;
+    if (KIND != MFG_REWARD_EXTERNAL) racc = seg_sum(racc, j, d, p2);
     if (valid) {
       pi_next[(b0 + tl) * d + j] = (float)acc;
       if (KIND != MFG_REWARD_EXTERNAL && j == 0) reward[b0 + tl] = (float)racc;
     }
     __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// a3+a4, d = 4*LPR (d = 128: LPR = 32, d = 256: LPR = 64): one wavefront per trajectory, every lane issues
+// 16-byte loads and one wave instruction covers 64/LPR consecutive rows (1 KiB, fully coalesced).  8-byte
+// or half-populated loads reach only ~0.55x of this rate (the d = 128 case of k_step_large).  The lane
+// groups that hold the same columns of different rows are combined with xor-shuffles at the end.
+// ---------------------------------------------------------------------------------------------
+#ifndef MFG_ROWS_UNROLL
+#define MFG_ROWS_UNROLL 8
+#endif
+template <int KIND, int LPR>
+__global__ __launch_bounds__(BLOCK) void k_step_rows(const float* __restrict__ pi, const float* __restrict__ P, int64_t B,
+                                                     float* __restrict__ pi_next, float* __restrict__ reward) {
+  constexpr int d = 4 * LPR, RPW = WAVE / LPR;
+  __shared__ double2 qs[WAVES][d];  // (pi_i, pi_i^2) fp64 per wave
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  const int sub = lane / LPR, c4 = lane - sub * LPR;
+  double2* q = qs[wv];
+  const int64_t nw = (int64_t)gridDim.x * WAVES;
+  for (int64_t b = (int64_t)blockIdx.x * WAVES + wv; b < B; b += nw) {
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < d; c += WAVE) {
+      const double v = (double)pi[b * d + c];
+      q[c] = make_double2(v, v * v);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    double acc[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0}, s2 = 0.0;
+    const float4* Pb = reinterpret_cast<const float4*>(P + b * (int64_t)d * d) + c4;
+#pragma unroll MFG_ROWS_UNROLL
+    for (int i0 = 0; i0 < d; i0 += RPW) {
+      const int row = i0 + sub;
+      const float4 v = Pb[row * LPR];
+      const double2 qq = q[row];
+      const float pv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double p = (double)pv[k];
+        acc[k] = fma(p, qq.x, acc[k]);
+        if (KIND != MFG_REWARD_EXTERNAL) {
+          const double pp = p * p;
+          s1[k] = fma(qq.x, pp, s1[k]);
+          if (KIND == MFG_REWARD_MFG_AC2) s2 = fma(qq.y, pp, s2);
+        }
+      }
+    }
+#pragma unroll
+    for (int off = LPR; off < WAVE; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc[k] += __shfl_xor(acc[k], off, WAVE);
+        if (KIND != MFG_REWARD_EXTERNAL) s1[k] += __shfl_xor(s1[k], off, WAVE);
+      }
+    }
+    if (sub == 0) {
+      float4 o;
+      o.x = (float)acc[0];
+      o.y = (float)acc[1];
+      o.z = (float)acc[2];
+      o.w = (float)acc[3];
+      reinterpret_cast<float4*>(pi_next + b * d)[c4] = o;
+    }
+    if (KIND != MFG_REWARD_EXTERNAL) {
+      double racc = 0.0;
+      if (sub == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) racc += (KIND == MFG_REWARD_MFG_AC2) ? q[4 * c4 + k].x * s1[k] : s1[k];
+      }
+      if (KIND == MFG_REWARD_MFG_AC2) racc -= s2;
+      racc = wave_sum(racc);
+      if (KIND == MFG_REWARD_SYNTHETIC) racc *= -0.5;
+      if (lane == 0) reward[b] = (float)racc;
+    }
   }
 }
 
@@ -286,7 +443,7 @@ __global__ __launch_bounds__(BLOCK) void k_step_large(const float* __restrict__ 
     for (int c = lane; c < d; c += WAVE) pis[c] = pi[b * d + c];
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave landed
-    double pc[R][VEC], acc[R][VEC];
+    double pc[R][VEC], acc[R][VEC], s1[R][VEC];
     int col[R];
 #pragma unroll
     for (int m = 0; m < R; ++m) {
@@ -295,13 +452,15 @@ __global__ __launch_bounds__(BLOCK) void k_step_large(const float* __restrict__ 
       for (int v = 0; v < VEC; ++v) {
         pc[m][v] = (col[m] + v < d) ? (double)pis[col[m] + v] : 0.0;
         acc[m][v] = 0.0;
+        s1[m][v] = 0.0;
       }
     }
-    double racc = 0.0;
+    double s2 = 0.0;  // sum_i pi_i^2 sum_(own columns) p^2
     const float* Pb = P + b * (int64_t)d * d;
 #pragma unroll 4
     for (int i = 0; i < d; ++i) {
       const double pii = (double)pis[i];
+      const double pii2 = pii * pii;
       const float* row = Pb + (int64_t)i * d;
 #pragma unroll
       for (int m = 0; m < R; ++m) {
@@ -312,8 +471,11 @@ __global__ __launch_bounds__(BLOCK) void k_step_large(const float* __restrict__ 
           for (int v = 0; v < VEC; ++v) {
             const double p = (double)pv[v];
             acc[m][v] = fma(p, pii, acc[m][v]);
-            if (KIND == MFG_REWARD_MFG_AC2) racc = fma(pii * (pc[m][v] - pii), p * p, racc);
-            if (KIND == MFG_REWARD_SYNTHETIC) racc = fma(pii, p * p, racc);
+            if (KIND != MFG_REWARD_EXTERNAL) {
+              const double pp = p * p;
+              s1[m][v] = fma(pii, pp, s1[m][v]);
+              if (KIND == MFG_REWARD_MFG_AC2) s2 = fma(pii2, pp, s2);
+            }
           }
         }
       }
@@ -328,6 +490,12 @@ __global__ __launch_bounds__(BLOCK) void k_step_large(const float* __restrict__ 
       }
     }
     if (KIND != MFG_REWARD_EXTERNAL) {
+      double racc = 0.0;
+#pragma unroll
+      for (int m = 0; m < R; ++m)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) racc += (KIND == MFG_REWARD_MFG_AC2) ? pc[m][v] * s1[m][v] : s1[m][v];
+      if (KIND == MFG_REWARD_MFG_AC2) racc -= s2;
       racc = wave_sum(racc);
       if (KIND == MFG_REWARD_SYNTHETIC) racc *= -0.5;
       if (lane == 0) reward[b] = (float)racc;
@@ -620,21 +788,33 @@ int mfg_step_given_P(const float* pi, const float* P, int64_t B, int d, int rewa
   hipStream_t st = S(stream);
   if (d <= WAVE) {
     const int G = WAVE / d, TB = WAVES * G;
-    const size_t lds = (size_t)TB * d * d * 4 + (size_t)TB * d * 4;
+    const size_t lds = (size_t)TB * d * d * 4 + (size_t)TB * d * 16;
     int bpc = (int)((160 * 1024) / (lds + 256));
     if (bpc > 8) bpc = 8;
     if (bpc < 1) bpc = 1;
     const int grid = grid_for(B, TB, bpc);
-    const int vec_ok = (((uintptr_t)P & 15) == 0) && (((int64_t)TB * d * d) % 4 == 0);
-#define STEP_SMALL(K)                                                                                         \
-  case K:                                                                                                     \
-    hipLaunchKernelGGL((k_step_small<K>), dim3(grid), dim3(BLOCK), lds, st, pi, P, B, d, vec_ok, pi_next, reward); \
-    break;
-    switch (reward_kind) {
-      STEP_SMALL(0)
-      STEP_SMALL(1)
-      STEP_SMALL(2)
-    }
+    const bool aligned = (((uintptr_t)P & 15) == 0);
+    const int per = (int)(((int64_t)TB * d * d / 4 + BLOCK - 1) / BLOCK);  // 16-byte loads per thread per tile
+#define STEP_SMALL(K, DD, PP) \
+  hipLaunchKernelGGL((k_step_small<K, DD, PP>), dim3(grid), dim3(BLOCK), lds, st, pi, P, B, d, pi_next, reward)
+#define STEP_SMALL_D(DD, PP)                 \
+  switch (reward_kind) {                     \
+    case 0: STEP_SMALL(0, DD, PP); break;    \
+    case 1: STEP_SMALL(1, DD, PP); break;    \
+    default: STEP_SMALL(2, DD, PP); break;   \
+  }
+    if (!aligned) {
+      switch (reward_kind) {
+        case 0: hipLaunchKernelGGL((k_step_small_unaligned<0>), dim3(grid), dim3(BLOCK), lds, st, pi, P, B, d, pi_next, reward); break;
+        case 1: hipLaunchKernelGGL((k_step_small_unaligned<1>), dim3(grid), dim3(BLOCK), lds, st, pi, P, B, d, pi_next, reward); break;
+        default: hipLaunchKernelGGL((k_step_small_unaligned<2>), dim3(grid), dim3(BLOCK), lds, st, pi, P, B, d, pi_next, reward); break;
+      }
+    } else if (d == 21) { STEP_SMALL_D(21, 6) }
+    else if (d == 15) { STEP_SMALL_D(15, 4) }
+    else if (per <= 4) { STEP_SMALL_D(0, 4) }
+    else if (per <= 8) { STEP_SMALL_D(0, 8) }
+    else { STEP_SMALL_D(0, 16) }
+#undef STEP_SMALL_D
 #undef STEP_SMALL
   } else {
     const size_t lds = (size_t)WAVES * d * 4;
@@ -645,6 +825,21 @@ int mfg_step_given_P(const float* pi, const float* P, int64_t B, int d, int rewa
     else if (a16 && d % 2 == 0) vec = 2;
     // keep at most 2 chunks per lane on the vector paths, fall back to narrower vectors otherwise
     int R = (d + WAVE * vec - 1) / (WAVE * vec);
+#define STEP_ROWS(L)                                                                                                    \
+  switch (reward_kind) {                                                                                                \
+    case 0: hipLaunchKernelGGL((k_step_rows<0, L>), dim3(grid), dim3(BLOCK), 0, st, pi, P, B, pi_next, reward); break;  \
+    case 1: hipLaunchKernelGGL((k_step_rows<1, L>), dim3(grid), dim3(BLOCK), 0, st, pi, P, B, pi_next, reward); break;  \
+    default: hipLaunchKernelGGL((k_step_rows<2, L>), dim3(grid), dim3(BLOCK), 0, st, pi, P, B, pi_next, reward); break; \
+  }
+    if (a16 && d == 128) {
+      STEP_ROWS(32)
+      return check_launch("step_given_P");
+    }
+    if (a16 && d == 256) {
+      STEP_ROWS(64)
+      return check_launch("step_given_P");
+    }
+#undef STEP_ROWS
 #define STEP_LARGE(V, RR, K) \
   hipLaunchKernelGGL((k_step_large<V, RR, K>), dim3(grid), dim3(BLOCK), lds, st, pi, P, B, d, pi_next, reward)
 #define STEP_LARGE_K(V, RR)                      \

@@ -25,6 +25,13 @@ def probe(d, B, T):
     bytes_step = 4 * (d * d + 2 * d + 1)
     t = timeit(lambda: ops.step_given_P(pi, P))
     print('d=%d B=%d step_given_P: %.1f us  %.3e steps/s  %.2f TB/s (%.1f%% of 8TB/s)' % (d, B, t*1e6, B/t, B*bytes_step/t/1e12, 100*B*bytes_step/t/8e12))
+    # HBM leg: a slab larger than the 256 MiB L3
+    Nbig = max(B, int(1.6e9 // (4 * d * d)))
+    piB = torch.rand(Nbig, d, device=dev, generator=g); piB = (piB / piB.sum(1, keepdim=True)).contiguous()
+    PB = torch.rand(Nbig, d, d, device=dev, generator=g)
+    t = timeit(lambda: ops.step_given_P(piB, PB))
+    print('   step_given_P on %.2f GB slab: %.1f us  %.3e steps/s  %.2f TB/s (%.1f%% of 8TB/s)' % (Nbig*d*d*4/1e9, t*1e6, Nbig/t, Nbig*bytes_step/t/1e12, 100*Nbig*bytes_step/t/8e12))
+    del piB, PB
     t = timeit(lambda: ops.sample_dirichlet(pi, th, 0.16, 12000.0, seed=1, out=P))
     print('   sample_dirichlet: %.1f us  %.3e steps/s' % (t*1e6, B/t))
     pn, r = ops.step_given_P(pi, P)
