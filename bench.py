@@ -181,17 +181,25 @@ def main():
             n_launch = 20
             t_step = event_time(lambda: ops.step_given_P(pi_all, P_all), n=n_launch)
             achieved = N * bytes_per_step / t_step / 1e9
-            traffic, traffic_src = pmc_traffic('k_step_small' if d <= 64 else 'k_step_large', d, T, B)
+            traffic, traffic_src = pmc_traffic('k_step_', d, T, B)
             roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
-                        'kernel': 'k_step_small' if d <= 64 else 'k_step_large',
+                        'kernel': 'k_step_small' if d <= 64 else ('k_step_rows' if d in (128, 256) else 'k_step_large'),
                         'leg': 'given-P transition+reward over %d transitions (P slab %.2f GB)' % (N, N * d * d * 4 / 1e9),
                         'algorithmic_bytes_per_launch': N * bytes_per_step, 'avg_launch_us': t_step * 1e6,
                         'env_steps_per_s': N / t_step}
             del P_all, pi_all, r
+            # this box's own streaming ceilings (stock torch kernels on a 1.6 GB buffer), for context
+            xx = torch.empty(400_000_000, device=dev).uniform_()
+            yy = torch.empty_like(xx)
+            t_rd = event_time(lambda: xx.sum(), n=5)
+            t_cp = event_time(lambda: yy.copy_(xx), n=5)
+            roofline['box_ceiling_GBs'] = {'torch_sum_read': xx.numel() * 4 / t_rd / 1e9,
+                                           'torch_copy_read_plus_write': 2 * xx.numel() * 4 / t_cp / 1e9}
+            del xx, yy
             t_f = event_time(lambda: ops.rollout(pi0, T, theta, shift, alpha_scale, w=w, gamma=gamma, seed=7,
                                                  traj_offset=traj_offset, td=True, G=G, ws=ws, out=bufs), n=5, warm=1)
-            fused = {'kernel': 'k_core_small<SAMPLE,TD>+grad' if d <= 64 else 'k_core_large<SAMPLE,TD>+grad',
+            fused = {'kernel': 'k_core_small<SAMPLE,TD,MIXED> (+ in-kernel batch sums)' if d <= 64 else 'k_core_large<SAMPLE,TD,MIXED>+grad',
                      'bound': 'valu/transcendental+rng (P stays on chip)', 'avg_launch_ms': t_f * 1e3,
                      'env_steps_per_s': B * T / t_f, 'hbm_algorithmic_GBs': B * T * bytes_per_step / t_f / 1e9}
         cpu = None
@@ -200,7 +208,7 @@ def main():
         out = {
             'metric': 'env-steps/sec for batched d-bin population rollouts', 'value': value, 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32 storage / f64 accumulate',
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32 storage + f32 hw transcendentals / f64 accumulate',
             'data': 'synthetic',
             'config': {'workload': 'forward-RL actor-critic training rollouts (mfg_ac2.train, update per rollout): '
                                    'd=%d topics, T=%d, batch=%d trajectories per GPU' % (d, T, B),
