@@ -124,7 +124,11 @@ class AC_IRL(actor_critic):
 
     def reward(self, pi, P):
         """r(pi, P) from the reward network: [B,d], [B,d,d] -> [B] (ac_irl.py:683)."""
-        with torch.no_grad():
+        if ops.reward_net_supported(self.reward_net) and pi.is_cuda:
+            self._reward_calls = getattr(self, '_reward_calls', 0) + 1           # fresh dropout masks per call
+            return ops.reward_net_forward(self.reward_net, pi.contiguous(), P.contiguous(), seed=self.seed + 0x5EED,
+                                          sample_offset=(self._reward_calls & 0xFFFF) << 32)
+        with torch.no_grad():                                                    # shapes outside the kernel's range
             return self.reward_net(pi, P).reshape(-1).float().contiguous()
 
     def calc_alpha_deriv(self, pi):

@@ -36,6 +36,8 @@ struct CoreArgs {
   double* partial;     // [gridDim.x][F+3] per-block gradient sums (D-specialised small kernels) or NULL
 };
 
+int set_error(int code, const char* msg);  // records mfg_last_error() (defined in mfg_kernels.hip)
+
 // launchers defined in mfg_core_small.hip / mfg_core_large_*.hip; return 0 or MFG_EUNSUPPORTED
 // *partial_blocks = number of per-block partial rows the kernel writes to a.partial (0 = none written)
 int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st,

@@ -31,6 +31,9 @@ static int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+namespace mfg {
+int set_error(int code, const char* msg) { return fail(code, "%s", msg); }
+}  // namespace mfg
 static int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(MFG_ELAUNCH, "%s: %s", what, hipGetErrorString(e));

@@ -197,3 +197,30 @@ def jsd(p, q):
     out = torch.empty(B, dtype=torch.float64, device=p.device)
     L.check(L.lib().mfg_jsd(p.data_ptr(), q.data_ptr(), B, d, out.data_ptr(), _stream()), 'mfg_jsd')
     return out
+
+
+def reward_net_supported(net) -> bool:
+    """True when networks.RewardNet `net` fits the HIP forward kernel (d <= 32, f1 = 1, f2 <= 2, n_fc <= 32)."""
+    k1, k2 = net.conv1.kernel_size[0], net.conv2.kernel_size[0]
+    return (net.conv1.out_channels == 1 and net.conv2.out_channels <= 2 and net.d <= 32 and k1 % 2 == 1 and k2 % 2 == 1
+            and k1 <= 7 and k2 <= 7 and net.fc3.out_features <= 32 and net.fc4.out_features <= 32
+            and next(net.parameters()).dtype == torch.float32 and next(net.parameters()).is_cuda)
+
+
+def reward_net_forward(net, state, action, dropout=None, seed=0, sample_offset=0):
+    """r(state, action) [B] with the weights of a networks.RewardNet, one HIP launch (ac_irl.py:683 batched).
+    dropout: None -> follow the module (active when the variant has dropout and dropout_always/training)."""
+    _chk_f32(state, 'state'); _chk_f32(action, 'action')
+    B, d = state.shape
+    if dropout is None:
+        dropout = net.use_dropout and (net.dropout_always or net.training)
+    keep = float(net.keep_prob) if dropout else 1.0
+    out = torch.empty(B, dtype=torch.float32, device=state.device)
+    P = lambda t: t.detach().contiguous().data_ptr()
+    L.check(L.lib().mfg_reward_net_forward(
+        state.data_ptr(), action.data_ptr(), B, d, net.conv1.kernel_size[0], net.conv2.out_channels,
+        net.conv2.kernel_size[0], net.fc3.out_features, net.fc4.out_features, P(net.conv1.weight), P(net.conv1.bias),
+        P(net.conv2.weight), P(net.conv2.bias), P(net.fc3.weight), P(net.fc3.bias), P(net.fc4.weight), P(net.fc4.bias),
+        P(net.out.weight), P(net.out.bias), keep, int(seed), int(sample_offset), out.data_ptr(), _stream()),
+        'mfg_reward_net_forward')
+    return out

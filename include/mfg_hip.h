@@ -144,6 +144,19 @@ int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, 
                 double* delta, double* g, float* P_out, double* G, int accumulate, void* workspace,
                 size_t workspace_bytes, mfg_stream_t stream);
 
+/* f1 (IRL): reward[b] = r_net(state_b, action_b), the reward network of networks.py:46-81 evaluated for B
+ * transitions in one launch (ac_irl.py:683 evaluates it with batch 1 per env step).  fp32.  Weight layouts are
+ * PyTorch's: conv1_w [k1*k1], conv2_w [f2][k2*k2], fc3_w [n3][d*d*f2] with the input index (pixel*f2 + channel)
+ * (TF's NHWC flatten, networks.py:67), fc4_w [n4][n3+d] (inputs = [fc3 activations, state], networks.py:72),
+ * out_w [n4].  keep_prob < 1 applies inverted dropout after fc3 and fc4 like tf.contrib.layers.dropout in
+ * training mode (the reference leaves it on when the net serves as the RL reward); masks come from Philox keyed
+ * by (seed, sample_offset + b).  Supported: d <= 32, f2 <= 2, n3, n4 <= 32, odd k1, k2 <= 7. */
+int mfg_reward_net_forward(const float* state, const float* action, int64_t B, int d, int k1, int f2, int k2, int n3,
+                           int n4, const float* conv1_w, const float* conv1_b, const float* conv2_w,
+                           const float* conv2_b, const float* fc3_w, const float* fc3_b, const float* fc4_w,
+                           const float* fc4_b, const float* out_w, const float* out_b, float keep_prob, uint64_t seed,
+                           uint64_t sample_offset, float* reward, mfg_stream_t stream);
+
 /* a11: out[b] = JSD(p_b, q_b), zeros -> 1e-100, inputs renormalised like scipy.stats.entropy
  * (mfg_ac2.py:546-563).  fp64 out. */
 int mfg_jsd(const float* p, const float* q, int64_t B, int d, double* out, mfg_stream_t stream);

@@ -232,3 +232,62 @@ def test_irl_outerloop_smoke(dev):
     assert np.isfinite(ac.loss_val)
     ac.train(max_episodes=3, stop_criteria=-1)
     assert len(ac.list_policies) == 2 and np.isfinite(float(np.ravel(ac.theta)[0]))
+
+
+@pytest.mark.parametrize('reg', ['none', 'dropout_l1l2'])
+@pytest.mark.parametrize('d,n3,n4', [(15, 8, 4), (21, 8, 4), (21, 6, 8), (32, 4, 4), (4, 3, 2)])
+def test_reward_net_hip_forward_matches_torch_and_numpy(dev, reg, d, n3, n4):
+    """One-launch HIP forward of the reward net (ac_irl.py:683 batched) vs the PyTorch module and the NumPy
+    restatement of networks.py:46-81 (dropout off: deterministic part)."""
+    from discrete_mean_field_game_amd import ops
+    from discrete_mean_field_game_amd.networks import RewardNet
+    from oracle import reward_net_oracle as RO
+    torch.manual_seed(d + n3)
+    net = RewardNet(d=d, reg=reg, n_fc3=n3, n_fc4=n4, dropout_always=False).to(dev).eval()
+    for p in net.parameters():
+        if p.dim() == 1:
+            torch.nn.init.uniform_(p, -0.2, 0.2)
+    assert ops.reward_net_supported(net)
+    rs = np.random.RandomState(d)
+    B = 333
+    state = rs.dirichlet(np.ones(d), size=B).astype(np.float32)
+    action = rs.dirichlet(np.ones(d), size=(B, d)).astype(np.float32)
+    s_t, a_t = torch.as_tensor(state, device=dev), torch.as_tensor(action, device=dev)
+    out = ops.reward_net_forward(net, s_t, a_t).cpu().numpy()
+    with torch.no_grad():
+        ref_t = net(s_t, a_t).reshape(-1).cpu().numpy()
+    ref_n = RO.forward(RO.params_from_torch(net), state.astype(np.float64), action.astype(np.float64))[:, 0]
+    assert out.shape == (B,)
+    assert np.max(np.abs(out - ref_n)) < 2e-6                  # fp32 kernel vs fp64 restatement
+    assert np.max(np.abs(out - ref_t)) < 5e-6                  # vs the MIOpen / rocBLAS path
+    assert np.max(np.abs(out)) < 1
+
+
+def test_reward_net_hip_dropout_statistics(dev):
+    """Dropout (keep 0.4, inverted scaling) stays on when the net is the RL reward, like the reference
+    (tf.contrib.layers.dropout defaults to is_training=True): masks differ per call and per sample, and the
+    pre-activation mean is preserved."""
+    from discrete_mean_field_game_amd import ops
+    from discrete_mean_field_game_amd.networks import RewardNet
+    torch.manual_seed(0)
+    d = 21
+    net = RewardNet(d=d, reg='dropout_l1l2').to(dev)
+    with torch.no_grad():
+        net.out.weight.mul_(0.05)                                # keep tanh in its linear range
+    rs = np.random.RandomState(1)
+    s1 = rs.dirichlet(np.ones(d)).astype(np.float32); a1 = rs.dirichlet(np.ones(d), size=d).astype(np.float32)
+    B = 20000
+    s_t = torch.as_tensor(np.repeat(s1[None], B, 0), device=dev)
+    a_t = torch.as_tensor(np.repeat(a1[None], B, 0), device=dev)
+    r1 = ops.reward_net_forward(net, s_t, a_t, seed=1).cpu().numpy()
+    r2 = ops.reward_net_forward(net, s_t, a_t, seed=2).cpu().numpy()
+    r1b = ops.reward_net_forward(net, s_t, a_t, seed=1).cpu().numpy()
+    assert np.array_equal(r1, r1b) and not np.array_equal(r1, r2)       # counter-based masks
+    assert len(np.unique(np.round(r1, 6))) > 10                          # masks differ across samples
+    with torch.no_grad():
+        torch.manual_seed(3)
+        rt = net(s_t, a_t).reshape(-1).cpu().numpy()                     # torch's dropout, same distribution
+    assert abs(r1.mean() - rt.mean()) < 4 * (r1.std() + rt.std()) / np.sqrt(B) + 1e-4
+    assert abs(r1.std() - rt.std()) < 0.05 * rt.std() + 1e-5
+    r0 = ops.reward_net_forward(net, s_t[:4].contiguous(), a_t[:4].contiguous(), dropout=False).cpu().numpy()
+    assert np.allclose(r0, r0[0])
