@@ -152,6 +152,8 @@ class AC_IRL(actor_critic):
         F = ops.num_features(d)
         G = torch.zeros(F + 3, dtype=torch.float64, device=self.device)
         ws = ops.workspace(shard.local_batch, d, self.device)
+        dg = (torch.empty(shard.local_batch, dtype=torch.float64, device=self.device),
+              torch.empty(shard.local_batch, dtype=torch.float64, device=self.device))
         rfn = reward_fn if reward_fn is not None else self.reward
         prev_theta = float(self._theta.cpu()[0])
         list_reward = []
@@ -160,21 +162,29 @@ class AC_IRL(actor_critic):
         for episode in range(1, max_episodes + 1):
             pi = ops.gather_start(self._mat_pi0_dev, self._draw_start(shard))
             discount = 1.0
-            total_reward = torch.zeros((), dtype=torch.float64, device=self.device)
+            total_reward = torch.zeros(1, dtype=torch.float64, device=self.device)
             sc, sa = lr_scales(episode, constant)          # lr/(episode+1) with the 1-indexed episode (:700)
             for step in range(T):
-                P = self._sample(pi, shard.traj_offset)
+                if self.rng == 'philox':
+                    # sample P and take the transition in one launch (P materialised for the reward net)
+                    o = ops.rollout(pi, 1, self._theta, self.shift, self.alpha_scale, seed=self.seed,
+                                    first_step=self._rng_step, traj_offset=shard.traj_offset, td=False, write_P=True,
+                                    precision=self.precision)
+                    self._rng_step += 1
+                    P = o['P'].view(shard.local_batch, d, d)
+                    pi_next = o['pi_traj'][:, 1].contiguous()
+                else:
+                    P = self._sample(pi, shard.traj_offset, snapshot=False)
+                    pi_next, _ = ops.step_given_P(pi, P, want_reward=False)
                 if write_all:
                     self._write_all(pi, P, step + 1)
-                pi_next, _ = ops.step_given_P(pi, P, want_reward=False)
                 r = rfn(pi, P)
                 ops.td_pg_accumulate(pi, pi_next, P, r, self._w, self._theta, self.shift, discount, G=G, ws=ws,
-                                     precision=self.precision,
+                                     precision=self.precision, out=dg,
                                      accumulate=(self.update_every == 'rollout' and step > 0))
                 if self.update_every == 'step':
                     all_reduce_gradients_(G, self.group)
-                    ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta)
-                    total_reward += G[F + 1] / G[F + 2]
+                    ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta, total_reward)
                     self._theta_is_array = True
                     if self.trace is not None:
                         self.trace.append(float(self._theta.cpu()[0]))
@@ -182,12 +192,12 @@ class AC_IRL(actor_critic):
                 pi = pi_next
             if self.update_every == 'rollout':
                 all_reduce_gradients_(G, self.group)
-                ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta)
-                total_reward = G[F + 1] / G[F + 2] * T
+                ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta, total_reward)
+                total_reward = total_reward * T
                 self._theta_is_array = True
             list_reward.append(total_reward)
             if episode % consecutive == 0:
-                reward_avg = float(torch.stack(list_reward).sum().cpu()) / consecutive
+                reward_avg = float(torch.cat(list_reward).sum().cpu()) / consecutive
                 list_reward = []
                 pi_host = pi[0].cpu().numpy().astype(np.float64)
                 if self.verbose:

@@ -139,10 +139,11 @@ __global__ void k_philox_raw(uint64_t seed, uint32_t first, uint32_t c1, uint32_
 }
 
 __global__ void k_apply_update(const double* __restrict__ G, int64_t F, double lr_c, double lr_a, double* __restrict__ w,
-                               double* __restrict__ theta) {
+                               double* __restrict__ theta, double* __restrict__ reward_acc) {
   const double count = G[F + 2];
   if (!(count > 0.0)) return;
   const double inv = 1.0 / count;
+  if (reward_acc && blockIdx.x == 0 && threadIdx.x == 0) *reward_acc += G[F + 1] * inv;
   for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < F; k += (int64_t)gridDim.x * blockDim.x)
     w[k] += lr_c * (G[k] * inv);
   if (blockIdx.x == 0 && threadIdx.x == 0) *theta += lr_a * (G[F] * inv);
@@ -691,7 +692,7 @@ static int launch_core(const CoreArgs& a, bool sample, bool td, int precision, h
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 2; }
+int mfg_abi_version(void) { return 3; }
 
 int mfg_device_info(int* cu_count_host, char* arch_host, int arch_len) {
   int dev = 0;
@@ -974,11 +975,11 @@ int mfg_td_pg_accumulate(const float* pi, const float* pi_next, const float* P, 
 }
 
 int mfg_apply_update(const double* G, int d, double lr_critic, double lr_actor, double* w, double* theta,
-                     mfg_stream_t stream) {
+                     double* reward_acc, mfg_stream_t stream) {
   REQUIRE(G && w && theta && d >= 1, "null pointer");
   const int64_t F = mfg_num_features(d);
   hipLaunchKernelGGL(k_apply_update, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, S(stream), G, F, lr_critic,
-                     lr_actor, w, theta);
+                     lr_actor, w, theta, reward_acc);
   return check_launch("apply_update");
 }
 

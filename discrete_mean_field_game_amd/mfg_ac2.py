@@ -214,9 +214,10 @@ class actor_critic:
                 y[b, i] = np.random.gamma(shape=a[b, i, :] * self.alpha_scale, scale=1)
         return torch.as_tensor(y.astype(np.float32), device=self.device)
 
-    def _sample(self, pi_dev, traj_offset=0):
+    def _sample(self, pi_dev, traj_offset=0, snapshot=True):
         self._pi_alpha = pi_dev
-        self._theta_at_sample = self._theta.clone()
+        if snapshot:                       # theta at sampling time, for the mat_alpha / mat_alpha_deriv attributes
+            self._theta_at_sample = self._theta.clone()
         if self.rng == 'numpy':
             return ops.dirichlet_from_gamma(self._host_gamma(pi_dev))
         P = ops.sample_dirichlet(pi_dev, self._theta, self.shift, self.alpha_scale, self.seed, self._rng_step,
@@ -314,8 +315,7 @@ class actor_critic:
                                   traj_offset=shard.traj_offset, td=True, G=G, ws=ws, precision=self.precision)
                 self._rng_step += T
                 all_reduce_gradients_(G, self.group)
-                ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta)
-                ep_reward[episode] = G[F + 1] / G[F + 2]
+                ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta, ep_reward[episode:episode + 1])
                 pi = out['pi_traj'][:, T].contiguous()
                 self._theta_is_array = True
                 if self.trace is not None:
@@ -330,7 +330,7 @@ class actor_critic:
                         self._rng_step += 1
                         pi_next = out['pi_traj'][:, 1].contiguous()
                     else:
-                        P = self._sample(pi, shard.traj_offset)
+                        P = self._sample(pi, shard.traj_offset, snapshot=False)
                         if write_all:
                             self._write_all(pi, P, step + 1)
                         pi_next, r = ops.step_given_P(pi, P, reward_kind=self.reward_kind)
@@ -339,20 +339,20 @@ class actor_critic:
                                              accumulate=(self.update_every == 'rollout' and step > 0))
                     if self.update_every == 'step':
                         all_reduce_gradients_(G, self.group)
-                        ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta)
-                        ep_reward[episode] += G[F + 1] / G[F + 2]
+                        ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta,
+                                         ep_reward[episode:episode + 1])
                         self._theta_is_array = True
                         if self.trace is not None:
                             self.trace.append(float(self._theta.cpu()[0]))
                     pi = pi_next
                 if self.update_every == 'rollout':
                     all_reduce_gradients_(G, self.group)
-                    ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta)
-                    ep_reward[episode] = G[F + 1] / G[F + 2] * T
+                    ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta,
+                                     ep_reward[episode:episode + 1])
                     self._theta_is_array = True
                     if self.trace is not None:
                         self.trace.append(float(self._theta.cpu()[0]))
-            if self.update_every == 'rollout' and self.rng == 'philox':
+            if self.update_every == 'rollout':
                 ep_reward[episode] *= T            # mean over B*T transitions -> mean episode return
             if episode % consecutive == 0:
                 # the reference divides the sum over the window by `consecutive` even at episode 0 (:530-534)

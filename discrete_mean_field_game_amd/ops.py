@@ -128,14 +128,17 @@ def score(pi_alpha, P, theta, shift, precision='mixed'):
 
 
 def td_pg_accumulate(pi, pi_next, P, reward, w, theta, shift, gamma_or_discount, G=None, accumulate=False, ws=None,
-                     precision='mixed'):
+                     precision='mixed', out=None):
     for t, n in ((pi, 'pi'), (pi_next, 'pi_next'), (P, 'P'), (reward, 'reward')):
         _chk_f32(t, n)
     _chk_f64(w, 'w'); _chk_f64(theta, 'theta')
     B, d = pi.shape
     F = num_features(d)
-    delta = torch.empty(B, dtype=torch.float64, device=pi.device)
-    g = torch.empty(B, dtype=torch.float64, device=pi.device)
+    if out is not None:
+        delta, g = out
+    else:
+        delta = torch.empty(B, dtype=torch.float64, device=pi.device)
+        g = torch.empty(B, dtype=torch.float64, device=pi.device)
     if G is None:
         G = torch.zeros(F + 3, dtype=torch.float64, device=pi.device)
     if ws is None:
@@ -148,10 +151,11 @@ def td_pg_accumulate(pi, pi_next, P, reward, w, theta, shift, gamma_or_discount,
     return delta, g, G
 
 
-def apply_update(G, d, lr_critic, lr_actor, w, theta):
+def apply_update(G, d, lr_critic, lr_actor, w, theta, reward_acc=None):
+    """w, theta update from the batch sums; reward_acc (fp64 device scalar / 1-element view) += mean reward."""
     _chk_f64(G, 'G'); _chk_f64(w, 'w'); _chk_f64(theta, 'theta')
     L.check(L.lib().mfg_apply_update(G.data_ptr(), d, float(lr_critic), float(lr_actor), w.data_ptr(),
-                                     theta.data_ptr(), _stream()), 'mfg_apply_update')
+                                     theta.data_ptr(), _ptr(reward_acc), _stream()), 'mfg_apply_update')
 
 
 def rollout(pi0, T, theta, shift, alpha_scale, w=None, gamma=1.0, reward_kind=L.REWARD_MFG_AC2, seed=0,

@@ -130,9 +130,11 @@ int mfg_td_pg_accumulate(const float* pi, const float* pi_next, const float* P, 
                          void* workspace, size_t workspace_bytes, mfg_stream_t stream);
 
 /* a6/a8: w += lr_critic * G_w / count ; theta += lr_actor * G_theta / count  (mfg_ac2.py:511-522).
- * count = G[F+2] (number of transitions summed, after any all-reduce). */
+ * count = G[F+2] (number of transitions summed, after any all-reduce).  If reward_acc is not NULL the mean
+ * reward of the update, G[F+1]/count, is added to *reward_acc (total_reward += reward, mfg_ac2.py:526) so the
+ * episode return never needs a host round trip. */
 int mfg_apply_update(const double* G, int d, double lr_critic, double lr_actor, double* w, double* theta,
-                     mfg_stream_t stream);
+                     double* reward_acc, mfg_stream_t stream);
 
 /* Fused T-step rollout with fixed (theta, w): a1-a5, a7 per step, state kept on chip.
  *   pi_traj[B,T+1,d] fp32 (pi_traj[:,0] = pi0), reward[B,T] fp32, delta[B,T], g[B,T] fp64,
