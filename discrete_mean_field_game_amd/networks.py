@@ -24,6 +24,18 @@ import torch.nn.functional as Fnn
 REG_VARIANTS = ('none', 'dropout', 'l1l2', 'dropout_l1l2')
 
 
+def conv2d_same_gemm(x, weight, bias):
+    """Stride-1 SAME cross-correlation as im2col + matmul (x [N,C,H,W], weight [O,C,k,k]).
+    Same math as F.conv2d(x, weight, bias, padding=k//2); written as unfold + GEMM so that on ROCm it runs on
+    kernels already inside the PyTorch binary (rocBLAS) instead of MIOpen, whose first call per shape JIT
+    compiles for tens of seconds on a fresh machine.  The maps here are tiny (d <= 64, <= 2 channels)."""
+    N, C, H, W = x.shape
+    O, _, k, _ = weight.shape
+    cols = Fnn.unfold(x, kernel_size=k, padding=k // 2)                  # [N, C*k*k, H*W]
+    out = torch.matmul(weight.reshape(O, C * k * k), cols)               # [N, O, H*W]
+    return (out + bias.reshape(1, O, 1)).reshape(N, O, H, W)
+
+
 class RewardNet(nn.Module):
 
     def __init__(self, d=15, reg='dropout_l1l2', f1=1, k1=5, f2=2, k2=3, n_fc3=8, n_fc4=4, keep_prob=0.4,
@@ -55,8 +67,8 @@ class RewardNet(nn.Module):
         d = self.d
         x = action.reshape(-1, 1, d, d)
         s = state.reshape(-1, d)
-        x = Fnn.relu(self.conv1(x))
-        x = Fnn.relu(self.conv2(x))
+        x = Fnn.relu(conv2d_same_gemm(x, self.conv1.weight, self.conv1.bias))
+        x = Fnn.relu(conv2d_same_gemm(x, self.conv2.weight, self.conv2.bias))
         x = x.permute(0, 2, 3, 1).reshape(-1, self.f2 * d * d)     # NHWC flatten, networks.py:67
         x = self._drop(Fnn.relu(self.fc3(x)))
         x = torch.cat([x, s], dim=1)                                # networks.py:72

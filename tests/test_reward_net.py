@@ -56,3 +56,17 @@ def test_maxent_loss_hand_values():
     loss, first, second = maxent_irl_loss(torch.as_tensor(rd), torch.as_tensor(rg), 5, 5, torch.tensor(0.5))
     ref = RO.irl_loss(rd, rg, 5, 5, 0.5)
     assert np.allclose([float(loss), float(first), float(second)], ref, rtol=1e-12)
+
+
+def test_gemm_conv_equals_conv2d():
+    from discrete_mean_field_game_amd.networks import conv2d_same_gemm
+    torch.manual_seed(0)
+    x = torch.randn(5, 2, 21, 21, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(3, 2, 5, 5, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(3, dtype=torch.float64)
+    a = conv2d_same_gemm(x, w, b)
+    r = torch.nn.functional.conv2d(x, w, b, padding=2)
+    assert torch.allclose(a, r, rtol=1e-12, atol=1e-12)
+    ga = torch.autograd.grad(a.sum(), (x, w))
+    gr = torch.autograd.grad(torch.nn.functional.conv2d(x, w, b, padding=2).sum(), (x, w))
+    assert all(torch.allclose(p, q, rtol=1e-10, atol=1e-10) for p, q in zip(ga, gr))
