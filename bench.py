@@ -45,6 +45,9 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
+                    help="collective backend; 'gloo' (+ --share-gpu) only exists to smoke-test the N>1 path on a 1-GPU box")
+    ap.add_argument('--share-gpu', action='store_true', help='debug: all ranks use GPU 0')
     return ap.parse_args()
 
 
@@ -94,11 +97,16 @@ def main():
     if not torch.cuda.is_available():
         sys.exit('bench.py needs a GPU: the HIP path has no CPU fallback')
     _lib.lib()  # fail loudly if the extension is missing
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
 
     d, T = args.d, args.T
     B = args.batch if args.scaling == 'weak' else args.batch // world
@@ -121,12 +129,20 @@ def main():
             'g': torch.empty(B, T, dtype=torch.float64, device=dev)}
     traj_offset = rank * B
 
+    def all_reduce_(t, op=dist.ReduceOp.SUM):
+        if args.backend == 'gloo':                                       # debug path: stage through the host
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+
     def one_step(k):
         pi0 = ops.gather_start(mat_pi0, idx)
         ops.rollout(pi0, T, theta, shift, alpha_scale, w=w, gamma=gamma, seed=2024, first_step=k * T,
                     traj_offset=traj_offset, td=True, G=G, ws=ws, out=bufs)
         if world > 1:
-            dist.all_reduce(G)                                           # one RCCL all-reduce per update
+            all_reduce_(G)                                               # one RCCL all-reduce per update
         sc = 1.0 / (k + 1)
         sa = 1.0 / ((k + 1) * np.log(np.log(k + 20)))                    # mfg_ac2.py:514,522
         ops.apply_update(G, d, lr_c * sc, lr_a * sa, w, theta)
@@ -147,7 +163,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        all_reduce_(te, op=dist.ReduceOp.MAX)
         elapsed = float(te[0])
     theta_end = float(theta[0])
     if not np.isfinite(theta_end):

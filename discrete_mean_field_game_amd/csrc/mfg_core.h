@@ -342,6 +342,10 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
   float* pis = smem + wv * 3 * d;  // current state
   float* pin = pis + d;            // next state
   float* pal = pin + d;            // state for alpha (GIVEN with pi_alpha)
+  // per-row (A_i, D_i, S_i) of this wave's trajectory: psi(A_i) D_i and ln(S_i) D_i are evaluated AFTER the row
+  // loop, one row per lane, instead of once per row by the whole wave (a fp64 digamma + log per row amortised
+  // over only d/64 elements per lane dominated the TD kernels at d = 128)
+  double* rowq = reinterpret_cast<double*>(smem + WAVES * 3 * d + ((WAVES * 3 * d) & 1)) + wv * 3 * d;
   const bool want_v = TD && a.w != nullptr;
   const double theta = *a.theta;
   const ThetaSplit ts = theta_split(theta, a.shift);
@@ -433,14 +437,17 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
         }
         double invS = 1.0;
         if (SAMPLE) {
-          Ssum = wave_sum(Ssum);
+          Ssum = wave_sum_dpp(Ssum);
           invS = 1.0 / Ssum;
         }
         if (TD) {
-          A = wave_sum(A);
-          D = wave_sum(D);
-          guni += digamma_pos(A) * D;
-          if (SAMPLE) guni -= log(Ssum) * D;
+          A = wave_sum_dpp(A);
+          D = wave_sum_dpp(D);
+          if (lane == 0) {
+            rowq[3 * i] = A;
+            rowq[3 * i + 1] = D;
+            rowq[3 * i + 2] = SAMPLE ? Ssum : 1.0;
+          }
         }
 #pragma unroll
         for (int m = 0; m < R; ++m) {
@@ -469,12 +476,19 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
       if (a.reward_kind == MFG_REWARD_EXTERNAL) {
         r = a.reward_in ? (double)a.reward_in[b * T + s] : 0.0;
       } else {
-        r = wave_sum(racc);
+        r = wave_sum_dpp(racc);
         if (a.reward_kind == MFG_REWARD_SYNTHETIC) r *= -0.5;
       }
       if (lane == 0 && a.reward_out) a.reward_out[b * T + s] = (float)r;
       if (TD) {
-        const double gsum = wave_sum(gacc) + guni;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        for (int r = lane; r < d; r += WAVE) {
+          const double Dr = rowq[3 * r + 1];
+          guni = fma(digamma_pos(rowq[3 * r]), Dr, guni);
+          if (SAMPLE) guni -= log(rowq[3 * r + 2]) * Dr;
+        }
+        const double gsum = wave_sum_dpp(gacc + guni);
         if (lane == 0 && a.g) a.g[b * T + s] = gsum;
         if (want_v) {
           __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -519,7 +533,7 @@ template <bool FAST>
 inline int launch_core_large_impl(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st) {
   const int d = a.d;
   const int R = (d + WAVE - 1) / WAVE;
-  const size_t lds = (size_t)WAVES * 3 * d * 4;
+  const size_t lds = (size_t)WAVES * 3 * d * 4 + 8 + (size_t)WAVES * 3 * d * 8;
   const int grid = core_grid(a.B, WAVES, 8, num_cus);
 #define MFG_CORE_LARGE_MODE(RR)                                                                              \
   if (sample && td) hipLaunchKernelGGL((k_core_large<RR, true, true, FAST>), dim3(grid), dim3(BLOCK), lds, st, a);        \

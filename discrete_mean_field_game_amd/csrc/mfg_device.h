@@ -232,6 +232,30 @@ __device__ __forceinline__ float digamma_pos_fast(float x) {
 // ---------------------------------------------------------------------------
 // wave-level reductions
 // ---------------------------------------------------------------------------
+// DPP move of a 64-bit value (two 32-bit DPP movs); lanes outside row_mask / without a source get 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+
+// Wave-wide fp64 sum on the DPP path (no LDS-pipe ds_bpermute): butterfly inside each row of 16 lanes
+// (quad_perm, row_half_mirror, row_mirror), then row_bcast:15 / row_bcast:31 accumulate the four row
+// totals into lane 63, which is broadcast through an SGPR.  Fixed order => deterministic.
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_mov_f64<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov_f64<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov_f64<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_mov_f64<0x140, 0xF>(v);  // row_mirror
+  v += dpp_mov_f64<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_mov_f64<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
