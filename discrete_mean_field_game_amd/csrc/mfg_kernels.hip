@@ -184,6 +184,89 @@ __global__ void k_jsd(const float* __restrict__ p, const float* __restrict__ q, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// f3: backward value recursion of mfg_synthetic (mfg_synthetic.py:768-774) and the two consistency metrics
+// of evaluate_synthetic (:776-790, sum_ij |P_ij - value_ij|) / evaluate_synthetic_JSD (:858-880, sum_i JSD(P_i,
+// implied row i) with entries <= 0 -> 1e-100).  One wavefront per trajectory, lane = row i, reverse-time scan
+// with V^{n+1} in LDS.  Evaluation-only: rows are read strided (L2 resident), fp64 throughout.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_backward_value(const float* __restrict__ P, int64_t B, int T, int d,
+                                                          double* __restrict__ V, double* __restrict__ diff_l1,
+                                                          double* __restrict__ diff_jsd) {
+  extern __shared__ __attribute__((aligned(16))) double smd[];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  double* vn1 = smd + wv * 2 * d;  // V^{n+1}
+  double* vn = vn1 + d;            // V^{n}
+  const int64_t nw = (int64_t)gridDim.x * WAVES;
+  for (int64_t b = (int64_t)blockIdx.x * WAVES + wv; b < B; b += nw) {
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < d; i += WAVE) {
+      vn1[i] = 0.0;
+      V[(b * (T + 1) + T) * d + i] = 0.0;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int n = T - 1; n >= 0; --n) {
+      const float* Pn = P + (b * T + n) * (int64_t)d * d;
+      double sumV = 0.0;
+      for (int i = lane; i < d; i += WAVE) {
+        const float* row = Pn + (int64_t)i * d;
+        double r2 = 0.0, acc = 0.0;
+        for (int j = 0; j < d; ++j) {
+          const double p = (double)row[j];
+          r2 = fma(p, p, r2);
+          acc = fma(p, vn1[j], acc);
+        }
+        const double v = fma(-0.5, r2, acc);
+        vn[i] = v;
+        V[(b * (T + 1) + n) * d + i] = v;
+        sumV += v;
+      }
+      sumV = wave_sum(sumV);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      double l1 = 0.0, js = 0.0;
+      for (int i = lane; i < d; i += WAVE) {
+        const float* row = Pn + (int64_t)i * d;
+        const double vi = vn[i];
+        const double diag = 1.0 - (sumV - (double)d * vi);
+        double sp = 0.0, sq = 0.0;
+        for (int j = 0; j < d; ++j) {
+          const double p = (double)row[j];
+          const double val = (j == i) ? diag : vn[j] - vi;
+          l1 += fabs(p - val);
+          sp += (p <= 0.0) ? 1e-100 : p;
+          sq += (val <= 0.0) ? 1e-100 : val;
+        }
+        if (diff_jsd) {
+          const double sm = 0.5 * (sp + sq);
+          double kl = 0.0;
+          for (int j = 0; j < d; ++j) {
+            double p = (double)row[j];
+            double q = (j == i) ? diag : vn[j] - vi;
+            if (p <= 0.0) p = 1e-100;
+            if (q <= 0.0) q = 1e-100;
+            const double m = 0.5 * (p + q) / sm;
+            const double pn = p / sp, qn = q / sq;
+            kl += pn * log(pn / m) + qn * log(qn / m);
+          }
+          js += 0.5 * kl;
+        }
+      }
+      l1 = wave_sum(l1);
+      if (diff_jsd) js = wave_sum(js);
+      if (lane == 0) {
+        diff_l1[b * T + n] = l1;
+        if (diff_jsd) diff_jsd[b * T + n] = js;
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < d; i += WAVE) vn1[i] = vn[i];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // a5: V(pi) = phi(pi).w, one wavefront per trajectory, lanes own columns c, rows i <= c.
 // w rows are contiguous in k for fixed i, so the loads are coalesced (L2 resident).
 // ---------------------------------------------------------------------------------------------
@@ -889,6 +972,16 @@ int mfg_features(const float* pi, int64_t B, int d, double* phi, mfg_stream_t st
   REQUIRE(pi && phi, "null pointer");
   hipLaunchKernelGGL(k_features, dim3(grid_for(B * d * d, 256, 8)), dim3(256), 0, S(stream), pi, B, d, phi);
   return check_launch("features");
+}
+
+int mfg_backward_value(const float* P, int64_t B, int T, int d, double* V, double* diff_l1, double* diff_jsd,
+                       mfg_stream_t stream) {
+  CHECK_BD();
+  REQUIRE(T >= 1, "T < 1");
+  REQUIRE(P && V && diff_l1, "null pointer");
+  hipLaunchKernelGGL(k_backward_value, dim3(grid_for(B, WAVES, 8)), dim3(BLOCK), (size_t)WAVES * 2 * d * 8, S(stream), P,
+                     B, T, d, V, diff_l1, diff_jsd);
+  return check_launch("backward_value");
 }
 
 int mfg_jsd(const float* p, const float* q, int64_t B, int d, double* out, mfg_stream_t stream) {

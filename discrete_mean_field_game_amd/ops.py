@@ -228,3 +228,15 @@ def reward_net_forward(net, state, action, dropout=None, seed=0, sample_offset=0
         P(net.out.weight), P(net.out.bias), keep, int(seed), int(sample_offset), out.data_ptr(), _stream()),
         'mfg_reward_net_forward')
     return out
+
+
+def backward_value(P_seq, want_jsd=True):
+    """mfg_synthetic backward recursion on actions P_seq [B,T,d,d]: returns V [B,T+1,d], diff_l1 [B,T], diff_jsd [B,T]|None."""
+    _chk_f32(P_seq, 'P_seq')
+    B, T, d, _ = P_seq.shape
+    V = torch.empty(B, T + 1, d, dtype=torch.float64, device=P_seq.device)
+    l1 = torch.empty(B, T, dtype=torch.float64, device=P_seq.device)
+    js = torch.empty(B, T, dtype=torch.float64, device=P_seq.device) if want_jsd else None
+    L.check(L.lib().mfg_backward_value(P_seq.data_ptr(), B, T, d, V.data_ptr(), l1.data_ptr(), _ptr(js), _stream()),
+            'mfg_backward_value')
+    return V, l1, js

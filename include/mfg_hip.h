@@ -159,6 +159,13 @@ int mfg_reward_net_forward(const float* state, const float* action, int64_t B, i
                            const float* fc4_b, const float* out_w, const float* out_b, float keep_prob, uint64_t seed,
                            uint64_t sample_offset, float* reward, mfg_stream_t stream);
 
+/* f3: backward value recursion of the mfg_synthetic variant: V^n = r^n + P^n V^{n+1}, r^n_i = -1/2 ||P^n_i||^2,
+ * V^T = 0 (mfg_synthetic.py:768-774) for P[B,T,d,d] -> V[B,T+1,d] (fp64), plus per (b,n) the consistency
+ * metrics of evaluate_synthetic (diff_l1 = sum_ij |P_ij - value_ij|, :776-790) and, if diff_jsd != NULL, of
+ * evaluate_synthetic_JSD (sum_i JSD(P_i, implied row i), entries <= 0 -> 1e-100, :858-880). */
+int mfg_backward_value(const float* P, int64_t B, int T, int d, double* V, double* diff_l1, double* diff_jsd,
+                       mfg_stream_t stream);
+
 /* a11: out[b] = JSD(p_b, q_b), zeros -> 1e-100, inputs renormalised like scipy.stats.entropy
  * (mfg_ac2.py:546-563).  fp64 out. */
 int mfg_jsd(const float* p, const float* q, int64_t B, int d, double* out, mfg_stream_t stream);

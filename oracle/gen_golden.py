@@ -215,6 +215,38 @@ def part_synthetic(scratch):
     np.savez_compressed(os.path.join(OUT, 'reward_mfg_synthetic.npz'), pi=np.array(pis), P=np.array(Ps),
                         reward=np.array(rs_out), kat_reward=kat)
 
+    # backward value recursion V^n = r + P V^{n+1} and its two consistency metrics
+    # (mfg_synthetic.py:741-812 evaluate_synthetic, :815-899 evaluate_synthetic_JSD)
+    a = mfg_synthetic.actor_critic(theta=2.6, shift=0.0, alpha_scale=10000, d=21)
+    # mfg_synthetic reads cwd/train_normalized/trend_distribution_day%d_reordered.csv (:181, :439)
+    rs2 = np.random.RandomState(5)
+    os.makedirs('train_normalized', exist_ok=True)
+    for day in range(1, 5):
+        np.savetxt('train_normalized/trend_distribution_day%d_reordered.csv' % day, rs2.dirichlet(np.ones(21), size=16),
+                   fmt='%.3e', delimiter=' ')
+    a.init_pi0(path_to_dir=os.getcwd() + '/train_normalized')
+    captured = []
+    orig = a.generate_trajectory
+
+    def hooked(pi0, total_hours, _orig=orig):
+        traj, acts = _orig(pi0, total_hours)
+        captured.append((traj.copy(), acts.copy()))
+        return traj, acts
+    a.generate_trajectory = hooked
+    np.random.seed(77)
+    with quiet():
+        l1_mean, l1_std = a.evaluate_synthetic(day_first=1, day_last=4)
+    acts_l1 = np.array([c[1] for c in captured])
+    captured.clear()
+    np.random.seed(78)
+    with quiet():
+        js_mean, js_std = a.evaluate_synthetic_JSD(day_first=1, day_last=4)
+    acts_js = np.array([c[1] for c in captured])
+    np.savez_compressed(os.path.join(OUT, 'backward_value_mfg_synthetic.npz'), mat_pi0=a.mat_pi0, theta=2.6, shift=0.0,
+                        alpha_scale=10000., actions_l1=acts_l1, l1_mean=l1_mean, l1_std=l1_std,
+                        actions_jsd=acts_js, jsd_mean=js_mean, jsd_std=js_std,
+                        reward_vector=a.calc_reward_vector(acts_l1[0, 0]))
+
 
 # --------------------------------------------------------------------------
 def fake_reward(pi, P):

@@ -219,6 +219,60 @@ def calc_gradient(P, pi, theta, shift, mat_alpha=None, mat_alpha_deriv=None):
 
 
 # --------------------------------------------------------------------------
+# f3: mfg_synthetic backward value recursion and its consistency metrics
+# --------------------------------------------------------------------------
+def calc_reward_vector(P):
+    """v_i = -1/2 ||P_i||^2.  mfg_synthetic.py:726-738."""
+    P = np.asarray(P, dtype=np.float64)
+    return -0.5 * np.sum(P * P, axis=-1)
+
+
+def backward_value(actions):
+    """V^n = r^n + P^n V^{n+1}, V^T = 0, for actions[..., T, d, d] -> V[..., T+1, d].
+    mfg_synthetic.py:768-774 (its mat_V is [d, 16]; here time-major)."""
+    actions = np.asarray(actions, dtype=np.float64)
+    T, d = actions.shape[-3], actions.shape[-1]
+    V = np.zeros(actions.shape[:-3] + (T + 1, d))
+    for n in range(T - 1, -1, -1):
+        V[..., n, :] = calc_reward_vector(actions[..., n, :, :]) + np.einsum('...ij,...j->...i', actions[..., n, :, :],
+                                                                              V[..., n + 1, :])
+    return V
+
+
+def value_implied_rows(V_n):
+    """Row i of the matrix implied by the value function: V_j - V_i off the diagonal,
+    1 - (sum V - d V_i) on it.  mfg_synthetic.py:784-790."""
+    V_n = np.asarray(V_n, dtype=np.float64)
+    d = V_n.shape[-1]
+    M = V_n[..., None, :] - V_n[..., :, None]
+    diag = 1 - (np.sum(V_n, axis=-1, keepdims=True) - d * V_n)
+    idx = np.arange(d)
+    M[..., idx, idx] = diag
+    return M
+
+
+def JSD_synthetic(P, Q):
+    """mfg_synthetic.py:528-547: like JSD but every entry <= 0 becomes 1e-100."""
+    P = np.array(P, dtype=np.float64, copy=True)
+    Q = np.array(Q, dtype=np.float64, copy=True)
+    P[P <= 0] = ZERO_P_REPLACEMENT
+    Q[Q <= 0] = ZERO_P_REPLACEMENT
+    M = 0.5 * (P + Q)
+    return 0.5 * (entropy(P, M, axis=-1) + entropy(Q, M, axis=-1))
+
+
+def evaluate_synthetic_diffs(actions):
+    """Per (trajectory, hour) metrics of evaluate_synthetic (sum_ij |P_ij - value_ij|) and of
+    evaluate_synthetic_JSD (sum_i JSD(P_i, implied row i)).  Returns (V, l1[..., T], jsd[..., T])."""
+    actions = np.asarray(actions, dtype=np.float64)
+    V = backward_value(actions)
+    M = value_implied_rows(V[..., :-1, :])
+    l1 = np.sum(np.abs(actions - M), axis=(-2, -1))
+    jsd = np.sum(JSD_synthetic(actions, M), axis=-1)
+    return V, l1, jsd
+
+
+# --------------------------------------------------------------------------
 # a11: Jensen-Shannon divergence
 # --------------------------------------------------------------------------
 def JSD(P, Q):

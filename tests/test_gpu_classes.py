@@ -291,3 +291,41 @@ def test_reward_net_hip_dropout_statistics(dev):
     assert abs(r1.std() - rt.std()) < 0.05 * rt.std() + 1e-5
     r0 = ops.reward_net_forward(net, s_t[:4].contiguous(), a_t[:4].contiguous(), dropout=False).cpu().numpy()
     assert np.allclose(r0, r0[0])
+
+
+def test_backward_value_kernel_vs_reference_golden(dev):
+    """mfg_synthetic backward recursion V^n = r + P V^{n+1} and the evaluate_synthetic(_JSD) metrics on the
+    actions captured from the unmodified reference (fixture pinned to its returned mean/std)."""
+    from discrete_mean_field_game_amd import ops
+    z = np.load(os.path.join(G, 'backward_value_mfg_synthetic.npz'))
+    for key, mean_k, std_k, pick in (('actions_l1', 'l1_mean', 'l1_std', 1), ('actions_jsd', 'jsd_mean', 'jsd_std', 2)):
+        acts = z[key].astype(np.float32)
+        out = ops.backward_value(torch.as_tensor(acts, device=dev))
+        Vo, l1o, jso = O().evaluate_synthetic_diffs(acts)                 # oracle on identical fp32 inputs
+        assert np.allclose(out[0].cpu().numpy(), Vo, rtol=1e-12, atol=1e-13)
+        assert np.allclose(out[1].cpu().numpy(), l1o, rtol=1e-12)
+        assert np.allclose(out[2].cpu().numpy(), jso, rtol=1e-10)
+        vals = out[pick].cpu().numpy()
+        assert abs(vals.mean() - float(z[mean_k])) < 1e-5 * abs(float(z[mean_k]))     # vs the reference (fp64 actions)
+        assert abs(vals.std() - float(z[std_k])) < 1e-4 * abs(float(z[std_k])) + 1e-9
+
+
+def test_mfg_synthetic_class_surface(dev):
+    from discrete_mean_field_game_amd.mfg_synthetic import actor_critic as SAC
+    z = np.load(os.path.join(G, 'reward_mfg_synthetic.npz'))
+    np.random.seed(0)
+    ac = SAC(theta=2.6, shift=0.0, alpha_scale=10000, d=21, pi0=z['pi'], verbose=0)
+    r = ac.calc_reward(z['P'], z['pi'], 21)
+    assert np.allclose(r, z['reward'], rtol=1e-5)
+    kat = ac.calc_reward(np.array([[1, 3, 3], [4, 5, 6], [7, 8, 9.]]), np.array([.1, .2, .7]), 3)
+    assert abs(kat[0] - float(z['kat_reward'])) < 1e-4 and abs(kat[0] + 76.55) < 1e-4
+    traj, acts = ac.generate_trajectory(z['pi'][0], 16)
+    assert traj.shape == (16, 21) and acts.shape == (15, 21, 21)
+    assert np.allclose(acts[0].T.dot(traj[0]), traj[1], rtol=1e-5, atol=1e-7)
+    assert np.allclose(ac.calc_reward_vector(acts[0]), O().calc_reward_vector(acts[0]), rtol=1e-6)
+    m, s = ac.evaluate_synthetic(day_first=1, day_last=4)
+    mj, sj = ac.evaluate_synthetic_JSD(day_first=1, day_last=4)
+    assert np.isfinite([m, s, mj, sj]).all() and m > 0 and ac.mat_V.shape == (4, 16, 21)
+    assert abs(ac.JSD(np.array([.5, .5, -1.]), np.array([.1, .2, .7])) - O().JSD_synthetic([.5, .5, -1.], [.1, .2, .7])) < 1e-6
+    ac.train(num_episodes=2, constant=1)                                  # synthetic reward inside the fused path
+    assert np.isfinite(float(np.ravel(ac.theta)[0]))

@@ -195,3 +195,14 @@ def test_batched_rollout_matches_sequential_semantics():
     phi = O.calc_features(traj[0, :15])
     assert np.allclose(G_w, (D[0][:, None] * phi).sum(0), rtol=1e-12)
     assert np.isclose(G_theta, float(np.sum(D[0] * Gs[0])), rtol=1e-12)
+
+
+def test_backward_value_recursion_mfg_synthetic():
+    """evaluate_synthetic / evaluate_synthetic_JSD of the reference (mfg_synthetic.py:741-899) on captured actions."""
+    z = load('backward_value_mfg_synthetic.npz')
+    assert np.allclose(O.calc_reward_vector(z['actions_l1'][0, 0]), z['reward_vector'], rtol=1e-14)
+    V, l1, _ = O.evaluate_synthetic_diffs(z['actions_l1'])
+    assert V.shape == (4, 16, 21) and np.all(V[:, 15] == 0)
+    assert np.isclose(l1.mean(), float(z['l1_mean']), rtol=1e-12) and np.isclose(l1.std(), float(z['l1_std']), rtol=1e-12)
+    _, _, jsd = O.evaluate_synthetic_diffs(z['actions_jsd'])
+    assert np.isclose(jsd.mean(), float(z['jsd_mean']), rtol=1e-12) and np.isclose(jsd.std(), float(z['jsd_std']), rtol=1e-12)
