@@ -34,6 +34,7 @@ struct CoreArgs {
   double* g;           // [B,T] or NULL
   float* P_out;        // [B,T,d,d] or NULL
   double* partial;     // [gridDim.x][F+3] per-block gradient sums (D-specialised small kernels) or NULL
+  const float4* htab;  // h(z) cubic table (mixed precision TD), see mfg_device.h
 };
 
 int set_error(int code, const char* msg);  // records mfg_last_error() (defined in mfg_kernels.hip)
@@ -58,6 +59,7 @@ template <bool FAST>
 struct PolicyElem {
   double al_d, ad_d;  // strict mode
   float al_f, ad_f;   // mixed mode
+  float x_f, z_f;     // mixed mode: x = pi_j - pi_i - shift, z = theta x
   GammaState gs;
 };
 
@@ -70,6 +72,8 @@ __device__ __forceinline__ void policy_setup(PolicyElem<FAST>& e, const CoreArgs
     theta_times_x(ts, pj, pi, x, zh, zl);
     softplus_sigmoid_fast(zh, zl, e.al_f, sg);
     e.ad_f = x * sg;
+    e.x_f = x;
+    e.z_f = zh + zl;
     if (SAMPLE) gamma_setup(e.gs, e.al_f * (float)a.alpha_scale);
   } else {
     const double x = (double)pj - (double)pi - a.shift;
@@ -82,13 +86,17 @@ __device__ __forceinline__ void policy_setup(PolicyElem<FAST>& e, const CoreArgs
 
 // Fold one finished element into the row sums / score.  v = gamma variate (SAMPLE) or stored probability.
 template <bool SAMPLE, bool TD, bool FAST>
-__device__ __forceinline__ void policy_accumulate(const PolicyElem<FAST>& e, float v, double& A, double& D, double& gacc) {
+__device__ __forceinline__ void policy_accumulate(const PolicyElem<FAST>& e, const float4* __restrict__ htab, float v,
+                                                  double& A, double& D, double& gacc) {
   if (!TD) return;
   if (FAST) {
     const float lnv = (!SAMPLE && v == 0.0f) ? (float)LOG_ZERO_P : fast_ln(v);
     A += (double)e.al_f;
     D += (double)e.ad_f;
-    gacc = fma((double)(lnv - digamma_pos_fast(e.al_f)), (double)e.ad_f, gacc);
+    // -psi(alpha) alpha' = -x h(z); beyond the table (z > 24, i.e. theta > ~28) fall back to the direct form
+    float psi_ad = e.x_f * htab_eval(htab, e.z_f);
+    if (e.z_f >= HTAB_ZMAX) psi_ad = digamma_pos_fast(e.al_f) * e.ad_f;
+    gacc += (double)fmaf(lnv, e.ad_f, -psi_ad);
   } else {
     const double lnv = (!SAMPLE && v == 0.0f) ? LOG_ZERO_P : log((double)v);
     A += e.al_d;
@@ -208,11 +216,11 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) 
             if (y1 == 0.0f) y1 = ZERO_GAMMA_REPLACEMENT;
             Ssum += (double)y0;
             trow[j] = y0;
-            policy_accumulate<SAMPLE, TD, FAST>(pe, y0, A, D_, gacc);
+            policy_accumulate<SAMPLE, TD, FAST>(pe, a.htab, y0, A, D_, gacc);
             if (has1) {
               Ssum += (double)y1;
               trow[j + 1] = y1;
-              policy_accumulate<SAMPLE, TD, FAST>(pe1, y1, A, D_, gacc);
+              policy_accumulate<SAMPLE, TD, FAST>(pe1, a.htab, y1, A, D_, gacc);
             }
           }
         } else {
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) 
           for (int j = 0; j < d; ++j) {
             policy_setup<SAMPLE, TD, FAST>(pe, a, theta, ts, pav[j], pai);
             const float p = trow[j];
-            policy_accumulate<SAMPLE, TD, FAST>(pe, p, A, D_, gacc);
+            policy_accumulate<SAMPLE, TD, FAST>(pe, a.htab, p, A, D_, gacc);
             racc += reward_term(a.reward_kind, pid, (double)pv[j], (double)p);
           }
         }
@@ -415,11 +423,11 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
               if (y1 == 0.0f) y1 = ZERO_GAMMA_REPLACEMENT;
               y[m] = y0;
               Ssum += (double)y0;
-              policy_accumulate<SAMPLE, TD, FAST>(pe, y0, A, D, gacc);
+              policy_accumulate<SAMPLE, TD, FAST>(pe, a.htab, y0, A, D, gacc);
               if (has1) {
                 if (m + 1 < R) y[m + 1] = y1;
                 Ssum += (double)y1;
-                policy_accumulate<SAMPLE, TD, FAST>(pe1, y1, A, D, gacc);
+                policy_accumulate<SAMPLE, TD, FAST>(pe1, a.htab, y1, A, D, gacc);
               }
             }
           }
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
             if (c < d) {
               policy_setup<SAMPLE, TD, FAST>(pe, a, theta, ts, pad[m], pai);
               y[m] = Pb[(int64_t)i * d + c];
-              policy_accumulate<SAMPLE, TD, FAST>(pe, y[m], A, D, gacc);
+              policy_accumulate<SAMPLE, TD, FAST>(pe, a.htab, y[m], A, D, gacc);
             }
           }
         }

@@ -14,6 +14,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "../../include/mfg_hip.h"
 #include "mfg_core.h"
 
@@ -759,7 +761,48 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
   return check_launch("grad_reduce");
 }
 
-static int launch_core(const CoreArgs& a, bool sample, bool td, int precision, hipStream_t st, int* partial_blocks = nullptr) {
+// ---- h(z) table (mfg_device.h): module-resident, fitted once per device in fp64 -------------------------
+__device__ float4 g_htab[HTAB_N];
+
+__global__ void k_init_htab(float4* __restrict__ tab) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= HTAB_N) return;
+  double y[4];
+  for (int q = 0; q < 4; ++q) {
+    const double z = -(double)HTAB_ZMAX + ((double)k + (double)q / 3.0) / (double)HTAB_PER_UNIT;
+    double sp, sg;
+    softplus_sigmoid(z, sp, sg);
+    y[q] = digamma_pos(sp) * sg;
+  }
+  // cubic through f = 0, 1/3, 2/3, 1 (Newton forward differences, t = 3 f)
+  const double d1 = y[1] - y[0], d2 = y[2] - 2.0 * y[1] + y[0], d3 = y[3] - 3.0 * y[2] + 3.0 * y[1] - y[0];
+  tab[k] = make_float4((float)y[0], (float)(3.0 * (d1 - 0.5 * d2 + d3 / 3.0)), (float)(9.0 * (0.5 * d2 - 0.5 * d3)),
+                       (float)(27.0 * d3 / 6.0));
+}
+
+// Device address of the table; the first call on a device fits it (one launch + one device sync, ever).
+static const float4* htab_ptr() {
+  static std::mutex mu;
+  static const float4* ptr[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ptr[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_htab)) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(k_init_htab, dim3((HTAB_N + 255) / 256), dim3(256), 0, 0, (float4*)p);
+    if (hipDeviceSynchronize() != hipSuccess) return nullptr;
+    ptr[dev] = (const float4*)p;
+  }
+  return ptr[dev];
+}
+
+static int launch_core(const CoreArgs& a_in, bool sample, bool td, int precision, hipStream_t st, int* partial_blocks = nullptr) {
+  CoreArgs a = a_in;
+  if (td && precision == MFG_PRECISION_MIXED) {
+    a.htab = htab_ptr();
+    if (!a.htab) return fail(MFG_ELAUNCH, "%s", "h(z) table initialisation failed");
+  }
   int rc;
   if (partial_blocks) *partial_blocks = 0;
   if (a.d <= WAVE) rc = launch_core_small(a, sample, td, precision == MFG_PRECISION_MIXED, num_cus(), st, partial_blocks);
@@ -775,7 +818,12 @@ static int launch_core(const CoreArgs& a, bool sample, bool td, int precision, h
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 3; }
+int mfg_abi_version(void) { return 4; }
+
+int mfg_init(void) {
+  if (!htab_ptr()) return fail(MFG_ELAUNCH, "%s", "mfg_init: no HIP device / table initialisation failed");
+  return MFG_OK;
+}
 
 int mfg_device_info(int* cu_count_host, char* arch_host, int arch_len) {
   int dev = 0;

@@ -53,6 +53,7 @@ class actor_critic:
         if not torch.cuda.is_available():
             raise L.MfgError('actor_critic needs a ROCm GPU: the HIP hot path has no CPU fallback')
         L.lib()
+        ops.init()
         self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
         self.shift = shift
         self.alpha_scale = alpha_scale

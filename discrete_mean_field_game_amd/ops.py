@@ -30,6 +30,11 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def init():
+    """One-time per-device setup of the HIP library (optional; done lazily otherwise)."""
+    L.check(L.lib().mfg_init(), 'mfg_init')
+
+
 def num_features(d: int) -> int:
     return int(L.lib().mfg_num_features(d))
 

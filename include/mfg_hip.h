@@ -67,6 +67,11 @@ enum {
 const char* mfg_last_error(void);
 int mfg_abi_version(void);
 
+/* One-time per-device setup (fits the 12 KB h(z) = psi(softplus z) sigmoid z table used by the mixed-precision
+ * score, one tiny launch + one device synchronise).  Optional: the first TD call does it lazily; call it
+ * explicitly before capturing launches into a hipGraph. */
+int mfg_init(void);
+
 /* Host-side query: multiprocessor count and gcnArchName of the current device. */
 int mfg_device_info(int* cu_count_host, char* arch_host, int arch_len);
 

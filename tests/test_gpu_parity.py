@@ -358,3 +358,23 @@ def test_error_paths(dev):
     # B = 0 is a no-op
     pn, r = ops().step_given_P(torch.zeros(0, 21, device=dev), torch.zeros(0, 21, 21, device=dev))
     assert pn.shape == (0, 21) and r.shape == (0,)
+
+
+@pytest.mark.parametrize('theta', [0.5, 27.0, 40.0, 60.0])
+def test_score_beyond_the_h_table_and_extreme_theta(dev, theta):
+    """Mixed precision evaluates -psi(alpha) alpha' from the h(z) table for |z| < 24 and falls back to the direct
+    form above it (theta (1 - shift) > 24); both must stay within the 1e-5 bar.  At large theta the reference's
+    own softplus, log(1 + exp(z)) (mfg_ac2.py:228), loses all digits of alpha for z < -36 (measured 3e-4 on g at
+    theta = 40), so the yardstick here is the same formula with log1p."""
+    rs = np.random.RandomState(int(theta))
+    pi, P = rand_case(rs, 64, 21, conc=0.3)
+    shift = 0.16
+    z = theta * (pi.astype(np.float64)[:, None, :] - pi.astype(np.float64)[:, :, None] - shift)
+    ref = O().calc_gradient(P, pi, theta, shift, mat_alpha=np.log1p(np.exp(z)))
+    gm = ops().score(t32(pi, dev), t32(P, dev), t64([theta], dev), shift, precision='mixed').cpu().numpy()
+    gf = ops().score(t32(pi, dev), t32(P, dev), t64([theta], dev), shift, precision='f64').cpu().numpy()
+    assert np.all(np.isfinite(gm)) and np.all(np.isfinite(gf))
+    assert rel(gf, ref, 1e-30) < 1e-9
+    assert rel(gm, ref, 1e-30) < 1e-5
+    if theta < 20:                                            # where the reference formula is still accurate
+        assert rel(gf, O().calc_gradient(P, pi, theta, shift), 1e-30) < 1e-9
