@@ -59,7 +59,7 @@ template <bool FAST>
 struct PolicyElem {
   double al_d, ad_d;  // strict mode
   float al_f, ad_f;   // mixed mode
-  float x_f, z_f;     // mixed mode: x = pi_j - pi_i - shift, z = theta x
+  float x_f;          // mixed mode: x = pi_j - pi_i - shift (z = theta x is recomputed where needed)
   GammaState gs;
 };
 
@@ -72,8 +72,7 @@ __device__ __forceinline__ void policy_setup(PolicyElem<FAST>& e, const CoreArgs
     theta_times_x(ts, pj, pi, x, zh, zl);
     softplus_sigmoid_fast(zh, zl, e.al_f, sg);
     e.ad_f = x * sg;
-    e.x_f = x;
-    e.z_f = zh + zl;
+    if (TD) e.x_f = x;
     if (SAMPLE) gamma_setup(e.gs, e.al_f * (float)a.alpha_scale);
   } else {
     const double x = (double)pj - (double)pi - a.shift;
@@ -86,16 +85,17 @@ __device__ __forceinline__ void policy_setup(PolicyElem<FAST>& e, const CoreArgs
 
 // Fold one finished element into the row sums / score.  v = gamma variate (SAMPLE) or stored probability.
 template <bool SAMPLE, bool TD, bool FAST>
-__device__ __forceinline__ void policy_accumulate(const PolicyElem<FAST>& e, const float4* __restrict__ htab, float v,
-                                                  double& A, double& D, double& gacc) {
+__device__ __forceinline__ void policy_accumulate(const PolicyElem<FAST>& e, const float4* __restrict__ htab, float th,
+                                                  float v, double& A, double& D, double& gacc) {
   if (!TD) return;
   if (FAST) {
     const float lnv = (!SAMPLE && v == 0.0f) ? (float)LOG_ZERO_P : fast_ln(v);
     A += (double)e.al_f;
     D += (double)e.ad_f;
     // -psi(alpha) alpha' = -x h(z); beyond the table (z > 24, i.e. theta > ~28) fall back to the direct form
-    float psi_ad = e.x_f * htab_eval(htab, e.z_f);
-    if (e.z_f >= HTAB_ZMAX) psi_ad = digamma_pos_fast(e.al_f) * e.ad_f;
+    const float z = th * e.x_f;  // fp32 product is ample for a table lookup (|dh/dz| < 1)
+    float psi_ad = e.x_f * htab_eval(htab, z);
+    if (z >= HTAB_ZMAX) psi_ad = digamma_pos_fast(e.al_f) * e.ad_f;
     gacc += (double)fmaf(lnv, e.ad_f, -psi_ad);
   } else {
     const double lnv = (!SAMPLE && v == 0.0f) ? LOG_ZERO_P : log((double)v);
@@ -161,6 +161,22 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) 
     for (int k = lane; k < FO; k += WAVE) gacc_w[k] = 0.0;
   }
   const int kbase = feat_idx(i, i, d);  // k(i,j) = kbase + (j - i)
+  // A wave only ever touches the tile rows / state slots of its OWN G trajectories, so when nothing is staged
+  // or copied out block-wide (SAMPLE without P_out) the per-step barriers need not span the block: waves of a
+  // block then run their serial chains without waiting for the slowest of the four.
+#ifdef MFG_NO_WAVE_LOCAL
+  const bool wave_local = false;
+#else
+  const bool wave_local = SAMPLE && a.P_out == nullptr;
+#endif
+  auto tile_sync = [&]() {
+    if (wave_local) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      __syncthreads();
+    }
+  };
   const int64_t ntiles = (a.B + TB - 1) / TB;
   for (int64_t tileid = blockIdx.x; tileid < ntiles; tileid += gridDim.x) {
     const int64_t b0 = tileid * TB;
@@ -174,7 +190,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) 
     double v_cur = 0.0, discount = 1.0;
     bool have_v = false;
     for (int s = 0; s < T; ++s) {
-      __syncthreads();
+      tile_sync();
       if (valid) pis[tlc * d + i] = pi_i;
       if (!SAMPLE) {
         // stage the given P tile (flat, coalesced) into the padded LDS tile
@@ -190,7 +206,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) 
         if (a.pi_alpha)
           for (int k = tid; k < nb * d; k += BLOCK) pal[k] = a.pi_alpha[b0 * d + k];
       }
-      __syncthreads();
+      tile_sync();
       float* trow = tile + (tlc * d + i) * dp;
       const float* pv = pis + tlc * d;
       const float* pav = (!SAMPLE && a.pi_alpha) ? pal + tlc * d : pv;
@@ -216,11 +232,11 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) 
             if (y1 == 0.0f) y1 = ZERO_GAMMA_REPLACEMENT;
             Ssum += (double)y0;
             trow[j] = y0;
-            policy_accumulate<SAMPLE, TD, FAST>(pe, a.htab, y0, A, D_, gacc);
+            policy_accumulate<SAMPLE, TD, FAST>(pe, a.htab, ts.th, y0, A, D_, gacc);
             if (has1) {
               Ssum += (double)y1;
               trow[j + 1] = y1;
-              policy_accumulate<SAMPLE, TD, FAST>(pe1, a.htab, y1, A, D_, gacc);
+              policy_accumulate<SAMPLE, TD, FAST>(pe1, a.htab, ts.th, y1, A, D_, gacc);
             }
           }
         } else {
@@ -228,7 +244,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) 
           for (int j = 0; j < d; ++j) {
             policy_setup<SAMPLE, TD, FAST>(pe, a, theta, ts, pav[j], pai);
             const float p = trow[j];
-            policy_accumulate<SAMPLE, TD, FAST>(pe, a.htab, p, A, D_, gacc);
+            policy_accumulate<SAMPLE, TD, FAST>(pe, a.htab, ts.th, p, A, D_, gacc);
             racc += reward_term(a.reward_kind, pid, (double)pv[j], (double)p);
           }
         }
@@ -244,7 +260,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) 
         }
         if (TD) gacc = fma(digamma_pos(A), D_, gacc);
       }
-      __syncthreads();
+      tile_sync();
       float pi_n;
       if (SAMPLE) {
         // pi'_i = sum_k pi_k P_ki : column read of the tile (consecutive lanes -> consecutive banks)
@@ -257,12 +273,21 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) 
           // coalesced copy-out of the block's P tile into [B,T,d,d]
           const int n = nb * dd;
           float* dst = a.P_out + (b0 * (int64_t)T) * dd;
-          for (int k = tid; k < n; k += BLOCK) {
-            const int row = (int)(((float)k + 0.5f) * inv_d);  // tl*d + i
-            const int colj = k - row * d;
-            const int tl2 = (int)(((float)row + 0.5f) * inv_d);
-            const int ii = row - tl2 * d;
-            dst[((int64_t)tl2 * T + s) * dd + ii * d + colj] = tile[row * dp + colj];
+          if (dp == d) {
+            // odd d: the tile is unpadded, i.e. [nb][d*d] contiguous -> one division per element
+            const float inv_dd = 1.0f / (float)dd;
+            for (int k = tid; k < n; k += BLOCK) {
+              const int tl2 = (int)(((float)k + 0.5f) * inv_dd);
+              dst[((int64_t)tl2 * T + s) * dd + (k - tl2 * dd)] = tile[k];
+            }
+          } else {
+            for (int k = tid; k < n; k += BLOCK) {
+              const int row = (int)(((float)k + 0.5f) * inv_d);  // tl*d + i
+              const int colj = k - row * d;
+              const int tl2 = (int)(((float)row + 0.5f) * inv_d);
+              const int ii = row - tl2 * d;
+              dst[((int64_t)tl2 * T + s) * dd + ii * d + colj] = tile[row * dp + colj];
+            }
           }
         }
       } else {
@@ -280,16 +305,16 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) 
         const double gsum = seg_sum(gacc, i, d, p2);
         if (valid && i == 0 && a.g) a.g[b * T + s] = gsum;
         if (want_v) {
-          __syncthreads();  // pin complete
+          tile_sync();  // pin complete
           if (!have_v) {
             double col = 0.0;
-            for (int k = 0; k <= i; ++k) col = fma(wl[feat_idx(k, i, d)], (double)pv[k], col);
+            for (int k = 0, idx = i; k <= i; idx += d - k - 1, ++k) col = fma(wl[idx], (double)pv[k], col);
             v_cur = seg_sum(pid * (col + wl[Q + i]), i, d, p2) + wl[Q + d];
             have_v = true;
           }
           const float* pn = pin + tlc * d;
           double col = 0.0;
-          for (int k = 0; k <= i; ++k) col = fma(wl[feat_idx(k, i, d)], (double)pn[k], col);
+          for (int k = 0, idx = i; k <= i; idx += d - k - 1, ++k) col = fma(wl[idx], (double)pn[k], col);
           const double v_next = seg_sum((double)pi_n * (col + wl[Q + i]), i, d, p2) + wl[Q + d];
           const double gd = a.discount_pow ? discount : a.gamma;
           const double del = r + gd * v_next - v_cur;
@@ -423,11 +448,11 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
               if (y1 == 0.0f) y1 = ZERO_GAMMA_REPLACEMENT;
               y[m] = y0;
               Ssum += (double)y0;
-              policy_accumulate<SAMPLE, TD, FAST>(pe, a.htab, y0, A, D, gacc);
+              policy_accumulate<SAMPLE, TD, FAST>(pe, a.htab, ts.th, y0, A, D, gacc);
               if (has1) {
                 if (m + 1 < R) y[m + 1] = y1;
                 Ssum += (double)y1;
-                policy_accumulate<SAMPLE, TD, FAST>(pe1, a.htab, y1, A, D, gacc);
+                policy_accumulate<SAMPLE, TD, FAST>(pe1, a.htab, ts.th, y1, A, D, gacc);
               }
             }
           }
@@ -439,7 +464,7 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
             if (c < d) {
               policy_setup<SAMPLE, TD, FAST>(pe, a, theta, ts, pad[m], pai);
               y[m] = Pb[(int64_t)i * d + c];
-              policy_accumulate<SAMPLE, TD, FAST>(pe, a.htab, y[m], A, D, gacc);
+              policy_accumulate<SAMPLE, TD, FAST>(pe, a.htab, ts.th, y[m], A, D, gacc);
             }
           }
         }
