@@ -172,7 +172,7 @@ class AC_IRL(actor_critic):
                                     precision=self.precision)
                     self._rng_step += 1
                     P = o['P'].view(shard.local_batch, d, d)
-                    pi_next = o['pi_traj'][:, 1].contiguous()
+                    pi_next = o['pi_last']
                 else:
                     P = self._sample(pi, shard.traj_offset, snapshot=False)
                     pi_next, _ = ops.step_given_P(pi, P, want_reward=False)

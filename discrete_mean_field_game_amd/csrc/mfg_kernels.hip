@@ -818,7 +818,7 @@ static int launch_core(const CoreArgs& a_in, bool sample, bool td, int precision
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 4; }
+int mfg_abi_version(void) { return 5; }
 
 int mfg_init(void) {
   if (!htab_ptr()) return fail(MFG_ELAUNCH, "%s", "mfg_init: no HIP device / table initialisation failed");
@@ -1126,8 +1126,8 @@ int mfg_apply_update(const double* G, int d, double lr_critic, double lr_actor, 
 
 int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, double shift, double alpha_scale,
                 const double* w, double gamma, int reward_kind, uint64_t seed, uint32_t first_step, uint64_t traj_offset,
-                int flags, float* pi_traj, float* reward, double* delta, double* g, float* P_out, double* G,
-                int accumulate, void* workspace, size_t workspace_bytes, mfg_stream_t stream) {
+                int flags, float* pi_traj, float* pi_last, float* reward, double* delta, double* g, float* P_out,
+                double* G, int accumulate, void* workspace, size_t workspace_bytes, mfg_stream_t stream) {
   CHECK_BD();
   REQUIRE(T >= 1, "T < 1");
   REQUIRE(pi0 && theta, "null pointer");
@@ -1151,6 +1151,7 @@ int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, 
   a.first_step = first_step;
   a.traj_offset = traj_offset;
   a.pi_traj = pi_traj;
+  a.pi_next_out = pi_last;
   a.reward_out = reward;
   a.delta = delta;
   a.g = g;

@@ -34,11 +34,15 @@ struct RewardNetArgs {
 
 constexpr int RN_BLOCK = 256, RN_WAVES = 4, RN_MAXF2 = 2, RN_MAXN = 32;
 
-// PPMAX = max pixels per lane (ceil(d*d/64))
-template <int PPMAX>
+// PPMAX = max pixels per lane (ceil(d*d/64)).  K1 / K2 / F2 > 0: compile-time conv geometry (the reference always
+// uses k1 = 5, k2 = 3, f2 = 2, ac_irl.py:251-267): taps unroll, LDS reads get immediate offsets and can be issued
+// together; with run-time bounds every tap is a dependent ~100-cycle LDS round trip (the first version of this
+// kernel spent 30 us per sample that way).  0 = generic run-time value.
+template <int PPMAX, int K1, int K2, int F2>
 __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int d = a.d, dd = d * d, k1 = a.k1, k2 = a.k2, f2 = a.f2, n3 = a.n3, n4 = a.n4;
+  const int d = a.d, dd = d * d, n3 = a.n3, n4 = a.n4;
+  const int k1 = K1 ? K1 : a.k1, k2 = K2 ? K2 : a.k2, f2 = F2 ? F2 : a.f2;
   const int h1 = k1 / 2, h2 = k2 / 2;
   const int W1 = d + 2 * h1, W2 = d + 2 * h2;  // padded widths of the input / conv1 maps
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
@@ -70,8 +74,26 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
   }
   if (tid == 0) s_bo[0] = a.bo[0];
   for (int k = tid; k < n3; k += RN_BLOCK) s_b3[k] = a.b3[k];
-  if (a.w3_in_lds)
-    for (int k = tid; k < n3 * f2 * dd; k += RN_BLOCK) s3[k] = a.w3[k];
+  if (a.w3_in_lds) {
+    // batched copy: 4 independent 16-byte loads in flight per thread (a plain loop serialises ~30 round trips)
+    const int n4 = (n3 * f2 * dd) >> 2;
+    const float4* src4 = reinterpret_cast<const float4*>(a.w3);
+    float4* dst4 = reinterpret_cast<float4*>(s3);
+    for (int k0 = 0; k0 < n4; k0 += 4 * RN_BLOCK) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * RN_BLOCK + tid;
+        v[u] = (k < n4) ? src4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * RN_BLOCK + tid;
+        if (k < n4) dst4[k] = v[u];
+      }
+    }
+    for (int k = (n4 << 2) + tid; k < n3 * f2 * dd; k += RN_BLOCK) s3[k] = a.w3[k];
+  }
   for (int k = lane; k < W1 * W1 + W2 * W2; k += WAVE) tin[k] = 0.0f;  // zero halos (interiors are rewritten)
   __syncthreads();
   const float* w3 = a.w3_in_lds ? s3 : a.w3;
@@ -91,8 +113,11 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
     for (int p = lane; p < dd; p += WAVE) {
       const int y = p / d, x = p - y * d;
       float s = sc1[k1 * k1];
-      for (int dy = 0; dy < k1; ++dy)
-        for (int dx = 0; dx < k1; ++dx) s = fmaf(tin[(y + dy) * W1 + x + dx], sc1[dy * k1 + dx], s);
+      const float* tp = tin + y * W1 + x;
+#pragma unroll
+      for (int dy = 0; dy < (K1 ? K1 : k1); ++dy)
+#pragma unroll
+        for (int dx = 0; dx < (K1 ? K1 : k1); ++dx) s = fmaf(tp[dy * W1 + dx], sc1[dy * k1 + dx], s);
       tc1[(y + h2) * W2 + x + h2] = fmaxf(s, 0.0f);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -110,8 +135,11 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
         for (int c = 0; c < RN_MAXF2; ++c) {
           if (c < f2) {
             float s = sc2[f2 * k2 * k2 + c];
-            for (int dy = 0; dy < k2; ++dy)
-              for (int dx = 0; dx < k2; ++dx) s = fmaf(tc1[(y + dy) * W2 + x + dx], sc2[c * k2 * k2 + dy * k2 + dx], s);
+            const float* tp = tc1 + y * W2 + x;
+#pragma unroll
+            for (int dy = 0; dy < (K2 ? K2 : k2); ++dy)
+#pragma unroll
+              for (int dx = 0; dx < (K2 ? K2 : k2); ++dx) s = fmaf(tp[dy * W2 + dx], sc2[c * k2 * k2 + dy * k2 + dx], s);
             act2[q][c] = fmaxf(s, 0.0f);
           }
         }
@@ -119,6 +147,7 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
     }
     // 4. FC3 + ReLU (+ dropout): every lane ends up with all n3 activations it needs for FC4
     float h3_mine = 0.0f;  // lane o < n3 keeps h3[o]
+#pragma unroll 2
     for (int o = 0; o < n3; ++o) {
       const float* wrow = w3 + (int64_t)o * f2 * dd;
       float s = 0.0f;
@@ -185,17 +214,25 @@ extern "C" int mfg_reward_net_forward(const float* state, const float* action, i
   size_t fl = (size_t)(k1 * k1 + 1) + (size_t)(f2 * k2 * k2 + f2) + (size_t)(n4 * (n3 + d) + 2 * n4 + 1 + n3);
   fl = (fl + 3) & ~(size_t)3;
   const size_t w3fl = (size_t)n3 * f2 * dd;
-  a.w3_in_lds = (w3fl * 4 <= 64 * 1024) ? 1 : 0;
+  int64_t grid = (B + RN_WAVES - 1) / RN_WAVES;
+  if (grid > 256 * 3) grid = 256 * 3;
+  // stage the FC3 weights in LDS only when a block amortises the copy over enough samples (and the pointer is
+  // 16-byte aligned); otherwise they are read straight from L2 (coalesced, 28 KB at d = 21)
+  const int64_t samples_per_block = (B + grid - 1) / grid;
+  a.w3_in_lds = (w3fl * 4 <= 64 * 1024 && samples_per_block >= 16 && (((uintptr_t)fc3_w & 15) == 0)) ? 1 : 0;
   if (a.w3_in_lds) fl += w3fl;
   fl = (fl + 3) & ~(size_t)3;
   fl += (size_t)RN_WAVES * (W1 * W1 + W2 * W2);
   const size_t lds = fl * 4;
-  int64_t grid = (B + RN_WAVES - 1) / RN_WAVES;
-  if (grid > 256 * 3) grid = 256 * 3;
   const int pp = (dd + WAVE - 1) / WAVE;
   hipStream_t st = (hipStream_t)stream;
-  if (pp <= 4) hipLaunchKernelGGL((k_reward_net<4>), dim3((unsigned)grid), dim3(RN_BLOCK), lds, st, a);
-  else if (pp <= 7) hipLaunchKernelGGL((k_reward_net<7>), dim3((unsigned)grid), dim3(RN_BLOCK), lds, st, a);
-  else hipLaunchKernelGGL((k_reward_net<16>), dim3((unsigned)grid), dim3(RN_BLOCK), lds, st, a);
+  const bool ref_geom = (k1 == 5 && k2 == 3 && f2 == 2);
+#define RN_LAUNCH(PP)                                                                                              \
+  if (ref_geom) hipLaunchKernelGGL((k_reward_net<PP, 5, 3, 2>), dim3((unsigned)grid), dim3(RN_BLOCK), lds, st, a); \
+  else hipLaunchKernelGGL((k_reward_net<PP, 0, 0, 0>), dim3((unsigned)grid), dim3(RN_BLOCK), lds, st, a);
+  if (pp <= 4) { RN_LAUNCH(4) }
+  else if (pp <= 7) { RN_LAUNCH(7) }
+  else { RN_LAUNCH(16) }
+#undef RN_LAUNCH
   return hipGetLastError() == hipSuccess ? MFG_OK : set_error(MFG_ELAUNCH, "reward_net: launch failed");
 }

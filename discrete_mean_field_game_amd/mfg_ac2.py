@@ -317,7 +317,7 @@ class actor_critic:
                 self._rng_step += T
                 all_reduce_gradients_(G, self.group)
                 ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta, ep_reward[episode:episode + 1])
-                pi = out['pi_traj'][:, T].contiguous()
+                pi = out['pi_last']
                 self._theta_is_array = True
                 if self.trace is not None:
                     self.trace.append(float(self._theta.cpu()[0]))
@@ -329,7 +329,7 @@ class actor_critic:
                                           traj_offset=shard.traj_offset, td=True, G=G, ws=ws, precision=self.precision,
                                           accumulate=(self.update_every == 'rollout' and step > 0))
                         self._rng_step += 1
-                        pi_next = out['pi_traj'][:, 1].contiguous()
+                        pi_next = out['pi_last']
                     else:
                         P = self._sample(pi, shard.traj_offset, snapshot=False)
                         if write_all:

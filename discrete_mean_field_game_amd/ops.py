@@ -166,12 +166,13 @@ def apply_update(G, d, lr_critic, lr_actor, w, theta, reward_acc=None):
 def rollout(pi0, T, theta, shift, alpha_scale, w=None, gamma=1.0, reward_kind=L.REWARD_MFG_AC2, seed=0,
             first_step=0, traj_offset=0, td=True, write_P=False, discount_pow=False, G=None, accumulate=False,
             ws=None, out=None, precision='mixed'):
-    """Fused T-step rollout.  Returns dict(pi_traj, reward, delta, g, P, G)."""
+    """Fused T-step rollout.  Returns dict(pi_traj, pi_last, reward, delta, g, P, G)."""
     _chk_f32(pi0, 'pi0'); _chk_f64(theta, 'theta')
     B, d = pi0.shape
     dev = pi0.device
     o = out or {}
     pi_traj = o.get('pi_traj') if 'pi_traj' in o else torch.empty(B, T + 1, d, dtype=torch.float32, device=dev)
+    pi_last = o.get('pi_last') if 'pi_last' in o else torch.empty(B, d, dtype=torch.float32, device=dev)
     reward = o.get('reward') if 'reward' in o else torch.empty(B, T, dtype=torch.float32, device=dev)
     delta = g = None
     flags = 0
@@ -194,10 +195,11 @@ def rollout(pi0, T, theta, shift, alpha_scale, w=None, gamma=1.0, reward_kind=L.
         flags |= L.ROLLOUT_F64
     L.check(L.lib().mfg_rollout(pi0.data_ptr(), B, d, T, theta.data_ptr(), float(shift), float(alpha_scale),
                                 _ptr(w) if td else None, float(gamma), int(reward_kind), int(seed), int(first_step),
-                                int(traj_offset), flags, pi_traj.data_ptr(), reward.data_ptr(), _ptr(delta), _ptr(g),
+                                int(traj_offset), flags, pi_traj.data_ptr(), _ptr(pi_last), reward.data_ptr(), _ptr(delta),
+                                _ptr(g),
                                 _ptr(P), _ptr(G) if td else None, int(accumulate), _ptr(ws) if td else None,
                                 ws.numel() * 8 if (td and ws is not None) else 0, _stream()), 'mfg_rollout')
-    return {'pi_traj': pi_traj, 'reward': reward, 'delta': delta, 'g': g, 'P': P, 'G': G}
+    return {'pi_traj': pi_traj, 'pi_last': pi_last, 'reward': reward, 'delta': delta, 'g': g, 'P': P, 'G': G}
 
 
 def jsd(p, q):

@@ -142,14 +142,15 @@ int mfg_apply_update(const double* G, int d, double lr_critic, double lr_actor, 
                      double* reward_acc, mfg_stream_t stream);
 
 /* Fused T-step rollout with fixed (theta, w): a1-a5, a7 per step, state kept on chip.
- *   pi_traj[B,T+1,d] fp32 (pi_traj[:,0] = pi0), reward[B,T] fp32, delta[B,T], g[B,T] fp64,
+ *   pi_traj[B,T+1,d] fp32 (pi_traj[:,0] = pi0; may be NULL for env-only rollouts), pi_last[B,d] = final state
+ *   (contiguous, may be NULL), reward[B,T] fp32, delta[B,T], g[B,T] fp64,
  *   P_out[B,T,d,d] fp32 when MFG_ROLLOUT_WRITE_P; G as in mfg_td_pg_accumulate over all B*T
  *   transitions when MFG_ROLLOUT_TD.  first_step offsets the RNG step counter. */
 int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, double shift,
                 double alpha_scale, const double* w, double gamma, int reward_kind, uint64_t seed,
-                uint32_t first_step, uint64_t traj_offset, int flags, float* pi_traj, float* reward,
-                double* delta, double* g, float* P_out, double* G, int accumulate, void* workspace,
-                size_t workspace_bytes, mfg_stream_t stream);
+                uint32_t first_step, uint64_t traj_offset, int flags, float* pi_traj, float* pi_last,
+                float* reward, double* delta, double* g, float* P_out, double* G, int accumulate,
+                void* workspace, size_t workspace_bytes, mfg_stream_t stream);
 
 /* f1 (IRL): reward[b] = r_net(state_b, action_b), the reward network of networks.py:46-81 evaluated for B
  * transitions in one launch (ac_irl.py:683 evaluates it with batch 1 per env step).  fp32.  Weight layouts are
