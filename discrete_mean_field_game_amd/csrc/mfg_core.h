@@ -33,7 +33,7 @@ struct CoreArgs {
   double* delta;       // [B,T] or NULL
   double* g;           // [B,T] or NULL
   float* P_out;        // [B,T,d,d] or NULL
-  double* partial;     // [gridDim.x][F+3] per-block gradient sums (D-specialised small kernels) or NULL
+  double* partial;     // [gridDim.x][F+3] per-block gradient sums (small-d kernels whose LDS rows fit) or NULL
   const float4* htab;  // h(z) cubic table (mixed precision TD), see mfg_device.h
 };
 
@@ -124,10 +124,11 @@ __device__ __forceinline__ double value_wave(const float* pis, const double* __r
 // small d (d <= 64): G = 64/d trajectories per wavefront, lane = (trajectory t, row i).
 // LDS per block: wl[F] (critic weights, fp64), tile[TB][d][dp] (gamma variates, then P), pis / pin / pal [TB][d].
 // ---------------------------------------------------------------------------------------------
-// D > 0: d is a compile-time constant (row loops unroll, the critic-gradient sums are accumulated in
-// registers inside the kernel); D == 0: generic runtime d.
-// The kernel is latency bound (serial Philox / transcendental chains per lane): 4 waves per SIMD are needed
-// to keep the VALU busy, so the mixed-precision build is capped at 128 VGPRs (no spills at that cap).
+// LDS per block additionally holds one fp64 row [F+3] per wavefront for the in-kernel batch sums (when they fit).
+// D > 0: d is a compile-time constant (constant trip counts / strides); D == 0: generic runtime d.
+// PMC: VALU ~94 % busy at 4 waves per SIMD, so the mixed-precision build is capped at 128
+// VGPRs (4 waves/SIMD, matching the 4 blocks/CU that LDS allows); below that occupancy the serial Philox /
+// transcendental chains are not covered (measured 2.9 ms vs 3.4 ms per rollout at 3 vs 2 waves/SIMD).
 template <bool SAMPLE, bool TD, bool FAST, int D>
 __global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

@@ -3,7 +3,7 @@
 //
 // Two work decompositions:
 //   small d (d <= 64): G = 64/d trajectories packed per wavefront; the d x d action matrix of each
-//       trajectory is staged in LDS per wavefront.  HBM-bound step kernel: lane = (trajectory, column j).
+//       trajectory is staged in LDS (per block tile).  HBM-bound step kernel: lane = (trajectory, column j).
 //       Compute-bound sampler / TD kernels: lane = (trajectory, row i) so that all per-row Dirichlet
 //       quantities (row sum of gamma variates, sum_j alpha_ij, ...) stay lane-local.
 //   large d (d > 64): one wavefront per trajectory, lanes own columns, rows are streamed from HBM
