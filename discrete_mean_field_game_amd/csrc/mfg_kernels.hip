@@ -302,7 +302,7 @@ __global__ void k_value(const float* __restrict__ pi, const double* __restrict__
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 #define MFG_STREAM_LOAD(p) __builtin_nontemporal_load(p)
 #ifndef MFG_STEP_WAVES
-#define MFG_STEP_WAVES 6
+#define MFG_STEP_WAVES 7
 #endif
 template <int KIND, int D, int PER>
 __global__ __launch_bounds__(BLOCK, (PER <= 6 ? MFG_STEP_WAVES : 4)) void k_step_small(const float* __restrict__ pi, const float* __restrict__ P,
@@ -311,8 +311,8 @@ __global__ __launch_bounds__(BLOCK, (PER <= 6 ? MFG_STEP_WAVES : 4)) void k_step
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int d = D ? D : d_rt;
   const int G = WAVE / d, TB = WAVES * G, dd = d * d;
-  double2* tQ = reinterpret_cast<double2*>(smem);     // [TB][d] (pi, pi^2) fp64
-  float* tP = reinterpret_cast<float*>(tQ + TB * d);  // [TB][d][d]
+  float* tQ = smem;                  // [TB][d] pi (fp32; widened on the fly: VALU is idle here, LDS bytes are not)
+  float* tP = smem + ((TB * d + 3) & ~3);  // [TB][d][d], 16-byte aligned
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
   const int t = lane / d, j = lane - t * d;
   const int p2 = next_pow2(d);
@@ -344,31 +344,28 @@ __global__ __launch_bounds__(BLOCK, (PER <= 6 ? MFG_STEP_WAVES : 4)) void k_step
       if (k < n4) d4[k] = pre[u];
     }
     for (int k = (n4 << 2) + tid; k < n; k += BLOCK) tP[k] = P[b0 * dd + k];  // ragged last tile only
-    if (tid < nb * d) {
-      const double v = (double)prepi;
-      tQ[tid] = make_double2(v, v * v);
-    }
+    if (tid < nb * d) tQ[tid] = prepi;
     __syncthreads();
     if (tile + gridDim.x < ntiles) MFG_STEP_PREFETCH(tile + gridDim.x)
     const int tl = wv * G + t;
     const bool valid = (t < G) && (tl < nb);
     const int tlc = valid ? tl : 0;
     const float* colp = tP + tlc * dd + j;
-    const double2* qv = tQ + tlc * d;
+    const float* qv = tQ + tlc * d;
     double acc = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll MFG_STEP_UNROLL
     for (int i = 0; i < (D ? D : d); ++i) {
       const double p = (double)colp[i * d];
-      const double2 q = qv[i];
-      acc = fma(p, q.x, acc);
+      const double qx = (double)qv[i];
+      acc = fma(p, qx, acc);
       if (KIND != MFG_REWARD_EXTERNAL) {
         const double pp = p * p;
-        s1 = fma(q.x, pp, s1);
-        if (KIND == MFG_REWARD_MFG_AC2) s2 = fma(q.y, pp, s2);
+        s1 = fma(qx, pp, s1);
+        if (KIND == MFG_REWARD_MFG_AC2) s2 = fma(qx * qx, pp, s2);
       }
     }
     double racc = 0.0;
-    if (KIND == MFG_REWARD_MFG_AC2) racc = fma(qv[j].x, s1, -s2);
+    if (KIND == MFG_REWARD_MFG_AC2) racc = fma((double)qv[j], s1, -s2);
     if (KIND == MFG_REWARD_SYNTHETIC) racc = -0.5 * s1;
     if (KIND != MFG_REWARD_EXTERNAL) racc = seg_sum(racc, j, d, p2);
     if (valid) {
@@ -927,8 +924,10 @@ int mfg_step_given_P(const float* pi, const float* P, int64_t B, int d, int rewa
   hipStream_t st = S(stream);
   if (d <= WAVE) {
     const int G = WAVE / d, TB = WAVES * G;
-    const size_t lds = (size_t)TB * d * d * 4 + (size_t)TB * d * 16;
-    int bpc = (int)((160 * 1024) / (lds + 256));
+    const size_t lds_pre = (size_t)TB * d * d * 4 + (size_t)((TB * d + 3) & ~3) * 4;   // prefetching kernel (fp32 pi)
+    const size_t lds_una = (size_t)TB * d * d * 4 + (size_t)TB * d * 16;               // unaligned fallback (fp64 pi, pi^2)
+    const size_t lds = (((uintptr_t)P & 15) == 0) ? lds_pre : lds_una;
+    int bpc = (int)((160 * 1024) / (lds + 64));
     if (bpc > 8) bpc = 8;
     if (bpc < 1) bpc = 1;
     const int grid = grid_for(B, TB, bpc);
