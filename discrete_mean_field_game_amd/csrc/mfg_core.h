@@ -33,18 +33,13 @@ struct CoreArgs {
   double* delta;       // [B,T] or NULL
   double* g;           // [B,T] or NULL
   float* P_out;        // [B,T,d,d] or NULL
-  double* partial;     // [gridDim.x][F+3] per-block gradient sums (small-d kernels whose LDS rows fit) or NULL
   const float4* htab;  // h(z) cubic table (mixed precision TD), see mfg_device.h
 };
 
 int set_error(int code, const char* msg);  // records mfg_last_error() (defined in mfg_kernels.hip)
 
 // launchers defined in mfg_core_small.hip / mfg_core_large_*.hip; return 0 or MFG_EUNSUPPORTED
-// *partial_blocks = number of per-block partial rows the kernel writes to a.partial (0 = none written)
-int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st,
-                      int* partial_blocks);
-bool core_small_has_inkernel_grad(int d);
-int core_small_max_blocks(int d, bool want_v, int num_cus, int64_t B);
+int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st);
 int launch_core_large_f64(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st);
 int launch_core_large_mixed(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st);
 
@@ -124,7 +119,8 @@ __device__ __forceinline__ double value_wave(const float* pis, const double* __r
 // small d (d <= 64): G = 64/d trajectories per wavefront, lane = (trajectory t, row i).
 // LDS per block: wl[F] (critic weights, fp64), tile[TB][d][dp] (gamma variates, then P), pis / pin / pal [TB][d].
 // ---------------------------------------------------------------------------------------------
-// LDS per block additionally holds one fp64 row [F+3] per wavefront for the in-kernel batch sums (when they fit).
+// (The batch sums sum delta phi are NOT accumulated here: doing it per step in LDS cost 0.49 ms of a 2.5 ms rollout;
+// the separate k_grad_* pass over pi_traj / delta costs ~0.05 ms.)
 // D > 0: d is a compile-time constant (constant trip counts / strides); D == 0: generic runtime d.
 // PMC: VALU ~94 % busy at 4 waves per SIMD, so the mixed-precision build is capped at 128
 // VGPRs (4 waves/SIMD, matching the 4 blocks/CU that LDS allows); below that occupancy the serial Philox /
@@ -151,17 +147,6 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) 
   if (want_v) {
     for (int k = tid; k < F; k += BLOCK) wl[k] = a.w[k];
   }
-  // in-kernel batch sums: one fp64 accumulator row [F+3] per wavefront in LDS (upper triangle of
-  // sum delta pi pi^T, linear, bias, sum delta g, sum r, count); the wave's G lane groups add in turn.
-  const bool grad = want_v && a.partial != nullptr;
-  const int FO = F + 3;
-  const int nfl = TB * d * dp + 3 * TB * d;
-  double* gacc0 = reinterpret_cast<double*>(tile + nfl + (nfl & 1));
-  double* gacc_w = gacc0 + wv * FO;
-  if (grad) {
-    for (int k = lane; k < FO; k += WAVE) gacc_w[k] = 0.0;
-  }
-  const int kbase = feat_idx(i, i, d);  // k(i,j) = kbase + (j - i)
   // A wave only ever touches the tile rows / state slots of its OWN G trajectories, so when nothing is staged
   // or copied out block-wide (SAMPLE without P_out) the per-step barriers need not span the block: waves of a
   // block then run their serial chains without waiting for the slowest of the four.
@@ -320,22 +305,6 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) 
           const double gd = a.discount_pow ? discount : a.gamma;
           const double del = r + gd * v_next - v_cur;
           if (valid && i == 0 && a.delta) a.delta[b * T + s] = del;
-          if (grad) {
-            const double ad_ = del * pid;
-            for (int grp = 0; grp < G; ++grp) {
-              if (valid && t == grp) {
-                for (int j = i; j < d; ++j) gacc_w[kbase + (j - i)] = fma(ad_, (double)pv[j], gacc_w[kbase + (j - i)]);
-                gacc_w[Q + i] += ad_;
-                if (i == 0) {
-                  gacc_w[Q + d] += del;
-                  gacc_w[Q + d + 1] = fma(del, gsum, gacc_w[Q + d + 1]);
-                  gacc_w[Q + d + 2] += r;
-                  gacc_w[Q + d + 3] += 1.0;
-                }
-              }
-              __builtin_amdgcn_wave_barrier();
-            }
-          }
           v_cur = v_next;
           discount *= a.gamma;
         }
@@ -345,24 +314,14 @@ __global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) 
     }
     if (valid && a.pi_next_out) a.pi_next_out[b * d + i] = pi_i;
   }
-  if (grad) {
-    // fixed-order sum of the block's 4 wavefront rows -> one partial row per block
-    __syncthreads();
-    const double* g0 = gacc0;
-    double* out = a.partial + (int64_t)blockIdx.x * FO;
-    for (int k = tid; k < FO; k += BLOCK) out[k] = ((g0[k] + g0[FO + k]) + g0[2 * FO + k]) + g0[3 * FO + k];
-  }
 }
 
-inline size_t core_small_lds(int d, bool want_v, bool grad) {
+inline size_t core_small_lds(int d, bool want_v) {
   const int G = WAVE / d, TB = WAVES * G, dp = d | 1;
   const size_t F = (size_t)d * (d + 1) / 2 + d + 1;
-  size_t fl = (size_t)TB * d * dp + 3 * (size_t)TB * d;  // floats: tile, pis, pin, pal
-  fl += fl & 1;                                          // keep the fp64 accumulator rows 8-byte aligned
-  return (want_v ? F * 8 : 0) + fl * 4 + (grad ? (size_t)WAVES * (F + 3) * 8 : 0);
+  const size_t fl = (size_t)TB * d * dp + 3 * (size_t)TB * d;  // floats: tile, pis, pin, pal
+  return (want_v ? F * 8 : 0) + fl * 4;
 }
-// in-kernel gradient sums are used while the block still fits 2x per CU
-inline bool core_small_grad_fits(int d) { return core_small_lds(d, true, true) <= 72 * 1024; }
 
 // ---------------------------------------------------------------------------------------------
 // large d (d > 64): one wavefront per trajectory, lane owns columns c = lane + 64 m (m < R).

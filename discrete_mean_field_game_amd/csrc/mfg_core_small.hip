@@ -22,8 +22,6 @@ static void dispatch(const CoreArgs& a, bool sample, bool td, bool fast, int gri
   }
 }
 
-bool core_small_has_inkernel_grad(int d) { return core_small_grad_fits(d); }
-
 static int blocks_for(size_t lds, int d, int num_cus, int64_t B) {
   const int G = WAVE / d, TB = WAVES * G;
   int bpc = (int)((160 * 1024) / (lds + 256));
@@ -32,22 +30,11 @@ static int blocks_for(size_t lds, int d, int num_cus, int64_t B) {
   return core_grid(B, TB, bpc, num_cus);
 }
 
-int core_small_max_blocks(int d, bool want_v, int num_cus, int64_t B) {
-  // upper bound over the with / without in-kernel-gradient LDS footprints
-  const int a = blocks_for(core_small_lds(d, want_v, false), d, num_cus, B);
-  const int b = blocks_for(core_small_lds(d, want_v, want_v && core_small_grad_fits(d)), d, num_cus, B);
-  return a > b ? a : b;
-}
-
-int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st,
-                      int* partial_blocks) {
+int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st) {
   const int d = a.d;
   const bool want_v = td && a.w != nullptr;
-  const bool grad = want_v && a.partial != nullptr;
-  if (grad && !core_small_grad_fits(d)) return MFG_EINVAL;  // caller must not request it (API checks)
-  const size_t lds = core_small_lds(d, want_v, grad);
+  const size_t lds = core_small_lds(d, want_v);
   const int grid = blocks_for(lds, d, num_cus, a.B);
-  if (partial_blocks) *partial_blocks = grad ? grid : 0;
   if (d == 21) dispatch<21>(a, sample, td, fast, grid, lds, st);
   else if (d == 15) dispatch<15>(a, sample, td, fast, grid, lds, st);
   else dispatch<0>(a, sample, td, fast, grid, lds, st);

@@ -688,6 +688,75 @@ __global__ __launch_bounds__(BLOCK) void k_grad_partial(GradArgs a) {
   }
 }
 
+// Compile-time-d version for the packed sizes (d = 21, 15): lane = (sample slot g, row i), G = 64/D samples per
+// wave iteration.  Each lane keeps row i of  M = sum_n delta_n pi_n pi_n^T  in D fp64 registers; pi_n is broadcast
+// to the lanes of its slot through a per-wave LDS line.  ~70 instructions per 3 samples (the generic kernel above
+// needs 3 LDS reads per FMA).  Partial rows are combined in a fixed order (deterministic).
+template <int D>
+__global__ __launch_bounds__(BLOCK) void k_grad_small(GradArgs a) {
+  constexpr int G = WAVE / D, Q = D * (D + 1) / 2, F = Q + D + 1, FO = F + 3;
+  __shared__ float line[WAVES][G * D];
+  __shared__ double red[D * D + D + 4];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  const int g = lane / D, i = lane - g * D;
+  const bool act = g < G;
+  double acc[D], lin = 0.0, s_d = 0.0, s_dg = 0.0, s_r = 0.0, s_n = 0.0;
+#pragma unroll
+  for (int j = 0; j < D; ++j) acc[j] = 0.0;
+  const double invT = 1.0 / (double)a.T;
+  const int64_t stride = (int64_t)gridDim.x * WAVES * G;
+  for (int64_t n0 = ((int64_t)blockIdx.x * WAVES + wv) * G; n0 < a.N; n0 += stride) {
+    const int64_t n = n0 + g;
+    const bool ok = act && n < a.N;
+    float pin = 0.0f;
+    double de = 0.0;
+    if (ok) {
+      const int64_t b = (int64_t)(((double)n + 0.5) * invT);
+      const int sidx = (int)(n - b * a.T);
+      pin = a.pi[b * a.stride_b + (int64_t)sidx * D + i];
+      de = a.delta[n];
+      if (i == 0) {
+        s_d += de;
+        if (a.g) s_dg = fma(de, a.g[n], s_dg);
+        if (a.reward) s_r += (double)a.reward[n];
+        s_n += 1.0;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (act) line[wv][lane] = pin;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const double ad = de * (double)pin;
+    const float* lp = line[wv] + (act ? g * D : 0);
+#pragma unroll
+    for (int j = 0; j < D; ++j) acc[j] = fma(ad, (double)lp[j], acc[j]);
+    lin += ad;
+  }
+  // block reduction in a fixed (wave, slot) order
+  for (int grp = 0; grp < WAVES * G; ++grp) {
+    __syncthreads();
+    if (act && wv * G + g == grp) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) red[i * D + j] = (grp == 0 ? 0.0 : red[i * D + j]) + acc[j];
+      red[D * D + i] = (grp == 0 ? 0.0 : red[D * D + i]) + lin;
+      if (i == 0) {
+        red[D * D + D + 0] = (grp == 0 ? 0.0 : red[D * D + D + 0]) + s_d;
+        red[D * D + D + 1] = (grp == 0 ? 0.0 : red[D * D + D + 1]) + s_dg;
+        red[D * D + D + 2] = (grp == 0 ? 0.0 : red[D * D + D + 2]) + s_r;
+        red[D * D + D + 3] = (grp == 0 ? 0.0 : red[D * D + D + 3]) + s_n;
+      }
+    }
+  }
+  __syncthreads();
+  double* out = a.partial + (int64_t)blockIdx.x * FO;
+  for (int k = tid; k < D * D; k += BLOCK) {
+    const int r_ = k / D, c_ = k - r_ * D;
+    if (c_ >= r_) out[feat_idx(r_, c_, D)] = red[k];  // M is symmetric; feature (r,c), r <= c, is M[r][c]
+  }
+  for (int k = tid; k < D; k += BLOCK) out[Q + k] = red[D * D + k];
+  if (tid < 4) out[Q + D + tid] = red[D * D + D + tid];
+}
+
 // Sum nsb partial rows in a fixed order: block = 16 slices (waves) x 64 outputs (lanes, coalesced);
 // slice s adds rows s, s+16, ... ; the 16 slice sums are combined in slice order through LDS.
 constexpr int RP_SLICES = 16;
@@ -755,6 +824,19 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
   if (ws_bytes < (size_t)(nsb * FO * 8)) return fail(MFG_EWORKSPACE, "%s: need %lld bytes, have %lld", "workspace",
                                                      (long long)(nsb * FO * 8), (long long)ws_bytes);
   GradArgs a{pi, stride_b, delta, g, reward, N, T, d, chunk, nsb, (double*)ws};
+  if (d == 21 || d == 15) {
+    // one partial row per block; nsb rows fit the workspace by construction (grad_geometry)
+    const int per = WAVE / d;
+    int64_t blocks = (N + (int64_t)WAVES * per * 8 - 1) / ((int64_t)WAVES * per * 8);  // >= 8 iterations per wave
+    if (blocks > nsb) blocks = nsb;
+    if (blocks < 1) blocks = 1;
+    a.nsb = blocks;
+    if (d == 21) hipLaunchKernelGGL((k_grad_small<21>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((k_grad_small<15>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
+                       (const double*)ws, blocks, FO, accumulate, G);
+    return check_launch("grad_small");
+  }
   const size_t lds = (size_t)chunk * 3 * 8 + (size_t)chunk * d * 4;
   hipLaunchKernelGGL(k_grad_partial, dim3((unsigned)nsb, (unsigned)nob), dim3(BLOCK), lds, st, a);
   hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
@@ -798,15 +880,14 @@ static const float4* htab_ptr() {
   return ptr[dev];
 }
 
-static int launch_core(const CoreArgs& a_in, bool sample, bool td, int precision, hipStream_t st, int* partial_blocks = nullptr) {
+static int launch_core(const CoreArgs& a_in, bool sample, bool td, int precision, hipStream_t st) {
   CoreArgs a = a_in;
   if (td && precision == MFG_PRECISION_MIXED) {
     a.htab = htab_ptr();
     if (!a.htab) return fail(MFG_ELAUNCH, "%s", "h(z) table initialisation failed");
   }
   int rc;
-  if (partial_blocks) *partial_blocks = 0;
-  if (a.d <= WAVE) rc = launch_core_small(a, sample, td, precision == MFG_PRECISION_MIXED, num_cus(), st, partial_blocks);
+  if (a.d <= WAVE) rc = launch_core_small(a, sample, td, precision == MFG_PRECISION_MIXED, num_cus(), st);
   else if (precision == MFG_PRECISION_MIXED) rc = launch_core_large_mixed(a, sample, td, num_cus(), st);
   else rc = launch_core_large_f64(a, sample, td, num_cus(), st);
   if (rc != MFG_OK) return fail(rc, "%s: d=%lld > %lld", "core", (long long)a.d, (long long)MFG_MAX_D);
@@ -855,26 +936,7 @@ size_t mfg_workspace_bytes(int64_t N, int d) {
   int chunk, nob;
   int64_t nsb;
   grad_geometry(N, d, &chunk, &nsb, &nob);
-  int64_t rows = nsb;
-  if (d <= WAVE && core_small_has_inkernel_grad(d)) {
-    const int64_t blocks = core_small_max_blocks(d, true, num_cus(), N);
-    if (blocks > rows) rows = blocks;
-  }
-  return (size_t)(rows * (mfg_num_features(d) + 3) * 8);
-}
-
-// Per-block partial rows written by a D-specialised core kernel -> G
-static int reduce_core_partials(const void* ws, int blocks, int d, double* G, int accumulate, hipStream_t st) {
-  const int64_t FO = mfg_num_features(d) + 3;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
-                     (const double*)ws, (int64_t)blocks, FO, accumulate, G);
-  return check_launch("reduce_core_partials");
-}
-
-static bool inkernel_grad_ok(int d, int64_t B, void* ws, size_t ws_bytes) {
-  if (d > WAVE || !core_small_has_inkernel_grad(d) || !ws) return false;
-  const int64_t blocks = core_small_max_blocks(d, true, num_cus(), B);
-  return ws_bytes >= (size_t)(blocks * (mfg_num_features(d) + 3) * 8);
+  return (size_t)(nsb * (mfg_num_features(d) + 3) * 8);
 }
 
 #define CHECK_BD()                                        \
@@ -1109,12 +1171,9 @@ int mfg_td_pg_accumulate(const float* pi, const float* pi_next, const float* P, 
   a.reward_kind = MFG_REWARD_EXTERNAL;
   a.delta = delta;
   a.g = g;
-  if (G && inkernel_grad_ok(d, B, workspace, workspace_bytes)) a.partial = (double*)workspace;
-  int pblocks = 0;
-  int rc = launch_core(a, false, true, precision, S(stream), &pblocks);
+  int rc = launch_core(a, false, true, precision, S(stream));
   if (rc != MFG_OK || !G) return rc;
   REQUIRE(workspace, "workspace is null");
-  if (pblocks > 0) return reduce_core_partials(workspace, pblocks, d, G, accumulate, S(stream));
   return launch_grad(pi, d, delta, g, reward, B, 1, d, G, accumulate, workspace, workspace_bytes, S(stream));
 }
 
@@ -1160,12 +1219,9 @@ int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, 
   a.g = g;
   a.P_out = (flags & MFG_ROLLOUT_WRITE_P) ? P_out : nullptr;
   const int precision = (flags & MFG_ROLLOUT_F64) ? MFG_PRECISION_F64 : MFG_PRECISION_MIXED;
-  if (td && G && inkernel_grad_ok(d, B, workspace, workspace_bytes)) a.partial = (double*)workspace;
-  int pblocks = 0;
-  int rc = launch_core(a, true, td, precision, S(stream), &pblocks);
+  int rc = launch_core(a, true, td, precision, S(stream));
   if (rc != MFG_OK || !td || !G) return rc;
   REQUIRE(workspace, "workspace is null");
-  if (pblocks > 0) return reduce_core_partials(workspace, pblocks, d, G, accumulate, S(stream));
   return launch_grad(pi_traj, (int64_t)(T + 1) * d, delta, g, reward, B * T, T, d, G, accumulate, workspace,
                      workspace_bytes, S(stream));
 }
