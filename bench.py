@@ -110,6 +110,29 @@ def pmc_traffic(kernel_prefix, d, T, B):
     return None, None
 
 
+def pmc_sq(kernel_prefix, d, T, B):
+    """VALU-busy fraction of the fused kernel from the newest committed SQ counter summary
+    (profiles/rNN_pmc_sq.json, written by tools/summarize_sq.py) taken at this shape."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_sq.json')), reverse=True):
+        try:
+            z = json.load(open(path))
+        except Exception:
+            continue
+        sh = z.get('shape', {})
+        if (sh.get('d'), sh.get('T'), sh.get('B')) != (d, T, B):
+            continue
+        best = None
+        for name, e in z.get('kernels', {}).items():
+            if name.replace('mfg::', '').startswith(kernel_prefix) and 'valu_busy' in e:
+                if best is None or e.get('dur_us_under_pmc', 0) > best[1].get('dur_us_under_pmc', 0):
+                    best = (name, e)
+        if best:
+            return {'valu_busy': best[1]['valu_busy'], 'valu_insts_per_wave': best[1].get('valu_insts_per_wave'),
+                    'pmc_source': os.path.basename(path)}
+    return {}
+
+
 def main():
     args = parse()
     import numpy as np
@@ -243,9 +266,10 @@ def main():
             del xx, yy
             t_f = event_time(lambda: ops.rollout(pi0, T, theta, shift, alpha_scale, w=w, gamma=gamma, seed=7,
                                                  traj_offset=traj_offset, td=True, G=G, ws=ws, out=bufs), n=5, warm=1)
-            fused = {'kernel': 'k_core_small<SAMPLE,TD,MIXED> (+ in-kernel batch sums)' if d <= 64 else 'k_core_large<SAMPLE,TD,MIXED>+grad',
+            fused = {'kernel': ('k_core_small' if d <= 64 else 'k_core_large') + '<SAMPLE,TD,MIXED> + k_grad + k_reduce_partials',
                      'bound': 'valu/transcendental+rng (P stays on chip)', 'avg_launch_ms': t_f * 1e3,
                      'env_steps_per_s': B * T / t_f, 'hbm_algorithmic_GBs': B * T * bytes_per_step / t_f / 1e9}
+            fused.update(pmc_sq('k_core_', d, T, B))
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(d, args.cpu_seconds)

@@ -692,10 +692,29 @@ __global__ __launch_bounds__(BLOCK) void k_grad_partial(GradArgs a) {
 // wave iteration.  Each lane keeps row i of  M = sum_n delta_n pi_n pi_n^T  in D fp64 registers; pi_n is broadcast
 // to the lanes of its slot through a per-wave LDS line.  ~70 instructions per 3 samples (the generic kernel above
 // needs 3 LDS reads per FMA).  Partial rows are combined in a fixed order (deterministic).
+struct GradSample {
+  float pin;         // pi_n[i]
+  double de, dg, rr; // delta_n, g_n, reward_n (0 when the lane holds no sample)
+};
+
+template <int D>
+__device__ __forceinline__ GradSample grad_load(const GradArgs& a, int64_t n, int i, bool act, double invT) {
+  GradSample s{0.0f, 0.0, 0.0, 0.0};
+  if (act && n < a.N) {
+    const int64_t b = (int64_t)(((double)n + 0.5) * invT);
+    const int sidx = (int)(n - b * a.T);
+    s.pin = a.pi[b * a.stride_b + (int64_t)sidx * D + i];
+    s.de = a.delta[n];
+    if (a.g) s.dg = a.g[n];
+    if (a.reward) s.rr = (double)a.reward[n];
+  }
+  return s;
+}
+
 template <int D>
 __global__ __launch_bounds__(BLOCK) void k_grad_small(GradArgs a) {
   constexpr int G = WAVE / D, Q = D * (D + 1) / 2, F = Q + D + 1, FO = F + 3;
-  __shared__ float line[WAVES][G * D];
+  __shared__ double line[WAVES][2][G * D];  // fp64 so the inner loop is one LDS read + one FMA per product
   __shared__ double red[D * D + D + 4];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
   const int g = lane / D, i = lane - g * D;
@@ -704,33 +723,34 @@ __global__ __launch_bounds__(BLOCK) void k_grad_small(GradArgs a) {
 #pragma unroll
   for (int j = 0; j < D; ++j) acc[j] = 0.0;
   const double invT = 1.0 / (double)a.T;
-  const int64_t stride = (int64_t)gridDim.x * WAVES * G;
-  for (int64_t n0 = ((int64_t)blockIdx.x * WAVES + wv) * G; n0 < a.N; n0 += stride) {
-    const int64_t n = n0 + g;
-    const bool ok = act && n < a.N;
-    float pin = 0.0f;
-    double de = 0.0;
-    if (ok) {
-      const int64_t b = (int64_t)(((double)n + 0.5) * invT);
-      const int sidx = (int)(n - b * a.T);
-      pin = a.pi[b * a.stride_b + (int64_t)sidx * D + i];
-      de = a.delta[n];
-      if (i == 0) {
-        s_d += de;
-        if (a.g) s_dg = fma(de, a.g[n], s_dg);
-        if (a.reward) s_r += (double)a.reward[n];
-        s_n += 1.0;
-      }
+  // two sample groups per iteration, the next iteration's loads issued before this one's FMAs
+  const int64_t stride = (int64_t)gridDim.x * WAVES * G * 2;
+  int64_t n0 = ((int64_t)blockIdx.x * WAVES + wv) * G * 2;
+  GradSample c0 = grad_load<D>(a, n0 + g, i, act, invT), c1 = grad_load<D>(a, n0 + G + g, i, act, invT);
+  const double* lp0 = line[wv][0] + (act ? g * D : 0);
+  const double* lp1 = line[wv][1] + (act ? g * D : 0);
+  for (; n0 < a.N; n0 += stride) {
+    const GradSample x0 = grad_load<D>(a, n0 + stride + g, i, act, invT);
+    const GradSample x1 = grad_load<D>(a, n0 + stride + G + g, i, act, invT);
+    __builtin_amdgcn_wave_barrier();
+    if (act) {
+      line[wv][0][lane] = (double)c0.pin;
+      line[wv][1][lane] = (double)c1.pin;
     }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only: the prefetched global loads stay in flight
     __builtin_amdgcn_wave_barrier();
-    if (act) line[wv][lane] = pin;
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    const double ad = de * (double)pin;
-    const float* lp = line[wv] + (act ? g * D : 0);
+    if (i == 0) {
+      s_d += c0.de + c1.de;
+      s_dg = fma(c0.de, c0.dg, fma(c1.de, c1.dg, s_dg));
+      s_r += c0.rr + c1.rr;
+      s_n += ((act && n0 + g < a.N) ? 1.0 : 0.0) + ((act && n0 + G + g < a.N) ? 1.0 : 0.0);
+    }
+    const double ad0 = c0.de * (double)c0.pin, ad1 = c1.de * (double)c1.pin;
 #pragma unroll
-    for (int j = 0; j < D; ++j) acc[j] = fma(ad, (double)lp[j], acc[j]);
-    lin += ad;
+    for (int j = 0; j < D; ++j) acc[j] = fma(ad0, lp0[j], fma(ad1, lp1[j], acc[j]));
+    lin += ad0 + ad1;
+    c0 = x0;
+    c1 = x1;
   }
   // block reduction in a fixed (wave, slot) order
   for (int grp = 0; grp < WAVES * G; ++grp) {
@@ -827,7 +847,7 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
   if (d == 21 || d == 15) {
     // one partial row per block; nsb rows fit the workspace by construction (grad_geometry)
     const int per = WAVE / d;
-    int64_t blocks = (N + (int64_t)WAVES * per * 8 - 1) / ((int64_t)WAVES * per * 8);  // >= 8 iterations per wave
+    int64_t blocks = (N + (int64_t)WAVES * per * 16 - 1) / ((int64_t)WAVES * per * 16);  // >= 8 iterations (2 groups each) per wave
     if (blocks > nsb) blocks = nsb;
     if (blocks < 1) blocks = 1;
     a.nsb = blocks;

@@ -1,0 +1,50 @@
+"""Turn the two rocprofv3 --pmc SQ passes of tools/profile_round.sh into a per-kernel issue summary.
+
+SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles (MI355X_MICROARCH.md, PMC units table), summed over
+all SIMDs of the device; GRBM_GUI_ACTIVE counts shader cycles, summed over the 8 XCDs.  Derived:
+  valu_busy = 4 * SQ_ACTIVE_INST_VALU / (n_simd * GRBM_GUI_ACTIVE / n_xcd)      (rocprof's VALUBusy definition)
+  valu_insts_per_wave = SQ_INSTS_VALU / SQ_WAVES
+usage: summarize_sq.py <pass1_csv> <pass2_csv> <round_tag> <d,T,B> [kernel-substring ...]
+"""
+import csv, json, sys
+
+p1, p2, tag, shape = sys.argv[1:5]
+want = sys.argv[5:] or ['k_core_', 'k_grad_', 'k_step_']
+d, T, B = (int(x) for x in shape.split(','))
+N_SIMD, N_XCD = 1024, 8
+
+
+def collect(path):
+    acc, meta = {}, {}
+    for r in csv.DictReader(open(path)):
+        name = r['Kernel_Name'].split('(')[0].replace('void ', '')
+        if not any(w in name for w in want):
+            continue
+        acc.setdefault(name, {}).setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+        m = meta.setdefault(name, {'vgpr': r.get('VGPR_Count'), 'lds_block_bytes': r.get('LDS_Block_Size'),
+                                   'grid': r.get('Grid_Size'), 'workgroup': r.get('Workgroup_Size'), 'dur_us': []})
+        m['dur_us'].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    return acc, meta
+
+
+out = {'round': tag, 'shape': {'d': d, 'T': T, 'B': B}, 'units': 'SQ_* in quad-cycles or instructions, device totals per launch',
+       'kernels': {}}
+for path in (p1, p2):
+    acc, meta = collect(path)
+    for k, c in acc.items():
+        e = out['kernels'].setdefault(k, {'counters': {}})
+        for cn, v in c.items():
+            e['counters'][cn] = sum(v) / len(v)
+        m = meta[k]
+        e.update(vgpr=m['vgpr'], lds_block_bytes=m['lds_block_bytes'], grid=m['grid'], workgroup=m['workgroup'],
+                 dur_us_under_pmc=sum(m['dur_us']) / len(m['dur_us']))
+for k, e in out['kernels'].items():
+    c = e['counters']
+    if 'SQ_ACTIVE_INST_VALU' in c and c.get('GRBM_GUI_ACTIVE'):
+        e['valu_busy'] = 4.0 * c['SQ_ACTIVE_INST_VALU'] / (N_SIMD * c['GRBM_GUI_ACTIVE'] / N_XCD)
+    if 'SQ_INSTS_VALU' in c and c.get('SQ_WAVES'):
+        e['valu_insts_per_wave'] = c['SQ_INSTS_VALU'] / c['SQ_WAVES']
+        e['lds_insts_per_wave'] = c.get('SQ_INSTS_LDS', 0.0) / c['SQ_WAVES']
+    if 'SQ_WAIT_INST_ANY' in c and c.get('SQ_WAVE_CYCLES'):
+        e['wait_inst_any_frac_of_wave_cycles'] = c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']
+json.dump(out, sys.stdout, indent=1)
