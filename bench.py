@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
                     help="collective backend; 'gloo' (+ --share-gpu) only exists to smoke-test the N>1 path on a 1-GPU box")
     ap.add_argument('--share-gpu', action='store_true', help='debug: all ranks use GPU 0')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='debug: take the process-group / all-reduce path even with one rank (RCCL smoke test on a 1-GPU box)')
     return ap.parse_args()
 
 
@@ -152,8 +154,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
         if args.backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         else:
@@ -192,7 +196,7 @@ def main():
         pi0 = ops.gather_start(mat_pi0, idx)
         ops.rollout(pi0, T, theta, shift, alpha_scale, w=w, gamma=gamma, seed=2024, first_step=k * T,
                     traj_offset=traj_offset, td=True, G=G, ws=ws, out=bufs)
-        if world > 1:
+        if multi:
             all_reduce_(G)                                               # one RCCL all-reduce per update
         sc = 1.0 / (k + 1)
         sa = 1.0 / ((k + 1) * np.log(np.log(k + 20)))                    # mfg_ac2.py:514,522
@@ -200,7 +204,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -212,7 +216,7 @@ def main():
         one_step(k)
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         all_reduce_(te, op=dist.ReduceOp.MAX)
         elapsed = float(te[0])
@@ -287,7 +291,7 @@ def main():
             'roofline': roofline, 'fused_kernel': fused, 'cpu_baseline': cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libmfg_hip.so')
+LIB_PATH = os.environ.get('MFG_HIP_LIB') or os.path.join(CSRC, 'libmfg_hip.so')   # MFG_HIP_LIB: alternative build
 
 MFG_MAX_D = 512
 REWARD_MFG_AC2, REWARD_SYNTHETIC, REWARD_EXTERNAL = 0, 1, 2

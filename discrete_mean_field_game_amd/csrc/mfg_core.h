@@ -125,8 +125,11 @@ __device__ __forceinline__ double value_wave(const float* pis, const double* __r
 // PMC: VALU ~94 % busy at 4 waves per SIMD, so the mixed-precision build is capped at 128
 // VGPRs (4 waves/SIMD, matching the 4 blocks/CU that LDS allows); below that occupancy the serial Philox /
 // transcendental chains are not covered (measured 2.9 ms vs 3.4 ms per rollout at 3 vs 2 waves/SIMD).
+#ifndef MFG_CORE_SMALL_WAVES
+#define MFG_CORE_SMALL_WAVES 4  // waves per SIMD the mixed-precision kernel is register-capped for (128 VGPRs)
+#endif
 template <bool SAMPLE, bool TD, bool FAST, int D>
-__global__ __launch_bounds__(BLOCK, FAST ? 4 : 2) void k_core_small(CoreArgs a) {
+__global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core_small(CoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int d = D ? D : a.d;
   const int dd = d * d, dp = d | 1, T = a.T;
@@ -514,6 +517,7 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
   }
 }
 
+constexpr int MFG_CORE_OVERSUBSCRIBE = 8;
 inline int core_grid(int64_t work_items, int per_block, int blocks_per_cu, int num_cus) {
   int64_t g = (work_items + per_block - 1) / per_block;
   const int64_t cap = (int64_t)num_cus * blocks_per_cu;
@@ -527,7 +531,7 @@ inline int launch_core_large_impl(const CoreArgs& a, bool sample, bool td, int n
   const int d = a.d;
   const int R = (d + WAVE - 1) / WAVE;
   const size_t lds = (size_t)WAVES * 3 * d * 4 + 8 + (size_t)WAVES * 3 * d * 8;
-  const int grid = core_grid(a.B, WAVES, 8, num_cus);
+  const int grid = core_grid(a.B, WAVES, 8 * MFG_CORE_OVERSUBSCRIBE, num_cus);
 #define MFG_CORE_LARGE_MODE(RR)                                                                              \
   if (sample && td) hipLaunchKernelGGL((k_core_large<RR, true, true, FAST>), dim3(grid), dim3(BLOCK), lds, st, a);        \
   else if (sample) hipLaunchKernelGGL((k_core_large<RR, true, false, FAST>), dim3(grid), dim3(BLOCK), lds, st, a);        \
