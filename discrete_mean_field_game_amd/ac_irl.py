@@ -253,6 +253,30 @@ class AC_IRL(actor_critic):
         self._gen_traj_counter = off + n
         return off
 
+    # ------------------------------------------------------------------ importance weights (ac_irl.py:270-379)
+    def calc_pdf_action(self, theta, action, state, log=False):
+        """q(a_t; s_t, theta) of the product-Dirichlet policy (ac_irl.py:270-289); `log=True` returns ln q (the
+        density itself under/overflows fp64 long before d=15 rows are multiplied)."""
+        s, a = self._pairs_to_tensors([(state, action)])
+        th = torch.tensor([float(np.ravel(theta)[0])], dtype=torch.float64, device=self.device)
+        lq = float(ops.policy_logpdf(s, a, th, self.shift)[0, 0].cpu())
+        return lq if log else float(np.exp(lq))
+
+    def calc_z(self, list_trajectories, log=False):
+        """z(traj_j) = [1/k sum_k q_k(traj_j)]^-1 over the policies in `list_policies` (ac_irl.py:292-321, :324-379;
+        alpha lower-bounded by 1+1e-6 like :359).  One HIP launch for all (transition, policy) pairs; the products
+        over topics / time and the sum over policies are done in log space instead of the reference's
+        divide-by-`c` normaliser.  Returns z [M] (or ln z with `log=True`)."""
+        thetas = torch.as_tensor(np.array([float(np.ravel(t)[0]) for t in self.list_policies], dtype=np.float64),
+                                 device=self.device)
+        M, T = len(list_trajectories), len(list_trajectories[0])
+        s, a = self._pairs_to_tensors([pair for traj in list_trajectories for pair in traj])
+        lq = ops.policy_logpdf(s, a, thetas, self.shift, 1.0, 1.0 + 1e-6).view(M, T, -1).sum(1)
+        lq = lq - float(np.log(self.num_start_samples))
+        lz = float(np.log(thetas.numel())) - torch.logsumexp(lq, dim=1)
+        out = lz if log else torch.exp(lz)
+        return out.cpu().numpy()
+
     # ------------------------------------------------------------------ reward learning (ac_irl.py:804-897)
     def update_reward(self, summary=False, iteration=0):
         if len(self.list_demonstrations) >= self.num_demo_samples:

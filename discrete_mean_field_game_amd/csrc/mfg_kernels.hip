@@ -186,6 +186,54 @@ __global__ void k_jsd(const float* __restrict__ p, const float* __restrict__ q, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// f1 (importance weights of the max-ent IRL loss, ac_irl.py:270-289 calc_pdf_action / :324-379 calc_z): log-density of
+// the product-Dirichlet policy, one wavefront per (sample n, policy k):
+//   log q_k(P_n | pi_n) = sum_i [ lgamma(sum_j a_ij) - sum_j lgamma(a_ij) + sum_j (a_ij - 1) ln P_ij ],
+//   a_ij = max(alpha_floor, alpha_scale * ln(1 + exp(theta_k (pi_j - pi_i - shift)))).
+// Log space replaces the reference's divide-by-normaliser trick (pdf / c before the products).  fp64 throughout.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_policy_logpdf(const float* __restrict__ pi, const float* __restrict__ P, int64_t N,
+                                                         int d, const double* __restrict__ thetas, int K, double shift,
+                                                         double alpha_scale, double alpha_floor, double p_floor,
+                                                         double* __restrict__ out) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / WAVE;
+  const int64_t nw = (int64_t)gridDim.x * blockDim.x / WAVE;
+  const int dd = d * d;
+  for (int64_t u = wave; u < N * K; u += nw) {
+    const int64_t n = u / K;
+    const int k = (int)(u - n * K);
+    const double th = thetas[k];
+    const float* pn = pi + n * d;
+    const float* Pn = P + n * (int64_t)dd;
+    double acc = 0.0;
+    for (int e = lane; e < dd; e += WAVE) {
+      const int i = e / d, j = e - i * d;
+      double sp, sg;
+      softplus_sigmoid(th * ((double)pn[j] - (double)pn[i] - shift), sp, sg);
+      double al = alpha_scale * sp;
+      if (al < alpha_floor) al = alpha_floor;
+      double pv = (double)Pn[e];
+      if (pv < p_floor) pv = p_floor;
+      acc += (al - 1.0) * log(pv) - lgamma(al);
+    }
+    for (int i = lane; i < d; i += WAVE) {
+      double A = 0.0;
+      for (int j = 0; j < d; ++j) {
+        double sp, sg;
+        softplus_sigmoid(th * ((double)pn[j] - (double)pn[i] - shift), sp, sg);
+        double al = alpha_scale * sp;
+        if (al < alpha_floor) al = alpha_floor;
+        A += al;
+      }
+      acc += lgamma(A);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[u] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // f3: backward value recursion of mfg_synthetic (mfg_synthetic.py:768-774) and the two consistency metrics
 // of evaluate_synthetic (:776-790, sum_ij |P_ij - value_ij|) / evaluate_synthetic_JSD (:858-880, sum_i JSD(P_i,
 // implied row i) with entries <= 0 -> 1e-100).  One wavefront per trajectory, lane = row i, reverse-time scan
@@ -920,7 +968,7 @@ static int launch_core(const CoreArgs& a_in, bool sample, bool td, int precision
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 5; }
+int mfg_abi_version(void) { return 6; }
 
 int mfg_init(void) {
   if (!htab_ptr()) return fail(MFG_ELAUNCH, "%s", "mfg_init: no HIP device / table initialisation failed");
@@ -1123,6 +1171,16 @@ int mfg_jsd(const float* p, const float* q, int64_t B, int d, double* out, mfg_s
   REQUIRE(p && q && out, "null pointer");
   hipLaunchKernelGGL(k_jsd, dim3(grid_for(B, WAVES, 8)), dim3(BLOCK), 0, S(stream), p, q, B, d, out);
   return check_launch("jsd");
+}
+
+int mfg_policy_logpdf(const float* pi, const float* P, int64_t N, int d, const double* thetas, int K, double shift,
+                      double alpha_scale, double alpha_floor, double p_floor, double* out, mfg_stream_t stream) {
+  const int64_t B = N;
+  CHECK_BD();
+  REQUIRE(pi && P && thetas && out && K >= 1, "null pointer / K < 1");
+  hipLaunchKernelGGL(k_policy_logpdf, dim3(grid_for(N * K, WAVES, 8)), dim3(BLOCK), 0, S(stream), pi, P, N, d, thetas, K,
+                     shift, alpha_scale, alpha_floor, p_floor, out);
+  return check_launch("policy_logpdf");
 }
 
 #define CHECK_PRECISION() REQUIRE(precision == MFG_PRECISION_F64 || precision == MFG_PRECISION_MIXED, "bad precision")

@@ -210,6 +210,20 @@ def jsd(p, q):
     return out
 
 
+def policy_logpdf(pi, P, thetas, shift, alpha_scale=1.0, alpha_floor=0.0, p_floor=0.0):
+    """log q_k(P_n | pi_n) [N,K] of the product-Dirichlet policy under K thetas (ac_irl.py:270-289, :324-379)."""
+    _chk_f32(pi, 'pi'); _chk_f32(P, 'P'); _chk_f64(thetas, 'thetas')
+    N, d = pi.shape
+    if P.shape != (N, d, d):
+        raise ValueError('P must be [N,d,d]')
+    K = thetas.numel()
+    out = torch.empty(N, K, dtype=torch.float64, device=pi.device)
+    L.check(L.lib().mfg_policy_logpdf(pi.data_ptr(), P.data_ptr(), N, d, thetas.data_ptr(), K, float(shift),
+                                      float(alpha_scale), float(alpha_floor), float(p_floor), out.data_ptr(), _stream()),
+            'mfg_policy_logpdf')
+    return out
+
+
 def reward_net_supported(net) -> bool:
     """True when networks.RewardNet `net` fits the HIP forward kernel (d <= 32, f1 = 1, f2 <= 2, n_fc <= 32)."""
     k1, k2 = net.conv1.kernel_size[0], net.conv2.kernel_size[0]

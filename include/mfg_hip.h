@@ -172,6 +172,16 @@ int mfg_reward_net_forward(const float* state, const float* action, int64_t B, i
 int mfg_backward_value(const float* P, int64_t B, int T, int d, double* V, double* diff_l1, double* diff_jsd,
                        mfg_stream_t stream);
 
+/* f1 (optional importance weights, ac_irl.py:270-289 calc_pdf_action, :324-379 calc_z): log-density of the
+ * product-Dirichlet policy for N (state, action) pairs under K policies theta_k (device array):
+ *   out[n*K + k] = sum_i log Dirichlet(P_n[i,:] ; a_i),  a_ij = max(alpha_floor, alpha_scale * softplus(theta_k x_ij)).
+ * The reference evaluates the density itself and divides by a normaliser c before multiplying 15*d factors
+ * (:365-373); the log-space value is exact where that under/overflows.  alpha_floor = 1+1e-6 and alpha_scale = 1
+ * reproduce calc_z; alpha_floor = 0 reproduces calc_pdf_action.  Entries of P below p_floor are raised to it
+ * (p_floor = 0: ln 0 = -inf, density 0, like tf.distributions.Dirichlet.prob).  fp64 out. */
+int mfg_policy_logpdf(const float* pi, const float* P, int64_t N, int d, const double* thetas, int K, double shift,
+                      double alpha_scale, double alpha_floor, double p_floor, double* out, mfg_stream_t stream);
+
 /* a11: out[b] = JSD(p_b, q_b), zeros -> 1e-100, inputs renormalised like scipy.stats.entropy
  * (mfg_ac2.py:546-563).  fp64 out. */
 int mfg_jsd(const float* p, const float* q, int64_t B, int d, double* out, mfg_stream_t stream);

@@ -517,3 +517,38 @@ def cpu_baseline_steps(d, n_steps, theta=8.86349, shift=0.16, alpha_scale=12000,
     t0 = time.perf_counter()
     train_mfg_ac2(mat_pi0, w, theta, shift, alpha_scale, episodes, rng=rs, record=False)
     return episodes * EPISODE_STEPS, time.perf_counter() - t0
+
+
+# --------------------------------------------------------------------------
+# f1 (optional importance weights of the max-ent loss; TensorFlow code in the reference, disabled at
+# ac_irl.py:404-405 -- "parity unpinned": checked against scipy.stats.dirichlet and hand-derived values only)
+
+def policy_logpdf(pi, P, thetas, shift, alpha_scale=1.0, alpha_floor=0.0, p_floor=0.0):
+    """log q_k(P_n | pi_n) for N pairs under K policies -> [N, K].
+
+    calc_pdf_action (ac_irl.py:270-289): mat_alpha = log(1 + exp(theta (pi_j - pi_i - shift))), pdf = prod_rows
+    Dirichlet(mat_alpha[row]).prob(action[row]).  calc_z (:324-379) lower-bounds alpha by 1+1e-6 (:359) and
+    multiplies the per-row densities over topics and time after dividing by a normaliser; here the logs are summed.
+    """
+    pi = np.asarray(pi, dtype=np.float64)
+    P = np.asarray(P, dtype=np.float64)
+    thetas = np.asarray(thetas, dtype=np.float64).reshape(-1)
+    out = np.zeros((pi.shape[0], thetas.size))
+    Pc = np.maximum(P, p_floor)
+    with np.errstate(divide='ignore'):
+        lnP = np.log(Pc)
+    for k, th in enumerate(thetas):
+        x = pi[:, None, :] - pi[:, :, None] - shift                   # x[n,i,j] = pi_j - pi_i - shift
+        al = np.maximum(alpha_scale * np.log1p(np.exp(th * x)), alpha_floor)
+        out[:, k] = np.sum(special.gammaln(al.sum(-1)) - special.gammaln(al).sum(-1) + ((al - 1.0) * lnP).sum(-1), axis=-1)
+    return out
+
+
+def calc_z(pi_traj, P_traj, thetas, shift, num_start_samples, alpha_floor=1.0 + 1e-6):
+    """z_j = [1/K sum_k q_k(traj_j)]^-1 with q_k(traj) = Pr(s_1) prod_t q_k(a_t; s_t) (ac_irl.py:292-321, :374-379), in
+    log space: returns log z_j for pi_traj [M,T,d], P_traj [M,T,d,d]."""
+    M, T, d = pi_traj.shape
+    lq = policy_logpdf(pi_traj.reshape(M * T, d), P_traj.reshape(M * T, d, d), thetas, shift, 1.0, alpha_floor)
+    lq = lq.reshape(M, T, -1).sum(1) - np.log(num_start_samples)      # [M,K]
+    K = lq.shape[1]
+    return np.log(K) - special.logsumexp(lq, axis=1)

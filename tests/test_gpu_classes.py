@@ -329,3 +329,22 @@ def test_mfg_synthetic_class_surface(dev):
     assert abs(ac.JSD(np.array([.5, .5, -1.]), np.array([.1, .2, .7])) - O().JSD_synthetic([.5, .5, -1.], [.1, .2, .7])) < 1e-6
     ac.train(num_episodes=2, constant=1)                                  # synthetic reward inside the fused path
     assert np.isfinite(float(np.ravel(ac.theta)[0]))
+
+
+def test_irl_importance_weights_calc_z(dev):
+    """AC_IRL.calc_z / calc_pdf_action (ac_irl.py:270-379) against the oracle's log-space restatement."""
+    from discrete_mean_field_game_amd import ac_irl
+    from oracle import mfg_oracle as O
+    rs = np.random.RandomState(3)
+    d = 15
+    ac = ac_irl.AC_IRL(d=d, pi0=rs.dirichlet(np.ones(d), size=8), demonstrations=[], seed=5, verbose=0)
+    ac.list_policies = [8.64, 7.9, 8.2]
+    trajs = ac.generate_trajectories(4)
+    lz = ac.calc_z(trajs, log=True)
+    pis = np.array([[p[0] for p in t] for t in trajs]); Ps = np.array([[p[1] for p in t] for t in trajs])
+    want = O.calc_z(pis.astype(np.float32), Ps.astype(np.float32), ac.list_policies, ac.shift, ac.num_start_samples)
+    np.testing.assert_allclose(lz, want, rtol=1e-9, atol=1e-6)
+    z = ac.calc_z(trajs)
+    assert z.shape == (4,) and np.all(z >= 0)
+    lq = ac.calc_pdf_action(8.64, trajs[0][0][1], trajs[0][0][0], log=True)
+    assert abs(lq - O.policy_logpdf(np.float32(trajs[0][0][0])[None], np.float32(trajs[0][0][1])[None], [8.64], ac.shift)[0, 0]) < 1e-6 * abs(lq)

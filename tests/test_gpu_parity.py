@@ -378,3 +378,21 @@ def test_score_beyond_the_h_table_and_extreme_theta(dev, theta):
     assert rel(gm, ref, 1e-30) < 1e-5
     if theta < 20:                                            # where the reference formula is still accurate
         assert rel(gf, O().calc_gradient(P, pi, theta, shift), 1e-30) < 1e-9
+
+
+@pytest.mark.parametrize('d,N', [(4, 9), (15, 30), (21, 64), (100, 3)])
+def test_policy_logpdf_vs_oracle(dev, d, N):
+    """f1: log-density of the product-Dirichlet policy under K policies (ac_irl.py:270-289, :324-379)."""
+    rs = np.random.RandomState(d)
+    pi, P = rand_case(rs, N, d, conc=1.0, pconc=2.0)
+    thetas = np.array([2.0, 6.5, 8.64])
+    for scale, floor, pfloor in [(1.0, 0.0, 0.0), (1.0, 1.0 + 1e-6, 0.0), (50.0, 0.0, 1e-6)]:
+        got = ops().policy_logpdf(t32(pi, dev), t32(P, dev), t64(thetas, dev), 0.05, scale, floor, pfloor).cpu().numpy()
+        want = O().policy_logpdf(pi, P, thetas, 0.05, scale, floor, pfloor)
+        assert got.shape == (N, 3)
+        assert rel(got, want, floor=1.0) < 1e-10
+    # an exact zero in an action: density 0 (log = -inf) when alpha > 1, like tf.distributions.Dirichlet.prob
+    P0 = P.copy()
+    P0[0, 1, 2] = 0.0
+    got = ops().policy_logpdf(t32(pi, dev), t32(P0, dev), t64(thetas, dev), 0.05, 1.0, 1.0 + 1e-6).cpu().numpy()
+    assert np.all(np.isneginf(got[0])) and np.all(np.isfinite(got[1:]))

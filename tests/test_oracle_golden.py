@@ -206,3 +206,30 @@ def test_backward_value_recursion_mfg_synthetic():
     assert np.isclose(l1.mean(), float(z['l1_mean']), rtol=1e-12) and np.isclose(l1.std(), float(z['l1_std']), rtol=1e-12)
     _, _, jsd = O.evaluate_synthetic_diffs(z['actions_jsd'])
     assert np.isclose(jsd.mean(), float(z['jsd_mean']), rtol=1e-12) and np.isclose(jsd.std(), float(z['jsd_std']), rtol=1e-12)
+
+
+def test_policy_logpdf_against_scipy_dirichlet():
+    """f1 (unpinned TF code, ac_irl.py:270-289): the oracle's log-density equals the sum of scipy's Dirichlet row
+    log-pdfs with the reference's alpha matrix, and calc_z's log-space result equals the direct formula (:292-321)."""
+    from scipy.stats import dirichlet
+    from scipy.special import logsumexp
+    rs = np.random.RandomState(0)
+    d, N = 5, 6
+    pi = rs.dirichlet(np.ones(d), size=N)
+    P = rs.dirichlet(np.ones(d) * 2.0, size=(N, d))
+    thetas = [3.0, 6.5]
+    lq = O.policy_logpdf(pi, P, thetas, 0.1)
+    for n in range(N):
+        for k, th in enumerate(thetas):
+            mat1 = np.repeat(pi[n].reshape(1, d), d, 0)
+            mat2 = np.repeat(pi[n].reshape(d, 1), d, 1)
+            alpha = np.log(1 + np.exp(th * (mat1 - mat2 - 0.1)))
+            want = sum(dirichlet.logpdf(P[n, i], alpha[i]) for i in range(d))
+            assert abs(lq[n, k] - want) < 1e-9 * max(1.0, abs(want))
+    # calc_z: 2 trajectories x 3 steps, direct product formula in linear space (small enough not to overflow)
+    M, T = 2, 3
+    lz = O.calc_z(pi.reshape(M, T, d), P.reshape(M, T, d, d), thetas, 0.1, num_start_samples=7)
+    lqf = O.policy_logpdf(pi, P, thetas, 0.1, 1.0, 1.0 + 1e-6).reshape(M, T, 2)
+    q = np.exp(lqf).prod(1) / 7.0
+    z = len(thetas) / q.sum(1)
+    np.testing.assert_allclose(np.exp(lz), z, rtol=1e-10)
