@@ -396,3 +396,26 @@ def test_policy_logpdf_vs_oracle(dev, d, N):
     P0[0, 1, 2] = 0.0
     got = ops().policy_logpdf(t32(pi, dev), t32(P0, dev), t64(thetas, dev), 0.05, 1.0, 1.0 + 1e-6).cpu().numpy()
     assert np.all(np.isneginf(got[0])) and np.all(np.isfinite(got[1:]))
+
+
+@pytest.mark.parametrize('d,B', [(21, 50), (15, 37), (64, 5), (100, 4), (128, 6), (256, 3), (130, 3)])
+@pytest.mark.parametrize('off', [1, 2])
+def test_step_given_P_misaligned_pointers(dev, d, B, off):
+    """Buffers that are only 4- or 8-byte aligned (views into a larger allocation) take the scalar / narrow-vector
+    fallbacks and must give exactly what the 16-byte-aligned fast paths give."""
+    rs = np.random.RandomState(100 + d)
+    pi, P = rand_case(rs, B, d)
+    pa, Pa = t32(pi, dev), t32(P, dev)
+    want_pi, want_r = ops().step_given_P(pa, Pa)
+    bufP = torch.zeros(B * d * d + 8, device=dev)
+    bufpi = torch.zeros(B * d + 8, device=dev)
+    Pv = bufP[off:off + B * d * d].view(B, d, d)
+    pv = bufpi[off:off + B * d].view(B, d)
+    Pv.copy_(Pa)
+    pv.copy_(pa)
+    assert Pv.data_ptr() % 16 != 0
+    got_pi, got_r = ops().step_given_P(pv, Pv)
+    assert torch.equal(got_pi, want_pi)
+    assert rel(got_r.cpu().numpy(), want_r.cpu().numpy(), floor=1e-3) < 1e-6
+    ref_pi = O().transition(P.astype(np.float64), pi.astype(np.float64))
+    np.testing.assert_allclose(got_pi.cpu().numpy(), ref_pi, rtol=0, atol=1e-7)
