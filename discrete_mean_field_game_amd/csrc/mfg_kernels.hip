@@ -661,6 +661,12 @@ struct GradArgs {
   int T, d, chunk;  // chunk = samples staged per iteration
   int64_t nsb;      // number of sample-blocks (grid.x)
   double* partial;  // [nsb][F+3]
+  // in-kernel finalisation by the last block to finish (k_grad_small with few rows): G, optional parameter update
+  unsigned* counter;  // zero on entry, zero again on exit; NULL -> separate k_reduce_partials launch
+  double* G;
+  int accumulate, apply;
+  double lr_c, lr_a;
+  double *w, *theta, *reward_acc;
 };
 
 __global__ __launch_bounds__(BLOCK) void k_grad_partial(GradArgs a) {
@@ -764,6 +770,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_small(GradArgs a) {
   constexpr int G = WAVE / D, Q = D * (D + 1) / 2, F = Q + D + 1, FO = F + 3;
   __shared__ double line[WAVES][2][G * D];  // fp64 so the inner loop is one LDS read + one FMA per product
   __shared__ double red[D * D + D + 4];
+  __shared__ double slots[WAVES * G][D * D + D + 4];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
   const int g = lane / D, i = lane - g * D;
   const bool act = g < G;
@@ -800,20 +807,27 @@ __global__ __launch_bounds__(BLOCK) void k_grad_small(GradArgs a) {
     c0 = x0;
     c1 = x1;
   }
-  // block reduction in a fixed (wave, slot) order
-  for (int grp = 0; grp < WAVES * G; ++grp) {
-    __syncthreads();
-    if (act && wv * G + g == grp) {
+  // block reduction in a fixed (wave, slot) order: every slot parks its sums in LDS, then each output is added up
+  // over the WAVES*G slots by one thread (two barriers instead of one per slot)
+  constexpr int NS = WAVES * G, RW = D * D + D + 4;
+  if (act) {
+    double* mine = slots[wv * G + g];
 #pragma unroll
-      for (int j = 0; j < D; ++j) red[i * D + j] = (grp == 0 ? 0.0 : red[i * D + j]) + acc[j];
-      red[D * D + i] = (grp == 0 ? 0.0 : red[D * D + i]) + lin;
-      if (i == 0) {
-        red[D * D + D + 0] = (grp == 0 ? 0.0 : red[D * D + D + 0]) + s_d;
-        red[D * D + D + 1] = (grp == 0 ? 0.0 : red[D * D + D + 1]) + s_dg;
-        red[D * D + D + 2] = (grp == 0 ? 0.0 : red[D * D + D + 2]) + s_r;
-        red[D * D + D + 3] = (grp == 0 ? 0.0 : red[D * D + D + 3]) + s_n;
-      }
+    for (int j = 0; j < D; ++j) mine[i * D + j] = acc[j];
+    mine[D * D + i] = lin;
+    if (i == 0) {
+      mine[D * D + D + 0] = s_d;
+      mine[D * D + D + 1] = s_dg;
+      mine[D * D + D + 2] = s_r;
+      mine[D * D + D + 3] = s_n;
     }
+  }
+  __syncthreads();
+  for (int k = tid; k < RW; k += BLOCK) {
+    double t = slots[0][k];
+#pragma unroll
+    for (int q = 1; q < NS; ++q) t += slots[q][k];
+    red[k] = t;
   }
   __syncthreads();
   double* out = a.partial + (int64_t)blockIdx.x * FO;
@@ -823,6 +837,55 @@ __global__ __launch_bounds__(BLOCK) void k_grad_small(GradArgs a) {
   }
   for (int k = tid; k < D; k += BLOCK) out[Q + k] = red[D * D + k];
   if (tid < 4) out[Q + D + tid] = red[D * D + D + tid];
+  if (!a.counter) return;
+  // Few rows (small batches, per-step updates): the last block to finish sums the rows in a fixed order, writes G
+  // and, when asked, applies the parameter update -- one launch instead of three dependent ones.
+  __shared__ int s_last;
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = (atomicAdd(a.counter, 1u) == gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const int nrows = (int)gridDim.x;
+  for (int k = tid; k < FO; k += BLOCK) {
+    // plain loads: the agent-scope fence above already invalidated this CU's L1, and nothing here was read before it
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const double* col = a.partial + k;
+    int r = 0;
+    for (; r + 7 < nrows; r += 8) {
+      const double v0 = col[(int64_t)r * FO], v1 = col[(int64_t)(r + 1) * FO], v2 = col[(int64_t)(r + 2) * FO],
+                   v3 = col[(int64_t)(r + 3) * FO], v4 = col[(int64_t)(r + 4) * FO], v5 = col[(int64_t)(r + 5) * FO],
+                   v6 = col[(int64_t)(r + 6) * FO], v7 = col[(int64_t)(r + 7) * FO];
+      s0 += v0;
+      s1 += v1;
+      s2 += v2;
+      s3 += v3;
+      s0 += v4;
+      s1 += v5;
+      s2 += v6;
+      s3 += v7;
+    }
+    for (; r < nrows; ++r) s0 += col[(int64_t)r * FO];
+    const double tot = (s0 + s1) + (s2 + s3);
+    const double gk = a.accumulate ? a.G[k] + tot : tot;
+    a.G[k] = gk;
+    red[k] = gk;  // FO <= D*D + D + 4
+  }
+  __syncthreads();
+  if (a.apply) {
+    // identical arithmetic to k_apply_update
+    const double count = red[F + 2];
+    if (count > 0.0) {
+      const double inv = 1.0 / count;
+      for (int k = tid; k < F; k += BLOCK) a.w[k] += a.lr_c * (red[k] * inv);
+      if (tid == 0) {
+        if (a.reward_acc) *a.reward_acc += red[F + 1] * inv;
+        *a.theta += a.lr_a * (red[F] * inv);
+      }
+    }
+  }
+  if (tid == 0) *a.counter = 0u;
 }
 
 // Sum nsb partial rows in a fixed order: block = 16 slices (waves) x 64 outputs (lanes, coalesced);
@@ -867,6 +930,14 @@ static int grid_for(int64_t work_items, int per_block, int blocks_per_cu) {
   return (int)g;
 }
 
+constexpr size_t MFG_WS_CONTROL_BYTES = 64;  // trailing control block of the workspace (completion counter), kept zero
+constexpr int MFG_GRAD_FUSE_MAX_ROWS = 32;   // in-kernel finalisation up to this many partial rows
+
+struct ApplyArgs {
+  double lr_c, lr_a;
+  double *w, *theta, *reward_acc;
+};
+
 static void grad_geometry(int64_t N, int d, int* chunk, int64_t* nsb, int* nob) {
   const int64_t FO = mfg_num_features(d) + 3;
   int ch = 8192 / d;
@@ -883,24 +954,62 @@ static void grad_geometry(int64_t N, int d, int* chunk, int64_t* nsb, int* nob) 
   *nob = (int)((FO + GR_OUT_PER_BLOCK - 1) / GR_OUT_PER_BLOCK);
 }
 
+// `apply` (optional): also perform the parameter update; *applied tells whether it was done in-kernel.
 static int launch_grad(const float* pi, int64_t stride_b, const double* delta, const double* g, const float* reward,
-                       int64_t N, int T, int d, double* G, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+                       int64_t N, int T, int d, double* G, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
+                       const ApplyArgs* apply = nullptr, bool* applied = nullptr) {
+  if (applied) *applied = false;
   const int64_t FO = mfg_num_features(d) + 3;
   int chunk, nob;
   int64_t nsb;
   grad_geometry(N, d, &chunk, &nsb, &nob);
-  if (ws_bytes < (size_t)(nsb * FO * 8)) return fail(MFG_EWORKSPACE, "%s: need %lld bytes, have %lld", "workspace",
-                                                     (long long)(nsb * FO * 8), (long long)ws_bytes);
-  GradArgs a{pi, stride_b, delta, g, reward, N, T, d, chunk, nsb, (double*)ws};
+  const size_t need = (size_t)(nsb * FO * 8) + MFG_WS_CONTROL_BYTES;
+  if (ws_bytes < need) return fail(MFG_EWORKSPACE, "%s: need %lld bytes, have %lld", "workspace", (long long)need,
+                                   (long long)ws_bytes);
+  GradArgs a{};
+  a.pi = pi;
+  a.stride_b = stride_b;
+  a.delta = delta;
+  a.g = g;
+  a.reward = reward;
+  a.N = N;
+  a.T = T;
+  a.d = d;
+  a.chunk = chunk;
+  a.nsb = nsb;
+  a.partial = (double*)ws;
   if (d == 21 || d == 15) {
     // one partial row per block; nsb rows fit the workspace by construction (grad_geometry)
     const int per = WAVE / d;
-    int64_t blocks = (N + (int64_t)WAVES * per * 16 - 1) / ((int64_t)WAVES * per * 16);  // >= 8 iterations (2 groups each) per wave
+    const int64_t per_block_iter = (int64_t)WAVES * per * 2;  // samples one block covers per loop iteration
+    int64_t blocks = (N + per_block_iter * 8 - 1) / (per_block_iter * 8);  // >= 8 iterations per wave ...
+    if (N <= per_block_iter * 8 * MFG_GRAD_FUSE_MAX_ROWS) {
+      // ... except for small batches (per-step updates): spread them over up to MFG_GRAD_FUSE_MAX_ROWS blocks so that
+      // the kernel is a few loop iterations deep and its last block can finish the sums (and the update) itself
+      blocks = (N + per_block_iter - 1) / per_block_iter;
+      if (blocks > MFG_GRAD_FUSE_MAX_ROWS) blocks = MFG_GRAD_FUSE_MAX_ROWS;
+    }
     if (blocks > nsb) blocks = nsb;
     if (blocks < 1) blocks = 1;
     a.nsb = blocks;
+    const bool fuse = blocks <= MFG_GRAD_FUSE_MAX_ROWS;
+    if (fuse) {
+      a.counter = reinterpret_cast<unsigned*>((char*)ws + (size_t)(nsb * FO * 8));
+      a.G = G;
+      a.accumulate = accumulate;
+      if (apply) {
+        a.apply = 1;
+        a.lr_c = apply->lr_c;
+        a.lr_a = apply->lr_a;
+        a.w = apply->w;
+        a.theta = apply->theta;
+        a.reward_acc = apply->reward_acc;
+        if (applied) *applied = true;
+      }
+    }
     if (d == 21) hipLaunchKernelGGL((k_grad_small<21>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
     else hipLaunchKernelGGL((k_grad_small<15>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
+    if (fuse) return check_launch("grad_small");
     hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
                        (const double*)ws, blocks, FO, accumulate, G);
     return check_launch("grad_small");
@@ -968,7 +1077,7 @@ static int launch_core(const CoreArgs& a_in, bool sample, bool td, int precision
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 6; }
+int mfg_abi_version(void) { return 7; }
 
 int mfg_init(void) {
   if (!htab_ptr()) return fail(MFG_ELAUNCH, "%s", "mfg_init: no HIP device / table initialisation failed");
@@ -1004,7 +1113,7 @@ size_t mfg_workspace_bytes(int64_t N, int d) {
   int chunk, nob;
   int64_t nsb;
   grad_geometry(N, d, &chunk, &nsb, &nob);
-  return (size_t)(nsb * (mfg_num_features(d) + 3) * 8);
+  return (size_t)(nsb * (mfg_num_features(d) + 3) * 8) + MFG_WS_CONTROL_BYTES;
 }
 
 #define CHECK_BD()                                        \
@@ -1302,6 +1411,58 @@ int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, 
   REQUIRE(workspace, "workspace is null");
   return launch_grad(pi_traj, (int64_t)(T + 1) * d, delta, g, reward, B * T, T, d, G, accumulate, workspace,
                      workspace_bytes, S(stream));
+}
+
+int mfg_train_episode(float* pi_io, float* pi_scratch, int64_t B, int d, int T, double* theta, double shift,
+                      double alpha_scale, double* w, double gamma, int reward_kind, uint64_t seed, uint32_t first_step,
+                      uint64_t traj_offset, int precision, double lr_critic, double lr_actor, float* reward, double* delta,
+                      double* g, double* G, double* reward_acc, void* workspace, size_t workspace_bytes,
+                      mfg_stream_t stream) {
+  CHECK_BD();
+  CHECK_PRECISION();
+  REQUIRE(T >= 1, "T < 1");
+  REQUIRE(pi_io && pi_scratch && theta && w && reward && delta && g && G && workspace, "null pointer");
+  REQUIRE(reward_kind == MFG_REWARD_MFG_AC2 || reward_kind == MFG_REWARD_SYNTHETIC, "needs an in-kernel reward");
+  hipStream_t st = S(stream);
+  float* cur = pi_io;
+  float* nxt = pi_scratch;
+  for (int s = 0; s < T; ++s) {
+    CoreArgs a{};
+    a.pi0 = cur;
+    a.theta = theta;
+    a.w = w;
+    a.shift = shift;
+    a.alpha_scale = alpha_scale;
+    a.gamma = gamma;
+    a.B = B;
+    a.d = d;
+    a.T = 1;
+    a.reward_kind = reward_kind;
+    a.seed = seed;
+    a.first_step = first_step + (uint32_t)s;
+    a.traj_offset = traj_offset;
+    a.pi_next_out = nxt;
+    a.reward_out = reward;
+    a.delta = delta;
+    a.g = g;
+    int rc = launch_core(a, true, true, precision, st);
+    if (rc != MFG_OK) return rc;
+    const ApplyArgs ap{lr_critic, lr_actor, w, theta, reward_acc};
+    bool applied = false;
+    rc = launch_grad(cur, d, delta, g, reward, B, 1, d, G, 0, workspace, workspace_bytes, st, &ap, &applied);
+    if (rc != MFG_OK) return rc;
+    if (!applied) {
+      const int64_t F = mfg_num_features(d);
+      hipLaunchKernelGGL(k_apply_update, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, G, F, lr_critic, lr_actor,
+                         w, theta, reward_acc);
+    }
+    float* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+  if (cur != pi_io && hipMemcpyAsync(pi_io, cur, (size_t)B * d * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return fail(MFG_ELAUNCH, "%s", "train_episode: final state copy failed");
+  return check_launch("train_episode");
 }
 
 }  // extern "C"

@@ -304,13 +304,24 @@ class actor_critic:
         ep_reward = torch.zeros(max(num_episodes, 1), dtype=torch.float64, device=self.device)
         window_start = 0
         pi = None
+        # per-step updates on one GPU: the whole episode is issued by native code (mfg_train_episode)
+        native_episode = (self.update_every == 'step' and self.rng == 'philox' and shard.world == 1
+                          and self.trace is None and not write_all)
+        ebufs = ops.episode_buffers(Bl, d, self.device) if native_episode else None
         for episode in range(num_episodes):
             if write_all:
                 with open('temp.csv', 'a') as f:
                     f.write('Episode %d \n\n' % episode)
             pi = ops.gather_start(self._mat_pi0_dev, self._draw_start(shard))
             sc, sa = lr_scales(episode, constant == 1)
-            if self.update_every == 'rollout' and self.rng == 'philox':
+            if native_episode:
+                ops.train_episode(pi, T, self._theta, self.shift, self.alpha_scale, self._w, gamma, lr_critic * sc,
+                                  lr_actor * sa, G, ws, ebufs, reward_kind=self.reward_kind, seed=self.seed,
+                                  first_step=self._rng_step, traj_offset=shard.traj_offset,
+                                  reward_acc=ep_reward[episode:episode + 1], precision=self.precision)
+                self._rng_step += T
+                self._theta_is_array = True
+            elif self.update_every == 'rollout' and self.rng == 'philox':
                 out = ops.rollout(pi, T, self._theta, self.shift, self.alpha_scale, w=self._w, gamma=gamma,
                                   reward_kind=self.reward_kind, seed=self.seed, first_step=self._rng_step,
                                   traj_offset=shard.traj_offset, td=True, G=G, ws=ws, precision=self.precision)

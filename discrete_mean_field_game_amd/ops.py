@@ -45,7 +45,7 @@ def feature_index(i: int, j: int, d: int) -> int:
 
 def workspace(N: int, d: int, device) -> torch.Tensor:
     n = int(L.lib().mfg_workspace_bytes(N, d))
-    return torch.empty(max(n, 8) // 8, dtype=torch.float64, device=device)
+    return torch.zeros(max(n, 8) // 8, dtype=torch.float64, device=device)   # zeroed: trailing control block (mfg_hip.h)
 
 
 def gather_start(mat_pi0, idx):
@@ -200,6 +200,28 @@ def rollout(pi0, T, theta, shift, alpha_scale, w=None, gamma=1.0, reward_kind=L.
                                 _ptr(P), _ptr(G) if td else None, int(accumulate), _ptr(ws) if td else None,
                                 ws.numel() * 8 if (td and ws is not None) else 0, _stream()), 'mfg_rollout')
     return {'pi_traj': pi_traj, 'pi_last': pi_last, 'reward': reward, 'delta': delta, 'g': g, 'P': P, 'G': G}
+
+
+def train_episode(pi, T, theta, shift, alpha_scale, w, gamma, lr_critic, lr_actor, G, ws, bufs, reward_kind=L.REWARD_MFG_AC2,
+                  seed=0, first_step=0, traj_offset=0, reward_acc=None, precision='mixed'):
+    """T env steps with the reference's per-step parameter updates, issued natively (single GPU).  `pi` [B,d] is
+    updated in place to the final states; `bufs` = dict(scratch[B,d] f32, reward[B] f32, delta[B] f64, g[B] f64)."""
+    _chk_f32(pi, 'pi'); _chk_f64(theta, 'theta'); _chk_f64(w, 'w')
+    B, d = pi.shape
+    L.check(L.lib().mfg_train_episode(pi.data_ptr(), bufs['scratch'].data_ptr(), B, d, int(T), theta.data_ptr(),
+                                      float(shift), float(alpha_scale), w.data_ptr(), float(gamma), int(reward_kind),
+                                      int(seed), int(first_step), int(traj_offset), L.PRECISIONS[precision],
+                                      float(lr_critic), float(lr_actor), bufs['reward'].data_ptr(),
+                                      bufs['delta'].data_ptr(), bufs['g'].data_ptr(), G.data_ptr(), _ptr(reward_acc),
+                                      ws.data_ptr(), ws.numel() * 8, _stream()), 'mfg_train_episode')
+    return pi
+
+
+def episode_buffers(B, d, device):
+    return {'scratch': torch.empty(B, d, dtype=torch.float32, device=device),
+            'reward': torch.empty(B, dtype=torch.float32, device=device),
+            'delta': torch.empty(B, dtype=torch.float64, device=device),
+            'g': torch.empty(B, dtype=torch.float64, device=device)}
 
 
 def jsd(p, q):

@@ -80,7 +80,10 @@ int mfg_device_info(int* cu_count_host, char* arch_host, int arch_len);
 int64_t mfg_feature_index(int i, int j, int d);
 int64_t mfg_num_features(int d);
 
-/* Bytes of scratch the gradient reductions need for N transitions of dimension d. */
+/* Bytes of scratch the gradient reductions need for N transitions of dimension d.  The last 64 bytes are a control
+ * block (completion counter of the in-kernel finalisation): zero the workspace ONCE after allocating it
+ * (hipMemset); every call leaves the control block zero again.  A workspace must not be shared by calls that can
+ * run concurrently on different streams. */
 size_t mfg_workspace_bytes(int64_t N, int d);
 
 /* a9: pi0[b,:] = mat_pi0[idx[b],:]                       (mfg_ac2.py:466-469) */
@@ -171,6 +174,20 @@ int mfg_reward_net_forward(const float* state, const float* action, int64_t B, i
  * evaluate_synthetic_JSD (sum_i JSD(P_i, implied row i), entries <= 0 -> 1e-100, :858-880). */
 int mfg_backward_value(const float* P, int64_t B, int T, int d, double* V, double* diff_l1, double* diff_jsd,
                        mfg_stream_t stream);
+
+/* a9, native inner loop of train() with the reference's per-step updates (mfg_ac2.py:478-525) on ONE GPU: for
+ * s < T: sample P ~ policy(pi), pi' = P^T pi, r, delta = r + gamma V(pi') - V(pi), g (a1-a7, one fused launch);
+ * batch sums over the B trajectories (a6/a8); w += lr_critic G_w/B, theta += lr_actor G_theta/B,
+ * *reward_acc += mean reward (if not NULL); pi <- pi'.  3T+... launches issued back to back from native code: no
+ * host round trip, no interpreter between dependent small kernels.  pi_io [B,d]: start states in, final states out;
+ * pi_scratch [B,d]; reward/delta/g [B] hold the last step's values on return; G [F+3]; workspace as for
+ * mfg_td_pg_accumulate(B).  Philox steps first_step .. first_step+T-1.  Multi-GPU jobs keep the per-step
+ * mfg_rollout(T=1) + all-reduce + mfg_apply_update sequence instead. */
+int mfg_train_episode(float* pi_io, float* pi_scratch, int64_t B, int d, int T, double* theta, double shift,
+                      double alpha_scale, double* w, double gamma, int reward_kind, uint64_t seed, uint32_t first_step,
+                      uint64_t traj_offset, int precision, double lr_critic, double lr_actor, float* reward, double* delta,
+                      double* g, double* G, double* reward_acc, void* workspace, size_t workspace_bytes,
+                      mfg_stream_t stream);
 
 /* f1 (optional importance weights, ac_irl.py:270-289 calc_pdf_action, :324-379 calc_z): log-density of the
  * product-Dirichlet policy for N (state, action) pairs under K policies theta_k (device array):

@@ -348,3 +348,24 @@ def test_irl_importance_weights_calc_z(dev):
     assert z.shape == (4,) and np.all(z >= 0)
     lq = ac.calc_pdf_action(8.64, trajs[0][0][1], trajs[0][0][0], log=True)
     assert abs(lq - O.policy_logpdf(np.float32(trajs[0][0][0])[None], np.float32(trajs[0][0][1])[None], [8.64], ac.shift)[0, 0]) < 1e-6 * abs(lq)
+
+
+@pytest.mark.parametrize('d,B,precision', [(21, 300, 'mixed'), (21, 7, 'f64'), (15, 64, 'mixed'), (47, 20, 'mixed'), (100, 5, 'mixed')])
+def test_native_episode_loop_equals_python_step_loop(dev, d, B, precision):
+    """mfg_train_episode (the whole 15-step episode with per-step updates issued natively) gives bit for bit what
+    the per-step Python sequence rollout(T=1) -> apply_update gives (same kernels, same order, same Philox steps)."""
+    rs = np.random.RandomState(d)
+    mat = rs.dirichlet(np.ones(d), size=9)
+    runs = []
+    for use_native in (True, False):
+        np.random.seed(21)
+        ac = AC(d=d, pi0=mat, batch=B, rng='philox', seed=5, update_every='step', precision=precision, verbose=0)
+        if not use_native:
+            ac.trace = []                       # tracing forces the per-step Python path
+        np.random.seed(22)
+        ac.train(num_episodes=3, gamma=0.95, constant=0, consecutive=2)
+        runs.append((np.ravel(ac.theta).copy(), ac.w.copy(), ac._last_pi.cpu().numpy().copy(), ac._rng_step))
+    assert runs[1][3] == runs[0][3] == 45
+    assert np.array_equal(runs[0][0], runs[1][0])
+    assert np.array_equal(runs[0][1], runs[1][1])
+    assert np.array_equal(runs[0][2], runs[1][2])
