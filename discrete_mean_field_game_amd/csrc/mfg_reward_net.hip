@@ -32,16 +32,32 @@ struct RewardNetArgs {
   int w3_in_lds;
 };
 
-constexpr int RN_BLOCK = 256, RN_WAVES = 4, RN_MAXF2 = 2, RN_MAXN = 32;
+#ifndef MFG_RN_WAVES
+#define MFG_RN_WAVES 8
+#endif
+#ifndef MFG_RN_P21
+#define MFG_RN_P21 25  // LDS row pitch of the padded tiles in the run-mapped kernel, d = 21 (>= 25)
+#endif
+#ifndef MFG_RN_P15
+#define MFG_RN_P15 19  // same, d = 15 (>= 19)
+#endif
+#ifndef MFG_RN_BPC
+#define MFG_RN_BPC 2
+#endif
+// 8 waves share one LDS copy of the FC3 weights (28 KB at d = 21, n3 = 8): 76 KB per block, 2 blocks per CU.
+constexpr int RN_WAVES = MFG_RN_WAVES, RN_BLOCK = RN_WAVES * WAVE, RN_MAXF2 = 2, RN_MAXN = 32;
 
 // PPMAX = max pixels per lane (ceil(d*d/64)).  K1 / K2 / F2 > 0: compile-time conv geometry (the reference always
 // uses k1 = 5, k2 = 3, f2 = 2, ac_irl.py:251-267): taps unroll, LDS reads get immediate offsets and can be issued
 // together; with run-time bounds every tap is a dependent ~100-cycle LDS round trip (the first version of this
 // kernel spent 30 us per sample that way).  0 = generic run-time value.
-template <int PPMAX, int K1, int K2, int F2>
+// D > 0: compile-time d (21 and 15, the reference's two sizes): pixel -> (row, column) needs no run-time division and
+// every tap of the convolutions is an immediate LDS offset (run-time d spent ~600 integer instructions per sample on
+// index arithmetic, more than the network's own FMAs).
+template <int PPMAX, int K1, int K2, int F2, int D>
 __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int d = a.d, dd = d * d, n3 = a.n3, n4 = a.n4;
+  const int d = D ? D : a.d, dd = d * d, n3 = a.n3, n4 = a.n4;
   const int k1 = K1 ? K1 : a.k1, k2 = K2 ? K2 : a.k2, f2 = F2 ? F2 : a.f2;
   const int h1 = k1 / 2, h2 = k2 / 2;
   const int W1 = d + 2 * h1, W2 = d + 2 * h2;  // padded widths of the input / conv1 maps
@@ -100,25 +116,39 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
   const float inv_keep = 1.0f / a.keep_prob;
   const bool drop = a.keep_prob < 1.0f;
   const int64_t nw = (int64_t)gridDim.x * RN_WAVES;
+  // pixel slots of this lane (p = lane + 64 q): offsets into the two padded tiles, computed once
+  int o1[PPMAX], o2[PPMAX];
+#pragma unroll
+  for (int q = 0; q < PPMAX; ++q) {
+    const int p = lane + q * WAVE;
+    const int pc = p < dd ? p : 0;
+    const int y = pc / d, x = pc - y * d;
+    o1[q] = y * W1 + x;
+    o2[q] = y * W2 + x;
+  }
   for (int64_t b = (int64_t)blockIdx.x * RN_WAVES + wv; b < a.B; b += nw) {
     const float* act = a.action + b * dd;
     // 1. action -> padded LDS tile
-    for (int p = lane; p < dd; p += WAVE) {
-      const int y = p / d, x = p - y * d;
-      tin[(y + h1) * W1 + x + h1] = act[p];
-    }
+    float av[PPMAX];
+#pragma unroll
+    for (int q = 0; q < PPMAX; ++q) av[q] = (lane + q * WAVE < dd) ? act[lane + q * WAVE] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < PPMAX; ++q)
+      if (lane + q * WAVE < dd) tin[o1[q] + h1 * W1 + h1] = av[q];
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     // 2. conv1 (cross-correlation, SAME) + ReLU -> padded conv1 map
-    for (int p = lane; p < dd; p += WAVE) {
-      const int y = p / d, x = p - y * d;
-      float s = sc1[k1 * k1];
-      const float* tp = tin + y * W1 + x;
 #pragma unroll
-      for (int dy = 0; dy < (K1 ? K1 : k1); ++dy)
+    for (int q = 0; q < PPMAX; ++q) {
+      if (lane + q * WAVE < dd) {
+        float s = sc1[k1 * k1];
+        const float* tp = tin + o1[q];
 #pragma unroll
-        for (int dx = 0; dx < (K1 ? K1 : k1); ++dx) s = fmaf(tp[dy * W1 + dx], sc1[dy * k1 + dx], s);
-      tc1[(y + h2) * W2 + x + h2] = fmaxf(s, 0.0f);
+        for (int dy = 0; dy < (K1 ? K1 : k1); ++dy)
+#pragma unroll
+          for (int dx = 0; dx < (K1 ? K1 : k1); ++dx) s = fmaf(tp[dy * W1 + dx], sc1[dy * k1 + dx], s);
+        tc1[o2[q] + h2 * W2 + h2] = fmaxf(s, 0.0f);
+      }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -126,16 +156,14 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
     float act2[PPMAX][RN_MAXF2];
 #pragma unroll
     for (int q = 0; q < PPMAX; ++q) {
-      const int p = lane + q * WAVE;
 #pragma unroll
       for (int c = 0; c < RN_MAXF2; ++c) act2[q][c] = 0.0f;
-      if (p < dd) {
-        const int y = p / d, x = p - y * d;
+      if (lane + q * WAVE < dd) {
 #pragma unroll
         for (int c = 0; c < RN_MAXF2; ++c) {
           if (c < f2) {
             float s = sc2[f2 * k2 * k2 + c];
-            const float* tp = tc1 + y * W2 + x;
+            const float* tp = tc1 + o2[q];
 #pragma unroll
             for (int dy = 0; dy < (K2 ? K2 : k2); ++dy)
 #pragma unroll
@@ -144,6 +172,13 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
           }
         }
       }
+    }
+    // dropout uniforms of this sample, all at once: lane o < 32 draws unit o of FC3, lane 32+o unit o of FC4 (same
+    // Philox counters as a per-unit draw; computing them one by one, wave-uniformly, was a third of the kernel)
+    float u_drop = 0.0f;
+    if (drop) {
+      const u32x4 r = philox_elem(a.seed, (uint32_t)(lane & 31), lane < 32 ? 3u : 4u, a.sample_offset + (uint64_t)b, 0);
+      u_drop = u01(r.x);
     }
     // 4. FC3 + ReLU (+ dropout): every lane ends up with all n3 activations it needs for FC4
     float h3_mine = 0.0f;  // lane o < n3 keeps h3[o]
@@ -162,10 +197,7 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
       }
       s = wave_sum(s);
       float h = fmaxf(s + s_b3[o], 0.0f);
-      if (drop) {
-        const u32x4 r = philox_elem(a.seed, (uint32_t)o, 3u, a.sample_offset + (uint64_t)b, 0);
-        h = (u01(r.x) <= a.keep_prob) ? h * inv_keep : 0.0f;
-      }
+      if (drop) h = (__shfl(u_drop, o, WAVE) <= a.keep_prob) ? h * inv_keep : 0.0f;
       if (lane == o) h3_mine = h;
     }
     // 5. FC4 over [h3, state] + ReLU (+ dropout): lane o < n4
@@ -177,14 +209,251 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
       const float* st = a.state + b * d;
       for (int k = 0; k < d; ++k) s = fmaf(st[k], s_w4[o * (n3 + d) + n3 + k], s);
       h4 = fmaxf(s, 0.0f);
-      if (drop) {
-        const u32x4 r = philox_elem(a.seed, (uint32_t)o, 4u, a.sample_offset + (uint64_t)b, 0);
-        h4 = (u01(r.x) <= a.keep_prob) ? h4 * inv_keep : 0.0f;
-      }
+      if (drop) h4 = (__shfl(u_drop, 32 + o, WAVE) <= a.keep_prob) ? h4 * inv_keep : 0.0f;
       h4 = (lane < n4) ? h4 * s_wo[o] : 0.0f;
     }
     // 6. output unit, tanh
     const float z = wave_sum(h4) + s_bo[0];
+    if (lane == 0) a.reward[b] = tanhf(z);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Run-mapped kernel for the reference geometry (k1 = 5, k2 = 3, f2 = 2) at compile-time d (21 and 15).
+// The pixel-per-lane kernel above is LDS bound (SQ_LDS_IDX_ACTIVE 78 % of the CU cycles, 28 % of them bank conflicts,
+// VALU 37 %): every tap of every pixel is its own LDS read.  Here a lane owns a horizontal RUN of pixels of one row
+// (RPR runs per row, RUN*RPR = d: 63 lanes at d = 21, 45 at d = 15); for each kernel row it reads the RUN+k-1 inputs
+// under its run once and slides the taps over them in registers: 55 + 27 LDS reads per sample instead of 175 + 63.
+// The run's 2*RUN FC3 inputs are contiguous in the NHWC-flattened weight rows (8-byte reads), the FC3 reductions run on
+// the DPP path instead of ds_bpermute, and the conv weights sit in scalar registers.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_f32_dpp(float v) {
+  v += dpp_mov_f32<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov_f32<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov_f32<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_mov_f32<0x140, 0xF>(v);  // row_mirror
+  v += dpp_mov_f32<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_mov_f32<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <int D, int RUN, int RPR, int P1, int P2>
+struct RunsGeom {
+  static_assert(RUN * RPR == D && D * RPR <= WAVE, "runs must tile a row exactly and fit one wavefront");
+  static constexpr int K1 = 5, K2 = 3, F2 = 2, H1 = 2, H2 = 1, DD = D * D;
+  static constexpr int T1 = (D + 2 * H1) * P1, T2 = (D + 2 * H2) * P2;  // floats per padded tile (pitches P1, P2)
+  static constexpr int PP = (DD + WAVE - 1) / WAVE;
+  static size_t lds_floats(int n3, int n4, bool w3_in_lds) {
+    size_t fl = (size_t)(n4 * (n3 + D) + 2 * n4 + 1 + n3);
+    fl = (fl + 3) & ~(size_t)3;
+    if (w3_in_lds) fl += (size_t)n3 * F2 * DD;
+    fl = (fl + 3) & ~(size_t)3;
+    return fl + (size_t)RN_WAVES * (T1 + T2);
+  }
+};
+
+template <int D, int RUN, int RPR, int P1, int P2>
+__global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
+  using Gm = RunsGeom<D, RUN, RPR, P1, P2>;
+  constexpr int K1 = Gm::K1, K2 = Gm::K2, F2 = Gm::F2, H1 = Gm::H1, H2 = Gm::H2, DD = Gm::DD, PP = Gm::PP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n3 = a.n3, n4 = a.n4, nin = n3 + D;  // FC4 input = [h3 (n3), state (D)], nin <= 64
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  float* s_w4 = smem;              // [n4][nin]
+  float* s_b4 = s_w4 + n4 * nin;
+  float* s_wo = s_b4 + n4;
+  float* s_bo = s_wo + n4;
+  float* s_b3 = s_bo + 1;
+  int off = n4 * nin + 2 * n4 + 1 + n3;
+  off = (off + 3) & ~3;
+  float* s3 = smem + off;
+  if (a.w3_in_lds) off += n3 * F2 * DD;
+  off = (off + 3) & ~3;
+  float* tin = smem + off + wv * (Gm::T1 + Gm::T2);
+  float* tc1 = tin + Gm::T1;
+  for (int k = tid; k < n4 * nin; k += RN_BLOCK) s_w4[k] = a.w4[k];
+  for (int k = tid; k < n4; k += RN_BLOCK) {
+    s_b4[k] = a.b4[k];
+    s_wo[k] = a.wo[k];
+  }
+  if (tid == 0) s_bo[0] = a.bo[0];
+  for (int k = tid; k < n3; k += RN_BLOCK) s_b3[k] = a.b3[k];
+  if (a.w3_in_lds) {
+    const int nq = (n3 * F2 * DD) >> 2;
+    const float4* src4 = reinterpret_cast<const float4*>(a.w3);
+    float4* dst4 = reinterpret_cast<float4*>(s3);
+    for (int k0 = 0; k0 < nq; k0 += 4 * RN_BLOCK) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * RN_BLOCK + tid;
+        v[u] = (k < nq) ? src4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * RN_BLOCK + tid;
+        if (k < nq) dst4[k] = v[u];
+      }
+    }
+    for (int k = (nq << 2) + tid; k < n3 * F2 * DD; k += RN_BLOCK) s3[k] = a.w3[k];
+  }
+  for (int k = lane; k < Gm::T1 + Gm::T2; k += WAVE) tin[k] = 0.0f;  // zero halos (interiors are rewritten)
+  // conv weights and biases: ONE gather per wave (lane t holds entry t of [c1w | c1b | c2w | c2b], 46 values), then
+  // v_readlane into scalar registers.  Plain `a.c1w[k]` reads are re-issued as vector loads for every sample (the
+  // compiler cannot prove that the reward store does not alias them) and sat on the critical path.
+  constexpr int NW1 = K1 * K1, NW2 = F2 * K2 * K2;
+  static_assert(NW1 + 1 + NW2 + F2 <= WAVE, "conv parameters must fit one wavefront");
+  float wtab;
+  {
+    const float* src = lane < NW1 ? a.c1w + lane
+                     : lane == NW1 ? a.c1b
+                     : lane < NW1 + 1 + NW2 ? a.c2w + (lane - NW1 - 1)
+                     : a.c2b + (lane < NW1 + 1 + NW2 + F2 ? lane - NW1 - 1 - NW2 : 0);
+    wtab = *src;
+  }
+  float w1[NW1], w2[F2][K2 * K2];
+#pragma unroll
+  for (int k = 0; k < NW1; ++k) w1[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), k));
+  const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1));
+#pragma unroll
+  for (int c = 0; c < F2; ++c)
+#pragma unroll
+    for (int k = 0; k < K2 * K2; ++k)
+      w2[c][k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 1 + c * K2 * K2 + k));
+  const float b20 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 1 + NW2));
+  const float b21 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 2 + NW2));
+  __syncthreads();
+  const float* w3g = a.w3;
+  const bool w3_lds = a.w3_in_lds != 0;
+  const float inv_keep = 1.0f / a.keep_prob;
+  const bool drop = a.keep_prob < 1.0f;
+  // this lane's run: row y, columns x0 .. x0+RUN-1
+  const bool active = lane < D * RPR;
+  const int y = active ? lane / RPR : 0, x0 = active ? (lane - y * RPR) * RUN : 0;
+  const float* win1 = tin + y * P1 + x0;                // top-left of the conv1 window in the padded input tile
+  float* out1 = tc1 + (y + H2) * P2 + x0 + H2;          // this run inside the padded conv1 map
+  const float* win2 = tc1 + y * P2 + x0;                // top-left of the conv2 window
+  const int w3off = (y * D + x0) * F2;                  // the run's 2*RUN inputs inside an FC3 weight row
+  int o1[PP];
+#pragma unroll
+  for (int q = 0; q < PP; ++q) {
+    const int p = lane + q * WAVE;
+    const int pc = p < DD ? p : 0;
+    o1[q] = (pc / D + H1) * P1 + pc % D + H1;
+  }
+  const int64_t nw = (int64_t)gridDim.x * RN_WAVES;
+  int64_t b = (int64_t)blockIdx.x * RN_WAVES + wv;
+  // software prefetch: the next sample's action (and state entry) is in flight while this one is evaluated
+  float av[PP], st_mine = 0.0f;
+#pragma unroll
+  for (int q = 0; q < PP; ++q) av[q] = (b < a.B && lane + q * WAVE < DD) ? a.action[b * DD + lane + q * WAVE] : 0.0f;
+  if (b < a.B && lane >= n3 && lane < nin) st_mine = a.state[b * D + (lane - n3)];
+  for (; b < a.B; b += nw) {
+    // 1. action -> padded LDS tile (coalesced global read, pixel p = lane + 64 q)
+#pragma unroll
+    for (int q = 0; q < PP; ++q)
+      if (lane + q * WAVE < DD) tin[o1[q]] = av[q];
+    const float st_cur = st_mine;
+    {
+      const int64_t bn = b + nw;
+#pragma unroll
+      for (int q = 0; q < PP; ++q) av[q] = (bn < a.B && lane + q * WAVE < DD) ? a.action[bn * DD + lane + q * WAVE] : 0.0f;
+      if (bn < a.B && lane >= n3 && lane < nin) st_mine = a.state[bn * D + (lane - n3)];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // 2. conv1 5x5 (cross-correlation, SAME) + ReLU over the run
+    float c1[RUN];
+#pragma unroll
+    for (int k = 0; k < RUN; ++k) c1[k] = b1;
+#pragma unroll
+    for (int dy = 0; dy < K1; ++dy) {
+      float row[RUN + K1 - 1];
+#pragma unroll
+      for (int t = 0; t < RUN + K1 - 1; ++t) row[t] = win1[dy * P1 + t];
+#pragma unroll
+      for (int k = 0; k < RUN; ++k)
+#pragma unroll
+        for (int dx = 0; dx < K1; ++dx) c1[k] = fmaf(row[k + dx], w1[dy * K1 + dx], c1[k]);
+    }
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < RUN; ++k) out1[k] = fmaxf(c1[k], 0.0f);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // 3. conv2 3x3, two filters + ReLU
+    float a2[RUN][F2];
+#pragma unroll
+    for (int k = 0; k < RUN; ++k) {
+      a2[k][0] = b20;
+      a2[k][1] = b21;
+    }
+#pragma unroll
+    for (int dy = 0; dy < K2; ++dy) {
+      float row[RUN + K2 - 1];
+#pragma unroll
+      for (int t = 0; t < RUN + K2 - 1; ++t) row[t] = win2[dy * P2 + t];
+#pragma unroll
+      for (int k = 0; k < RUN; ++k)
+#pragma unroll
+        for (int dx = 0; dx < K2; ++dx) {
+          a2[k][0] = fmaf(row[k + dx], w2[0][dy * K2 + dx], a2[k][0]);
+          a2[k][1] = fmaf(row[k + dx], w2[1][dy * K2 + dx], a2[k][1]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RUN; ++k) {
+      a2[k][0] = active ? fmaxf(a2[k][0], 0.0f) : 0.0f;
+      a2[k][1] = active ? fmaxf(a2[k][1], 0.0f) : 0.0f;
+    }
+    // dropout uniforms of this sample (lane o < 32: FC3 unit o, lane 32+o: FC4 unit o)
+    float u_drop = 0.0f;
+    if (drop) {
+      const u32x4 r = philox_elem(a.seed, (uint32_t)(lane & 31), lane < 32 ? 3u : 4u, a.sample_offset + (uint64_t)b, 0);
+      u_drop = u01(r.x);
+    }
+    // 4. FC3 + ReLU (+ dropout); lane o < n3 keeps unit o, lanes n3 .. n3+D-1 hold the state: `x4` is FC4's input
+    float x4 = (lane >= n3 && lane < nin) ? st_cur : 0.0f;
+#pragma unroll 2
+    for (int o = 0; o < n3; ++o) {
+      float s = 0.0f;
+      if (w3_lds) {
+        const float2* wr = reinterpret_cast<const float2*>(s3 + o * F2 * DD + w3off);
+#pragma unroll
+        for (int k = 0; k < RUN; ++k) {
+          const float2 wv2 = wr[k];
+          s = fmaf(a2[k][0], wv2.x, s);
+          s = fmaf(a2[k][1], wv2.y, s);
+        }
+      } else {
+        const float2* wr = reinterpret_cast<const float2*>(w3g + (int64_t)o * F2 * DD + w3off);
+#pragma unroll
+        for (int k = 0; k < RUN; ++k) {
+          const float2 wv2 = wr[k];
+          s = fmaf(a2[k][0], wv2.x, s);
+          s = fmaf(a2[k][1], wv2.y, s);
+        }
+      }
+      s = wave_sum_f32_dpp(s);
+      float h = fmaxf(s + s_b3[o], 0.0f);
+      if (drop) h = (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(u_drop), o)) <= a.keep_prob) ? h * inv_keep : 0.0f;
+      if (lane == o) x4 = h;
+    }
+    // 5. FC4 over [h3, state] + ReLU (+ dropout), 6. output unit: lane-parallel products, one DPP sum per unit
+    float z = s_bo[0];
+    for (int o = 0; o < n4; ++o) {
+      const float wgt = lane < nin ? s_w4[o * nin + lane] : 0.0f;
+      float h4 = fmaxf(wave_sum_f32_dpp(x4 * wgt) + s_b4[o], 0.0f);
+      if (drop) h4 = (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(u_drop), 32 + o)) <= a.keep_prob) ? h4 * inv_keep : 0.0f;
+      z = fmaf(h4, s_wo[o], z);
+    }
     if (lane == 0) a.reward[b] = tanhf(z);
     __builtin_amdgcn_wave_barrier();
   }
@@ -215,7 +484,7 @@ extern "C" int mfg_reward_net_forward(const float* state, const float* action, i
   fl = (fl + 3) & ~(size_t)3;
   const size_t w3fl = (size_t)n3 * f2 * dd;
   int64_t grid = (B + RN_WAVES - 1) / RN_WAVES;
-  if (grid > 256 * 3) grid = 256 * 3;
+  if (grid > 256 * MFG_RN_BPC) grid = 256 * MFG_RN_BPC;
   // stage the FC3 weights in LDS only when a block amortises the copy over enough samples (and the pointer is
   // 16-byte aligned); otherwise they are read straight from L2 (coalesced, 28 KB at d = 21)
   const int64_t samples_per_block = (B + grid - 1) / grid;
@@ -227,10 +496,20 @@ extern "C" int mfg_reward_net_forward(const float* state, const float* action, i
   const int pp = (dd + WAVE - 1) / WAVE;
   hipStream_t st = (hipStream_t)stream;
   const bool ref_geom = (k1 == 5 && k2 == 3 && f2 == 2);
-#define RN_LAUNCH(PP)                                                                                              \
-  if (ref_geom) hipLaunchKernelGGL((k_reward_net<PP, 5, 3, 2>), dim3((unsigned)grid), dim3(RN_BLOCK), lds, st, a); \
-  else hipLaunchKernelGGL((k_reward_net<PP, 0, 0, 0>), dim3((unsigned)grid), dim3(RN_BLOCK), lds, st, a);
-  if (pp <= 4) { RN_LAUNCH(4) }
+#define RN_LAUNCH(PP)                                                                                                 \
+  if (ref_geom) hipLaunchKernelGGL((k_reward_net<PP, 5, 3, 2, 0>), dim3((unsigned)grid), dim3(RN_BLOCK), lds, st, a); \
+  else hipLaunchKernelGGL((k_reward_net<PP, 0, 0, 0, 0>), dim3((unsigned)grid), dim3(RN_BLOCK), lds, st, a);
+  // w3 rows are read as float2 at even offsets: needs an 8-byte aligned fc3_w when it is not staged in LDS
+  const bool runs_ok = ref_geom && (a.w3_in_lds || (((uintptr_t)fc3_w & 7) == 0));
+  if (runs_ok && d == 21) {
+    using Gm = RunsGeom<21, 7, 3, MFG_RN_P21, MFG_RN_P21>;
+    hipLaunchKernelGGL((k_reward_net_runs<21, 7, 3, MFG_RN_P21, MFG_RN_P21>), dim3((unsigned)grid), dim3(RN_BLOCK),
+                       Gm::lds_floats(n3, n4, a.w3_in_lds != 0) * 4, st, a);
+  } else if (runs_ok && d == 15) {
+    using Gm = RunsGeom<15, 5, 3, MFG_RN_P15, MFG_RN_P15>;
+    hipLaunchKernelGGL((k_reward_net_runs<15, 5, 3, MFG_RN_P15, MFG_RN_P15>), dim3((unsigned)grid), dim3(RN_BLOCK),
+                       Gm::lds_floats(n3, n4, a.w3_in_lds != 0) * 4, st, a);
+  } else if (pp <= 4) { RN_LAUNCH(4) }
   else if (pp <= 7) { RN_LAUNCH(7) }
   else { RN_LAUNCH(16) }
 #undef RN_LAUNCH
