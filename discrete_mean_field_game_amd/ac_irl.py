@@ -155,6 +155,11 @@ class AC_IRL(actor_critic):
         dg = (torch.empty(shard.local_batch, dtype=torch.float64, device=self.device),
               torch.empty(shard.local_batch, dtype=torch.float64, device=self.device))
         rfn = reward_fn if reward_fn is not None else self.reward
+        Bl = shard.local_batch
+        # rollout(T=1) output buffers, reused every step (pi_last is a fresh tensor per step)
+        rbufs = {'pi_traj': torch.empty(Bl, 2, d, dtype=torch.float32, device=self.device),
+                 'P': torch.empty(Bl, 1, d, d, dtype=torch.float32, device=self.device),
+                 'delta': dg[0].view(Bl, 1), 'g': dg[1].view(Bl, 1)}
         prev_theta = float(self._theta.cpu()[0])
         list_reward = []
         episode = 0
@@ -165,23 +170,30 @@ class AC_IRL(actor_critic):
             total_reward = torch.zeros(1, dtype=torch.float64, device=self.device)
             sc, sa = lr_scales(episode, constant)          # lr/(episode+1) with the 1-indexed episode (:700)
             for step in range(T):
+                acc = (self.update_every == 'rollout' and step > 0)
                 if self.rng == 'philox':
-                    # sample P and take the transition in one launch (P materialised for the reward net)
-                    o = ops.rollout(pi, 1, self._theta, self.shift, self.alpha_scale, seed=self.seed,
-                                    first_step=self._rng_step, traj_offset=shard.traj_offset, td=False, write_P=True,
-                                    precision=self.precision)
+                    # ONE launch samples P, takes the transition and evaluates everything of the TD step that does not
+                    # need the reward (score g, gamma V(pi') - V(pi)); P is materialised for the reward network, whose
+                    # output is folded in by the gradient kernel (delta += r) -- no second pass over P
+                    o = ops.rollout(pi, 1, self._theta, self.shift, self.alpha_scale, w=self._w, gamma=discount,
+                                    reward_kind=L.REWARD_EXTERNAL, seed=self.seed, first_step=self._rng_step,
+                                    traj_offset=shard.traj_offset, td=True, write_P=True, precision=self.precision,
+                                    out=rbufs)
                     self._rng_step += 1
                     P = o['P'].view(shard.local_batch, d, d)
                     pi_next = o['pi_last']
+                    if write_all:
+                        self._write_all(pi, P, step + 1)
+                    r = rfn(pi, P)
+                    ops.grad_accumulate(pi, dg[0], dg[1], r, G, ws, add_reward=True, accumulate=acc)
                 else:
                     P = self._sample(pi, shard.traj_offset, snapshot=False)
                     pi_next, _ = ops.step_given_P(pi, P, want_reward=False)
-                if write_all:
-                    self._write_all(pi, P, step + 1)
-                r = rfn(pi, P)
-                ops.td_pg_accumulate(pi, pi_next, P, r, self._w, self._theta, self.shift, discount, G=G, ws=ws,
-                                     precision=self.precision, out=dg,
-                                     accumulate=(self.update_every == 'rollout' and step > 0))
+                    if write_all:
+                        self._write_all(pi, P, step + 1)
+                    r = rfn(pi, P)
+                    ops.td_pg_accumulate(pi, pi_next, P, r, self._w, self._theta, self.shift, discount, G=G, ws=ws,
+                                         precision=self.precision, out=dg, accumulate=acc)
                 if self.update_every == 'step':
                     all_reduce_gradients_(G, self.group)
                     ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta, total_reward)

@@ -662,6 +662,7 @@ struct GradArgs {
   int64_t nsb;      // number of sample-blocks (grid.x)
   double* partial;  // [nsb][F+3]
   // in-kernel finalisation by the last block to finish (k_grad_small with few rows): G, optional parameter update
+  int add_reward;     // delta_n <- delta_n + reward_n first (external reward arrived after the rollout); written back
   unsigned* counter;  // zero on entry, zero again on exit; NULL -> separate k_reduce_partials launch
   double* G;
   int accumulate, apply;
@@ -742,6 +743,11 @@ __global__ __launch_bounds__(BLOCK) void k_grad_partial(GradArgs a) {
   }
 }
 
+__global__ void k_add_reward(double* __restrict__ delta, const float* __restrict__ reward, int64_t N) {
+  for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < N; n += (int64_t)gridDim.x * blockDim.x)
+    delta[n] += (double)reward[n];
+}
+
 // Compile-time-d version for the packed sizes (d = 21, 15): lane = (sample slot g, row i), G = 64/D samples per
 // wave iteration.  Each lane keeps row i of  M = sum_n delta_n pi_n pi_n^T  in D fp64 registers; pi_n is broadcast
 // to the lanes of its slot through a per-wave LDS line.  ~70 instructions per 3 samples (the generic kernel above
@@ -761,6 +767,10 @@ __device__ __forceinline__ GradSample grad_load(const GradArgs& a, int64_t n, in
     s.de = a.delta[n];
     if (a.g) s.dg = a.g[n];
     if (a.reward) s.rr = (double)a.reward[n];
+    if (a.add_reward) {
+      s.de += s.rr;
+      if (i == 0) const_cast<double*>(a.delta)[n] = s.de;  // every lane of the slot has issued its load of delta[n] above
+    }
   }
   return s;
 }
@@ -957,7 +967,7 @@ static void grad_geometry(int64_t N, int d, int* chunk, int64_t* nsb, int* nob) 
 // `apply` (optional): also perform the parameter update; *applied tells whether it was done in-kernel.
 static int launch_grad(const float* pi, int64_t stride_b, const double* delta, const double* g, const float* reward,
                        int64_t N, int T, int d, double* G, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
-                       const ApplyArgs* apply = nullptr, bool* applied = nullptr) {
+                       const ApplyArgs* apply = nullptr, bool* applied = nullptr, bool add_reward = false) {
   if (applied) *applied = false;
   const int64_t FO = mfg_num_features(d) + 3;
   int chunk, nob;
@@ -978,7 +988,10 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
   a.chunk = chunk;
   a.nsb = nsb;
   a.partial = (double*)ws;
+  if (add_reward && !(d == 21 || d == 15))
+    hipLaunchKernelGGL(k_add_reward, dim3(grid_for(N, 256, 8)), dim3(256), 0, st, const_cast<double*>(delta), reward, N);
   if (d == 21 || d == 15) {
+    a.add_reward = add_reward ? 1 : 0;
     // one partial row per block; nsb rows fit the workspace by construction (grad_geometry)
     const int per = WAVE / d;
     const int64_t per_block_iter = (int64_t)WAVES * per * 2;  // samples one block covers per loop iteration
@@ -1077,7 +1090,7 @@ static int launch_core(const CoreArgs& a_in, bool sample, bool td, int precision
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 7; }
+int mfg_abi_version(void) { return 8; }
 
 int mfg_init(void) {
   if (!htab_ptr()) return fail(MFG_ELAUNCH, "%s", "mfg_init: no HIP device / table initialisation failed");
@@ -1380,10 +1393,13 @@ int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, 
   CHECK_BD();
   REQUIRE(T >= 1, "T < 1");
   REQUIRE(pi0 && theta, "null pointer");
-  REQUIRE(reward_kind == MFG_REWARD_MFG_AC2 || reward_kind == MFG_REWARD_SYNTHETIC, "fused rollout needs an in-kernel reward");
+  REQUIRE(reward_kind >= 0 && reward_kind <= 2, "bad reward_kind");
   const bool td = (flags & MFG_ROLLOUT_TD) != 0;
+  const bool ext = reward_kind == MFG_REWARD_EXTERNAL;
   REQUIRE(!(flags & MFG_ROLLOUT_WRITE_P) || P_out, "WRITE_P without P_out");
-  REQUIRE(!td || (w && delta && g && reward && pi_traj), "TD rollout needs w, delta, g, reward, pi_traj");
+  REQUIRE(!td || (w && delta && g && pi_traj && (reward || ext)), "TD rollout needs w, delta, g, reward, pi_traj");
+  REQUIRE(!(ext && td && G), "external reward: the batch sums need the reward, call mfg_grad_accumulate afterwards");
+  if (ext) reward = nullptr;
   CoreArgs a{};
   a.pi0 = pi0;
   a.theta = theta;
@@ -1411,6 +1427,17 @@ int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, 
   REQUIRE(workspace, "workspace is null");
   return launch_grad(pi_traj, (int64_t)(T + 1) * d, delta, g, reward, B * T, T, d, G, accumulate, workspace,
                      workspace_bytes, S(stream));
+}
+
+int mfg_grad_accumulate(const float* pi, int64_t stride_b, double* delta, const double* g, const float* reward, int64_t B,
+                        int T, int d, int add_reward, double* G, int accumulate, void* workspace, size_t workspace_bytes,
+                        mfg_stream_t stream) {
+  CHECK_BD();
+  REQUIRE(T >= 1 && stride_b >= (int64_t)T * d, "bad T / stride_b");
+  REQUIRE(pi && delta && G && workspace, "null pointer");
+  REQUIRE(!add_reward || reward, "add_reward without reward");
+  return launch_grad(pi, stride_b, delta, g, reward, B * T, T, d, G, accumulate, workspace, workspace_bytes, S(stream),
+                     nullptr, nullptr, add_reward != 0);
 }
 
 int mfg_train_episode(float* pi_io, float* pi_scratch, int64_t B, int d, int T, double* theta, double shift,

@@ -173,7 +173,10 @@ def rollout(pi0, T, theta, shift, alpha_scale, w=None, gamma=1.0, reward_kind=L.
     o = out or {}
     pi_traj = o.get('pi_traj') if 'pi_traj' in o else torch.empty(B, T + 1, d, dtype=torch.float32, device=dev)
     pi_last = o.get('pi_last') if 'pi_last' in o else torch.empty(B, d, dtype=torch.float32, device=dev)
-    reward = o.get('reward') if 'reward' in o else torch.empty(B, T, dtype=torch.float32, device=dev)
+    ext = int(reward_kind) == L.REWARD_EXTERNAL
+    if ext and G is not None:
+        raise ValueError('external reward: the batch sums need the reward; call grad_accumulate(add_reward=True) afterwards')
+    reward = None if ext else (o.get('reward') if 'reward' in o else torch.empty(B, T, dtype=torch.float32, device=dev))
     delta = g = None
     flags = 0
     if td:
@@ -181,10 +184,11 @@ def rollout(pi0, T, theta, shift, alpha_scale, w=None, gamma=1.0, reward_kind=L.
         flags |= L.ROLLOUT_TD
         delta = o.get('delta') if 'delta' in o else torch.empty(B, T, dtype=torch.float64, device=dev)
         g = o.get('g') if 'g' in o else torch.empty(B, T, dtype=torch.float64, device=dev)
-        if G is None:
-            G = torch.zeros(num_features(d) + 3, dtype=torch.float64, device=dev)
-        if ws is None:
-            ws = workspace(B * T, d, dev)
+        if not ext:
+            if G is None:
+                G = torch.zeros(num_features(d) + 3, dtype=torch.float64, device=dev)
+            if ws is None:
+                ws = workspace(B * T, d, dev)
     P = None
     if write_P:
         flags |= L.ROLLOUT_WRITE_P
@@ -195,11 +199,25 @@ def rollout(pi0, T, theta, shift, alpha_scale, w=None, gamma=1.0, reward_kind=L.
         flags |= L.ROLLOUT_F64
     L.check(L.lib().mfg_rollout(pi0.data_ptr(), B, d, T, theta.data_ptr(), float(shift), float(alpha_scale),
                                 _ptr(w) if td else None, float(gamma), int(reward_kind), int(seed), int(first_step),
-                                int(traj_offset), flags, pi_traj.data_ptr(), _ptr(pi_last), reward.data_ptr(), _ptr(delta),
+                                int(traj_offset), flags, pi_traj.data_ptr(), _ptr(pi_last), _ptr(reward), _ptr(delta),
                                 _ptr(g),
-                                _ptr(P), _ptr(G) if td else None, int(accumulate), _ptr(ws) if td else None,
-                                ws.numel() * 8 if (td and ws is not None) else 0, _stream()), 'mfg_rollout')
+                                _ptr(P), _ptr(G) if (td and not ext) else None, int(accumulate),
+                                _ptr(ws) if (td and not ext) else None,
+                                ws.numel() * 8 if (td and not ext and ws is not None) else 0, _stream()), 'mfg_rollout')
     return {'pi_traj': pi_traj, 'pi_last': pi_last, 'reward': reward, 'delta': delta, 'g': g, 'P': P, 'G': G}
+
+
+def grad_accumulate(pi, delta, g, reward, G, ws, T=1, stride_b=None, add_reward=False, accumulate=False):
+    """Batch sums G (+)= [sum delta phi | sum delta g | sum r | N] over B*T samples; add_reward: delta += reward first
+    (in place) -- the IRL step after the reward network has run."""
+    d = pi.shape[-1]
+    B = delta.numel() // T
+    if stride_b is None:
+        stride_b = (T + 1) * d if (pi.dim() == 3 and pi.shape[1] == T + 1) else T * d
+    L.check(L.lib().mfg_grad_accumulate(pi.data_ptr(), int(stride_b), delta.data_ptr(), _ptr(g), _ptr(reward), B, int(T), d,
+                                        int(bool(add_reward)), G.data_ptr(), int(bool(accumulate)), ws.data_ptr(),
+                                        ws.numel() * 8, _stream()), 'mfg_grad_accumulate')
+    return G
 
 
 def train_episode(pi, T, theta, shift, alpha_scale, w, gamma, lr_critic, lr_actor, G, ws, bufs, reward_kind=L.REWARD_MFG_AC2,

@@ -148,7 +148,10 @@ int mfg_apply_update(const double* G, int d, double lr_critic, double lr_actor, 
  *   pi_traj[B,T+1,d] fp32 (pi_traj[:,0] = pi0; may be NULL for env-only rollouts), pi_last[B,d] = final state
  *   (contiguous, may be NULL), reward[B,T] fp32, delta[B,T], g[B,T] fp64,
  *   P_out[B,T,d,d] fp32 when MFG_ROLLOUT_WRITE_P; G as in mfg_td_pg_accumulate over all B*T
- *   transitions when MFG_ROLLOUT_TD.  first_step offsets the RNG step counter. */
+ *   transitions when MFG_ROLLOUT_TD.  first_step offsets the RNG step counter.
+ *   reward_kind = MFG_REWARD_EXTERNAL (the IRL step: the reward network needs the sampled action first,
+ *   ac_irl.py:679-691): `reward` is not touched, delta = gamma V(pi') - V(pi) WITHOUT the reward, G must be NULL;
+ *   finish with mfg_grad_accumulate(add_reward = 1) once the rewards exist. */
 int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, double shift,
                 double alpha_scale, const double* w, double gamma, int reward_kind, uint64_t seed,
                 uint32_t first_step, uint64_t traj_offset, int flags, float* pi_traj, float* pi_last,
@@ -174,6 +177,15 @@ int mfg_reward_net_forward(const float* state, const float* action, int64_t B, i
  * evaluate_synthetic_JSD (sum_i JSD(P_i, implied row i), entries <= 0 -> 1e-100, :858-880). */
 int mfg_backward_value(const float* P, int64_t B, int T, int d, double* V, double* diff_l1, double* diff_jsd,
                        mfg_stream_t stream);
+
+/* a6/a8 batch sums on their own: G (+)= [sum delta phi(pi) | sum delta g | sum reward | N] over the B*T samples
+ * n = (b, s), pi_n = pi + b*stride_b + s*d (stride_b = (T+1)*d for a pi_traj, d for a plain [B,d] batch).
+ * add_reward != 0: first delta_n <- delta_n + reward_n, written back -- the IRL step, where the rollout
+ * (reward_kind = MFG_REWARD_EXTERNAL) leaves delta = gamma V(pi') - V(pi) and the reward network (ac_irl.py:683)
+ * runs in between (:691).  Workspace as for mfg_td_pg_accumulate(B*T). */
+int mfg_grad_accumulate(const float* pi, int64_t stride_b, double* delta, const double* g, const float* reward, int64_t B,
+                        int T, int d, int add_reward, double* G, int accumulate, void* workspace, size_t workspace_bytes,
+                        mfg_stream_t stream);
 
 /* a9, native inner loop of train() with the reference's per-step updates (mfg_ac2.py:478-525) on ONE GPU: for
  * s < T: sample P ~ policy(pi), pi' = P^T pi, r, delta = r + gamma V(pi') - V(pi), g (a1-a7, one fused launch);

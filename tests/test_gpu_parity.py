@@ -419,3 +419,49 @@ def test_step_given_P_misaligned_pointers(dev, d, B, off):
     assert rel(got_r.cpu().numpy(), want_r.cpu().numpy(), floor=1e-3) < 1e-6
     ref_pi = O().transition(P.astype(np.float64), pi.astype(np.float64))
     np.testing.assert_allclose(got_pi.cpu().numpy(), ref_pi, rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize('d,B', [(21, 100), (15, 64), (47, 9), (100, 5), (4, 33)])
+@pytest.mark.parametrize('precision,gtol', [('f64', 1e-9), ('mixed', 1e-5)])
+def test_external_reward_step_equals_two_pass_step(dev, d, B, precision, gtol):
+    """The IRL step (ac_irl.py:679-708): rollout(T=1, reward_kind=EXTERNAL) leaves delta = disc*V(pi') - V(pi) and g,
+    mfg_grad_accumulate(add_reward) folds the network's reward in -- same actions, same sums as sampling P first and
+    running mfg_td_pg_accumulate on it afterwards, and both agree with the oracle on the sampled actions."""
+    from discrete_mean_field_game_amd import _lib as L
+    o_ = ops()
+    rs = np.random.RandomState(d + B)
+    pi = t32(rs.dirichlet(np.ones(d), size=B), dev)
+    w = t64(rs.rand(o_.num_features(d)), dev)
+    th = t64([8.64], dev)
+    disc = 0.81
+    a = o_.rollout(pi, 1, th, 0.0, 1e4, seed=9, first_step=4, td=False, write_P=True, precision=precision)
+    P = a['P'].view(B, d, d)
+    r = torch.tanh(5.0 * torch.einsum('bi,bii->b', pi, P) - 0.3).contiguous()           # any reward of (pi, P)
+    ws = o_.workspace(B, d, dev)
+    Ga = torch.zeros(o_.num_features(d) + 3, dtype=torch.float64, device=dev)
+    da, ga, _ = o_.td_pg_accumulate(pi, a['pi_last'], P, r, w, th, 0.0, disc, G=Ga, ws=ws, precision=precision)
+    b = o_.rollout(pi, 1, th, 0.0, 1e4, w=w, gamma=disc, reward_kind=L.REWARD_EXTERNAL, seed=9, first_step=4, td=True,
+                   write_P=True, precision=precision)
+    assert b['reward'] is None and torch.equal(b['P'], a['P']) and torch.equal(b['pi_last'], a['pi_last'])
+    Gb = torch.zeros_like(Ga)
+    delta = b['delta'].view(B).clone()
+    o_.grad_accumulate(pi, delta, b['g'].view(B), r, Gb, ws, add_reward=True)
+    assert rel(delta.cpu().numpy(), da.cpu().numpy(), floor=1e-3) < 1e-12
+    gt = max(gtol, 2e-7)      # fused: ln P = ln y - ln S; two-pass: ln of the fp32-rounded P
+    assert rel(b['g'].view(B).cpu().numpy(), ga.cpu().numpy(), floor=1.0) < gt
+    Q = o_.num_features(d)
+    assert rel(Gb[:Q].cpu().numpy(), Ga[:Q].cpu().numpy(), floor=float(Ga[:Q].abs().max())) < 1e-12
+    assert abs(float(Gb[Q]) - float(Ga[Q])) <= gt * max(1.0, float((da * ga).abs().sum()))
+    assert abs(float(Gb[Q + 1]) - float(Ga[Q + 1])) <= 1e-12 * max(1.0, abs(float(Ga[Q + 1])))
+    assert float(Gb[Q + 2]) == B
+    # oracle on the sampled actions
+    dl, gg, G_w, G_t, _ = O().batched_td_pg(pi.cpu().numpy(), a['pi_last'].cpu().numpy(), P.cpu().numpy().astype(np.float64),
+                                            r.cpu().numpy().astype(np.float64), w.cpu().numpy(), 8.64, 0.0, disc)
+    assert rel(delta.cpu().numpy(), dl, floor=1e-2) < 1e-5
+    assert rel(Gb[:Q].cpu().numpy(), G_w, floor=float(np.abs(G_w).max())) < 1e-5
+    # accumulate=True adds a second identical batch
+    o_.grad_accumulate(pi, b['delta'].view(B).clone(), b['g'].view(B), r, Gb, ws, add_reward=True, accumulate=True)
+    assert rel(Gb[:Q].cpu().numpy(), 2 * Ga[:Q].cpu().numpy(), floor=float(Ga[:Q].abs().max())) < 1e-12
+    # misuse is refused
+    with pytest.raises(Exception):
+        o_.rollout(pi, 1, th, 0.0, 1e4, w=w, reward_kind=L.REWARD_EXTERNAL, td=True, G=Ga, ws=ws)
