@@ -4,7 +4,10 @@
 #include <cstdint>
 #include <cstdio>
 
-constexpr int ITERS = 4096, CHAINS = 8;
+#ifndef MFG_CHAINS
+#define MFG_CHAINS 8
+#endif
+constexpr int ITERS = 4096, CHAINS = MFG_CHAINS;
 
 #define OP_KERNEL(NAME, TYPE, INIT, BODY)                                            \
   __global__ __launch_bounds__(256) void NAME(TYPE* out, TYPE seed) {                \
