@@ -940,7 +940,8 @@ static int grid_for(int64_t work_items, int per_block, int blocks_per_cu) {
   return (int)g;
 }
 
-constexpr size_t MFG_WS_CONTROL_BYTES = 64;  // trailing control block of the workspace (completion counter), kept zero
+constexpr size_t MFG_WS_CONTROL_BYTES = 64;  // control block at the START of the workspace (completion counter), kept zero:
+                                              // a fixed place, whatever N a call is made with; partial rows follow it
 constexpr int MFG_GRAD_FUSE_MAX_ROWS = 32;   // in-kernel finalisation up to this many partial rows
 
 struct ApplyArgs {
@@ -987,7 +988,7 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
   a.d = d;
   a.chunk = chunk;
   a.nsb = nsb;
-  a.partial = (double*)ws;
+  a.partial = reinterpret_cast<double*>((char*)ws + MFG_WS_CONTROL_BYTES);
   if (add_reward && !(d == 21 || d == 15))
     hipLaunchKernelGGL(k_add_reward, dim3(grid_for(N, 256, 8)), dim3(256), 0, st, const_cast<double*>(delta), reward, N);
   if (d == 21 || d == 15) {
@@ -1007,7 +1008,7 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
     a.nsb = blocks;
     const bool fuse = blocks <= MFG_GRAD_FUSE_MAX_ROWS;
     if (fuse) {
-      a.counter = reinterpret_cast<unsigned*>((char*)ws + (size_t)(nsb * FO * 8));
+      a.counter = reinterpret_cast<unsigned*>(ws);
       a.G = G;
       a.accumulate = accumulate;
       if (apply) {
@@ -1024,13 +1025,13 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
     else hipLaunchKernelGGL((k_grad_small<15>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
     if (fuse) return check_launch("grad_small");
     hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
-                       (const double*)ws, blocks, FO, accumulate, G);
+                       (const double*)a.partial, blocks, FO, accumulate, G);
     return check_launch("grad_small");
   }
   const size_t lds = (size_t)chunk * 3 * 8 + (size_t)chunk * d * 4;
   hipLaunchKernelGGL(k_grad_partial, dim3((unsigned)nsb, (unsigned)nob), dim3(BLOCK), lds, st, a);
   hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
-                     (const double*)ws, nsb, FO, accumulate, G);
+                     (const double*)a.partial, nsb, FO, accumulate, G);
   return check_launch("grad_reduce");
 }
 

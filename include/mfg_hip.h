@@ -80,9 +80,10 @@ int mfg_device_info(int* cu_count_host, char* arch_host, int arch_len);
 int64_t mfg_feature_index(int i, int j, int d);
 int64_t mfg_num_features(int d);
 
-/* Bytes of scratch the gradient reductions need for N transitions of dimension d.  The last 64 bytes are a control
+/* Bytes of scratch the gradient reductions need for N transitions of dimension d.  The first 64 bytes are a control
  * block (completion counter of the in-kernel finalisation): zero the workspace ONCE after allocating it
- * (hipMemset); every call leaves the control block zero again.  A workspace must not be shared by calls that can
+ * (hipMemset); every call leaves the control block zero again, so one workspace sized for the largest N serves
+ * calls with any smaller N.  A workspace must not be shared by calls that can
  * run concurrently on different streams. */
 size_t mfg_workspace_bytes(int64_t N, int d);
 

@@ -465,3 +465,23 @@ def test_external_reward_step_equals_two_pass_step(dev, d, B, precision, gtol):
     # misuse is refused
     with pytest.raises(Exception):
         o_.rollout(pi, 1, th, 0.0, 1e4, w=w, reward_kind=L.REWARD_EXTERNAL, td=True, G=Ga, ws=ws)
+
+
+def test_one_workspace_serves_calls_of_different_sizes(dev):
+    """A workspace sized for the largest batch is reused by smaller calls (a 15-step rollout, then single steps):
+    the completion counter of the in-kernel finalisation lives at a fixed place, not behind the rows of one N."""
+    o_ = ops()
+    d, B, T = 21, 3000, 15
+    rs = np.random.RandomState(1)
+    pi = t32(rs.dirichlet(np.ones(d), size=B), dev)
+    w = t64(rs.rand(o_.num_features(d)), dev)
+    th = t64([8.86349], dev)
+    ws = o_.workspace(B * T, d, dev)
+    big = o_.rollout(pi, T, th, 0.16, 12000.0, w=w, seed=1, td=True, ws=ws)
+    for n in (B, 7, 500, 64):
+        sub = pi[:n].contiguous()
+        a = o_.rollout(sub, 1, th, 0.16, 12000.0, w=w, seed=2, td=True, ws=ws)                 # shared, oversized
+        b = o_.rollout(sub, 1, th, 0.16, 12000.0, w=w, seed=2, td=True)                        # its own workspace
+        assert torch.equal(a['G'], b['G']) and float(a['G'][-1]) == n
+    again = o_.rollout(pi, T, th, 0.16, 12000.0, w=w, seed=1, td=True, ws=ws)
+    assert torch.equal(again['G'], big['G'])
