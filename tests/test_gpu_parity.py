@@ -485,3 +485,72 @@ def test_one_workspace_serves_calls_of_different_sizes(dev):
         assert torch.equal(a['G'], b['G']) and float(a['G'][-1]) == n
     again = o_.rollout(pi, T, th, 0.16, 12000.0, w=w, seed=1, td=True, ws=ws)
     assert torch.equal(again['G'], big['G'])
+
+
+@pytest.mark.parametrize('d', [1, 2, 63, 511, 512])
+def test_extreme_dimensions_against_oracle(dev, d):
+    """Smallest and largest supported d (MFG_MAX_D = 512) through every stage: given-P step, TD/score, fused rollout."""
+    o_ = ops()
+    B, T = (3, 2) if d >= 511 else (7, 3)
+    rs = np.random.RandomState(d)
+    pi, P = rand_case(rs, B, d)
+    w = rs.rand(O().num_features(d))
+    theta, shift, scale = 4.0, 0.05, 500.0
+    pn, r = o_.step_given_P(t32(pi, dev), t32(P, dev))
+    np.testing.assert_allclose(pn.cpu().numpy(), O().transition(P.astype(np.float64), pi.astype(np.float64)), rtol=0, atol=2e-7)
+    r_ref = O().calc_reward(P.astype(np.float64), pi.astype(np.float64))
+    assert rel(r.cpu().numpy(), r_ref, floor=1e-6) < 1e-5
+    for precision, gtol in (('f64', 1e-9), ('mixed', 1e-5)):
+        dl, gg, G = o_.td_pg_accumulate(t32(pi, dev), pn, t32(P, dev), r, t64(w, dev), t64([theta], dev), shift, 0.9,
+                                        precision=precision)
+        d_ref, g_ref, G_w, G_t, _ = O().batched_td_pg(pi, pn.cpu().numpy(), P, r.cpu().numpy().astype(np.float64), w, theta,
+                                                      shift, 0.9)
+        assert rel(dl.cpu().numpy(), d_ref, floor=1e-2) < 1e-9
+        assert rel(gg.cpu().numpy(), g_ref, floor=1.0) < gtol
+        F = O().num_features(d)
+        assert rel(G[:F].cpu().numpy(), G_w, floor=float(np.abs(G_w).max()) + 1e-300) < 1e-9
+    out = o_.rollout(t32(pi, dev), T, t64([theta], dev), shift, scale, w=t64(w, dev), gamma=0.9, seed=5, td=True, write_P=True)
+    Pk = out['P'].cpu().numpy()
+    assert np.max(np.abs(Pk.astype(np.float64).sum(-1) - 1)) < 2e-6 and Pk.min() >= 0
+    traj, R, D, Gs, _, _ = O().batched_rollout_given_P(pi, Pk, w, theta, shift, gamma=0.9)
+    np.testing.assert_allclose(out['pi_traj'].cpu().numpy(), traj, rtol=0, atol=3e-7)
+    assert rel(out['reward'].cpu().numpy(), R, floor=1e-6) < 1e-4
+    assert rel(out['delta'].cpu().numpy(), D, floor=1e-2) < 1e-5
+    assert rel(out['g'].cpu().numpy(), Gs, floor=1.0) < 1e-5
+
+
+def test_empty_batches_and_bad_arguments(dev):
+    """B = 0 is a no-op everywhere; undersized workspaces, null pointers and d > 512 are refused with an error code
+    and a message instead of a launch."""
+    from discrete_mean_field_game_amd import _lib as L
+    o_ = ops()
+    d = 21
+    th = t64([8.0], dev)
+    w = t64(np.zeros(o_.num_features(d)), dev)
+    e2 = torch.zeros(0, d, device=dev)
+    e3 = torch.zeros(0, d, d, device=dev)
+    assert o_.sample_dirichlet(e2, th, 0.1, 100.0, seed=1).shape == (0, d, d)
+    out = o_.rollout(e2, 3, th, 0.1, 100.0, w=w, seed=1, td=True)
+    assert out['pi_traj'].shape == (0, 4, d) and out['delta'].shape == (0, 3)
+    assert o_.jsd(e2, e2).shape == (0,)
+    assert o_.value(e2, w).shape == (0,)
+    lib = L.lib()
+    pi = torch.rand(8, d, device=dev)
+    P = torch.rand(8, d, d, device=dev)
+    buf = torch.zeros(8, d, device=dev)
+    r = torch.zeros(8, device=dev)
+    dl = torch.zeros(8, dtype=torch.float64, device=dev)
+    G = torch.zeros(o_.num_features(d) + 3, dtype=torch.float64, device=dev)
+    small = torch.zeros(4, dtype=torch.float64, device=dev)
+    rc = lib.mfg_td_pg_accumulate(pi.data_ptr(), buf.data_ptr(), P.data_ptr(), r.data_ptr(), w.data_ptr(), th.data_ptr(), 0.1,
+                                  1.0, 8, d, L.PRECISION_MIXED, dl.data_ptr(), dl.data_ptr(), G.data_ptr(), 0,
+                                  small.data_ptr(), small.numel() * 8, None)
+    assert rc == -4 and b'workspace' in lib.mfg_last_error()                     # MFG_EWORKSPACE
+    assert lib.mfg_step_given_P(None, P.data_ptr(), 8, d, 0, buf.data_ptr(), r.data_ptr(), None) == -1   # MFG_EINVAL
+    assert lib.mfg_step_given_P(pi.data_ptr(), P.data_ptr(), 8, 513, 0, buf.data_ptr(), r.data_ptr(), None) == -3
+    assert lib.mfg_step_given_P(pi.data_ptr(), P.data_ptr(), 8, d, 7, buf.data_ptr(), r.data_ptr(), None) == -1
+    assert lib.mfg_rollout(pi.data_ptr(), 8, d, 0, th.data_ptr(), 0.1, 100.0, None, 1.0, 0, 1, 0, 0, 0, None, None, None, None,
+                           None, None, None, 0, None, 0, None) == -1             # T < 1
+    torch.cuda.synchronize()                                                     # nothing was launched, nothing is broken
+    pn, _ = o_.step_given_P(pi, P)
+    assert torch.isfinite(pn).all()
