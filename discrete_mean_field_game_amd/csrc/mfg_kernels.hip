@@ -780,7 +780,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_small(GradArgs a) {
   constexpr int G = WAVE / D, Q = D * (D + 1) / 2, F = Q + D + 1, FO = F + 3;
   __shared__ double line[WAVES][2][G * D];  // fp64 so the inner loop is one LDS read + one FMA per product
   __shared__ double red[D * D + D + 4];
-  __shared__ double slots[WAVES * G][D * D + D + 4];
+  __shared__ double rows[WAVES][D * D + D + 4];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
   const int g = lane / D, i = lane - g * D;
   const bool act = g < G;
@@ -817,26 +817,31 @@ __global__ __launch_bounds__(BLOCK) void k_grad_small(GradArgs a) {
     c0 = x0;
     c1 = x1;
   }
-  // block reduction in a fixed (wave, slot) order: every slot parks its sums in LDS, then each output is added up
-  // over the WAVES*G slots by one thread (two barriers instead of one per slot)
-  constexpr int NS = WAVES * G, RW = D * D + D + 4;
-  if (act) {
-    double* mine = slots[wv * G + g];
+  // block reduction in a fixed (slot, wave) order: inside a wave the G slots fold into the wave's LDS row one after
+  // the other (wave-local barriers only), then each output is added up over the WAVES rows by one thread.  (One row
+  // per slot needed 45 KB of LDS and cost a block per CU; one barrier per slot cost ~4 us on the small-batch path.)
+  constexpr int RW = D * D + D + 4;
+  double* mine = rows[wv];
+  for (int q = 0; q < G; ++q) {
+    if (act && g == q) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) mine[i * D + j] = acc[j];
-    mine[D * D + i] = lin;
-    if (i == 0) {
-      mine[D * D + D + 0] = s_d;
-      mine[D * D + D + 1] = s_dg;
-      mine[D * D + D + 2] = s_r;
-      mine[D * D + D + 3] = s_n;
+      for (int j = 0; j < D; ++j) mine[i * D + j] = (q == 0 ? 0.0 : mine[i * D + j]) + acc[j];
+      mine[D * D + i] = (q == 0 ? 0.0 : mine[D * D + i]) + lin;
+      if (i == 0) {
+        mine[D * D + D + 0] = (q == 0 ? 0.0 : mine[D * D + D + 0]) + s_d;
+        mine[D * D + D + 1] = (q == 0 ? 0.0 : mine[D * D + D + 1]) + s_dg;
+        mine[D * D + D + 2] = (q == 0 ? 0.0 : mine[D * D + D + 2]) + s_r;
+        mine[D * D + D + 3] = (q == 0 ? 0.0 : mine[D * D + D + 3]) + s_n;
+      }
     }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
   }
   __syncthreads();
   for (int k = tid; k < RW; k += BLOCK) {
-    double t = slots[0][k];
+    double t = rows[0][k];
 #pragma unroll
-    for (int q = 1; q < NS; ++q) t += slots[q][k];
+    for (int q = 1; q < WAVES; ++q) t += rows[q][k];
     red[k] = t;
   }
   __syncthreads();
