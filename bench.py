@@ -280,7 +280,7 @@ def main():
         out = {
             'metric': 'env-steps/sec for batched d-bin population rollouts', 'value': value, 'unit': 'env-steps/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32 storage + f32 hw transcendentals / f64 accumulate',
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32 (f64 accumulate)',
             'data': 'synthetic',
             'config': {'workload': 'forward-RL actor-critic training rollouts (mfg_ac2.train, update per rollout): '
                                    'd=%d topics, T=%d, batch=%d trajectories per GPU' % (d, T, B),
