@@ -554,3 +554,49 @@ def test_empty_batches_and_bad_arguments(dev):
     torch.cuda.synchronize()                                                     # nothing was launched, nothing is broken
     pn, _ = o_.step_given_P(pi, P)
     assert torch.isfinite(pn).all()
+
+
+def _sweep_cases():
+    rs = np.random.RandomState(2024)
+    cases = []
+    for _ in range(36):
+        cases.append((int(rs.randint(1, 65)), int(rs.randint(1, 70)), int(rs.randint(1, 5))))
+    for _ in range(8):
+        cases.append((int(rs.randint(65, 400)), int(rs.randint(1, 9)), int(rs.randint(1, 3))))
+    return cases
+
+
+@pytest.mark.parametrize('d,B,T', _sweep_cases())
+def test_random_shape_sweep(dev, d, B, T):
+    """Seeded sweep over (d, B, T): every packing (G = 64/d trajectories per wave, odd/even d, ragged last tile,
+    1..7 columns per lane above d = 64) through the fused rollout, the given-P kernel and the gradient sums."""
+    o_ = ops()
+    rs = np.random.RandomState(1000 * d + B)
+    theta, shift, scale, gamma = float(rs.uniform(1, 12)), float(rs.uniform(0, 0.3)), float(10 ** rs.uniform(1, 4.5)), 0.93
+    pi0 = rs.dirichlet(np.ones(d) * rs.choice([0.3, 1.0, 5.0]), size=B).astype(np.float32)
+    w = rs.rand(O().num_features(d))
+    precision = 'mixed' if (d + B) % 2 else 'f64'
+    out = o_.rollout(t32(pi0, dev), T, t64([theta], dev), shift, scale, w=t64(w, dev), gamma=gamma, seed=d * 7 + B,
+                     first_step=3, traj_offset=11, td=True, write_P=True, precision=precision)
+    P = out['P'].cpu().numpy()
+    assert np.isfinite(P).all() and P.min() >= 0 and np.max(np.abs(P.astype(np.float64).sum(-1) - 1)) < 2e-6
+    traj, R, D, Gs, G_w, G_t = O().batched_rollout_given_P(pi0, P, w, theta, shift, gamma=gamma)
+    np.testing.assert_allclose(out['pi_traj'].cpu().numpy(), traj, rtol=0, atol=3e-7)
+    pt = out['pi_traj'].cpu().numpy().astype(np.float64)
+    r_ref = np.stack([O().calc_reward(P[:, t].astype(np.float64), pt[:, t]) for t in range(T)], 1)
+    assert rel(out['reward'].cpu().numpy(), r_ref, floor=1e-6) < 1e-5
+    g_ref = np.stack([O().calc_gradient(P[:, t], pt[:, t], theta, shift) for t in range(T)], 1)
+    assert rel(out['g'].cpu().numpy(), g_ref, floor=1.0) < 1e-5
+    V = O().calc_features(pt).dot(w)
+    d_ref = out['reward'].cpu().numpy().astype(np.float64) + gamma * V[:, 1:] - V[:, :-1]
+    assert np.max(np.abs(out['delta'].cpu().numpy() - d_ref)) < 1e-6 * max(1.0, np.abs(V).max())
+    dl, gg = out['delta'].cpu().numpy(), out['g'].cpu().numpy()
+    F = O().num_features(d)
+    Gw_ref = np.einsum('bt,btf->f', dl, O().calc_features(pt)[:, :T])
+    Gh = out['G'].cpu().numpy()
+    assert np.max(np.abs(Gh[:F] - Gw_ref)) <= 1e-10 * (np.abs(Gw_ref).max() + 1e-300)
+    assert abs(Gh[F] - np.sum(dl * gg)) <= 1e-9 * max(1.0, np.abs(dl * gg).sum())
+    assert Gh[F + 2] == B * T
+    pn, r1 = o_.step_given_P(out['pi_traj'][:, 0].contiguous(), out['P'][:, 0].contiguous())
+    assert torch.equal(pn, out['pi_traj'][:, 1])
+    assert rel(r1.cpu().numpy(), out['reward'][:, 0].cpu().numpy(), floor=1e-6) < 2e-6
