@@ -63,6 +63,41 @@ __global__ __launch_bounds__(256) void k_tiles(const v4f* __restrict__ x, int64_
   if (s == 123.456f) out[0] = s;
 }
 
+
+// same tile pattern, but the loads write straight into LDS (global_load_lds_dwordx4, no VGPR hop, no ds_write):
+// double-buffered tiles, one wave instruction moves 64 x 16 B = 1 KiB to M0-based LDS addresses
+__global__ __launch_bounds__(256) void k_tiles_dma(const v4f* __restrict__ x, int64_t ntiles, int tile4, float* out) {
+  extern __shared__ v4f lds[];  // [2][tile4 rounded up to 64]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int CH = 6;                    // chunks per wave per tile: always issued, so vmcnt(CH) is exact
+  const int pitch = 4 * CH * 64;           // float4 per buffer (24 KiB); lanes past the tile load a dummy address
+  v4f acc = (v4f)(0.0f);
+  auto fetch = [&](int64_t t, int buf) {
+    const v4f* s = x + t * tile4;
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+      const int c = wv + 4 * u;
+      const int k = c * 64 + lane;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s + (k < tile4 ? k : 0)),
+                                       (__attribute__((address_space(3))) void*)(lds + buf * pitch + c * 64), 16, 0, 0);
+    }
+  };
+  int buf = 0;
+  if ((int64_t)blockIdx.x < ntiles) fetch(blockIdx.x, 0);
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    if (t + gridDim.x < ntiles) fetch(t + gridDim.x, buf ^ 1);
+    // wait for the CURRENT tile only: the prefetch just issued may stay in flight
+    if (t + gridDim.x < ntiles) __builtin_amdgcn_s_waitcnt(0x0f70 | 6);  // vmcnt(6): this wave's 6 newest loads pending
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    acc += lds[buf * pitch + (tid * 7) % tile4];
+    __syncthreads();
+    buf ^= 1;
+  }
+  const float s = acc.x + acc.y + acc.z + acc.w;
+  if (s == 123.456f) out[0] = s;
+}
+
 template <typename F>
 static double time_ms(F launch, int reps = 10) {
   hipEvent_t e0, e1;
@@ -110,6 +145,12 @@ int main() {
     printf("tiles 21 KB, regs    %2d blocks/CU  %.2f TB/s\n", bpc, (double)ntiles * tile4 * 16 / t / 1e9);
     t = time_ms([&] { hipLaunchKernelGGL((k_tiles<6, true>), dim3(grid), dim3(256), tile4 * 16, 0, (const v4f*)x, ntiles, tile4, (float*)out); });
     printf("tiles 21 KB, LDS+bar %2d blocks/CU  %.2f TB/s\n", bpc, (double)ntiles * tile4 * 16 / t / 1e9);
+  }
+  for (int bpc : {2, 3}) {
+    const int grid = cus * bpc;
+    const int pitch = 4 * 6 * 64;
+    const double t = time_ms([&] { hipLaunchKernelGGL(k_tiles_dma, dim3(grid), dim3(256), 2 * pitch * 16, 0, (const v4f*)x, ntiles, tile4, (float*)out); });
+    printf("tiles 21 KB, LDS DMA x2 %2d blocks/CU  %.2f TB/s\n", bpc, (double)ntiles * tile4 * 16 / t / 1e9);
   }
   return 0;
 }
