@@ -281,7 +281,10 @@ def reward_net_forward(net, state, action, dropout=None, seed=0, sample_offset=0
         dropout = net.use_dropout and (net.dropout_always or net.training)
     keep = float(net.keep_prob) if dropout else 1.0
     out = torch.empty(B, dtype=torch.float32, device=state.device)
-    P = lambda t: t.detach().contiguous().data_ptr()
+    def P(t):
+        if not t.is_contiguous():
+            raise ValueError('reward net parameters must be contiguous')
+        return t.data_ptr()
     L.check(L.lib().mfg_reward_net_forward(
         state.data_ptr(), action.data_ptr(), B, d, net.conv1.kernel_size[0], net.conv2.out_channels,
         net.conv2.kernel_size[0], net.fc3.out_features, net.fc4.out_features, P(net.conv1.weight), P(net.conv1.bias),
