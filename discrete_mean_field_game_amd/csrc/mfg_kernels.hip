@@ -405,11 +405,13 @@ __global__ __launch_bounds__(BLOCK, (PER <= 6 ? MFG_STEP_WAVES : 4)) void k_step
     for (int i = 0; i < (D ? D : d); ++i) {
       const double p = (double)colp[i * d];
       const double qx = (double)qv[i];
-      acc = fma(p, qx, acc);
+      // u = pi_i P_ij is exact in fp64 (two fp32 factors), so acc += u equals the fma, and pi_i P_ij^2 = u p,
+      // pi_i^2 P_ij^2 = u^2 are formed inside the fmas with the same single rounding as before: 4 fp64 ops, not 5
+      const double u = p * qx;
+      acc += u;
       if (KIND != MFG_REWARD_EXTERNAL) {
-        const double pp = p * p;
-        s1 = fma(qx, pp, s1);
-        if (KIND == MFG_REWARD_MFG_AC2) s2 = fma(qx * qx, pp, s2);
+        s1 = fma(u, p, s1);
+        if (KIND == MFG_REWARD_MFG_AC2) s2 = fma(u, u, s2);
       }
     }
     double racc = 0.0;
