@@ -424,47 +424,76 @@ class actor_critic:
             traj = torch.stack(rows, dim=1)
         return self._out(traj, pi0, single)
 
-    def evaluate(self, theta=8.86349, shift=0.5, alpha_scale=1e4, d=21, episode_length=16,
-                 indir='test_normalized_round2', outfile='eval_mfg_round2/test_eval_fixed_reward.csv',
-                 write_header=0):
-        """L1 / JSD of generated vs empirical trajectories over every file of indir (mfg_ac2.py:595-670).
-        All test trajectories are generated in one batched launch."""
-        self.theta = theta
-        self.shift = shift
-        self.alpha_scale = alpha_scale
-        self.d = d
+    _EVAL_HEADER = ('theta,shift,alpha_scale,mean_l1_final,std_l1_final,mean_l1_mean,std_l1_mean,'
+                    'mean_JSD_final,std_JSD_final,mean_JSD_mean,std_JSD_mean\n')
+
+    def _load_empirical(self, indir, d, episode_length):
+        """Every file of cwd/indir as [N, L, d] (mfg_ac2.py:612-626): fp64 for the L1 metric, fp32 for the kernels."""
         path_to_dir = os.getcwd() + '/' + indir
         emp = []
         for filename in os.listdir(path_to_dir):
             with open(path_to_dir + '/' + filename, 'r') as f:
                 emp.append(np.loadtxt(f, delimiter=' ')[:, 0:d])
-        emp = np.array(emp)[:, :episode_length]                              # [N, L, d]
-        gen = self.generate_trajectory(emp[:, 0], episode_length)           # [N, L, d]
-        diff = np.abs(emp - gen).sum(-1)                                    # L1 per step
-        N, Lh = emp.shape[0], episode_length
-        jsd = self.JSD(emp.reshape(N * Lh, d).copy(), gen.reshape(N * Lh, d).copy()).reshape(N, Lh)
-        res = [diff[:, -1].mean(), diff[:, -1].std(), diff.mean(1).mean(), diff.mean(1).std(),
-               jsd[:, -1].mean(), jsd[:, -1].std(), jsd.mean(1).mean(), jsd.mean(1).std()]
+        emp = np.array(emp)[:, :episode_length]
+        return (torch.as_tensor(emp, dtype=torch.float64, device=self.device),
+                torch.as_tensor(emp.astype(np.float32), device=self.device))
+
+    def _eval_metrics_dev(self, emp64, emp32):
+        """The eight metrics of evaluate() for the CURRENT policy, computed on the device (fp64 tensor [8], no host
+        round trip): all test trajectories are generated in one launch, L1 per step by torch, JSD by mfg_jsd."""
+        N, Lh, d = emp32.shape
+        gen = self.generate_trajectory(emp32[:, 0].contiguous(), Lh)                       # [N, L, d] device tensor
+        diff = (emp64 - gen.double()).abs().sum(-1)                                       # L1 per step
+        jsd = ops.jsd(emp32.reshape(N * Lh, d).contiguous(), gen.reshape(N * Lh, d).contiguous()).view(N, Lh)
+        std = lambda t: t.std(unbiased=False)                                             # numpy's default ddof = 0
+        return torch.stack([diff[:, -1].mean(), std(diff[:, -1]), diff.mean(1).mean(), std(diff.mean(1)),
+                            jsd[:, -1].mean(), std(jsd[:, -1]), jsd.mean(1).mean(), std(jsd.mean(1))])
+
+    def evaluate(self, theta=8.86349, shift=0.5, alpha_scale=1e4, d=21, episode_length=16,
+                 indir='test_normalized_round2', outfile='eval_mfg_round2/test_eval_fixed_reward.csv',
+                 write_header=0):
+        """L1 / JSD of generated vs empirical trajectories over every file of indir (mfg_ac2.py:595-670).
+        All test trajectories are generated in one batched launch; the metrics are reduced on the device."""
+        self.theta = theta
+        self.shift = shift
+        self.alpha_scale = alpha_scale
+        self.d = d
+        emp64, emp32 = self._load_empirical(indir, d, episode_length)
+        res = [float(v) for v in self._eval_metrics_dev(emp64, emp32).cpu()]
         with open(outfile, 'a') as f:
             if write_header:
-                f.write('theta,shift,alpha_scale,mean_l1_final,std_l1_final,mean_l1_mean,std_l1_mean,'
-                        'mean_JSD_final,std_JSD_final,mean_JSD_mean,std_JSD_mean\n')
+                f.write(self._EVAL_HEADER)
             f.write('%f,%f,%f,%.3e,%.3e,%.3e,%.3e,%.3e,%.3e,%.3e,%.3e\n' % ((theta, shift, alpha_scale) + tuple(res)))
         return res[0], res[2], res[4], res[6]
 
     def gridsearch(self, theta_range, shift_range, alpha_range, indir, outfile):
-        """Sweep (theta, shift, alpha_scale) and keep the best of each metric (mfg_ac2.py:673-689)."""
-        list_tuples = [[100, 0, 0, 0], [100, 0, 0, 0], [100, 0, 0, 0], [100, 0, 0, 0]]
+        """Sweep (theta, shift, alpha_scale) and keep the best of each metric (mfg_ac2.py:673-689).  The test files
+        are read once, every grid point is evaluated on the device back to back (one rollout + one JSD launch per
+        point, no host synchronisation in the sweep); the CSV lines evaluate() would have appended and the argmin
+        scan of the reference are produced from one final copy.  Same numbers as calling evaluate() per point."""
+        emp64, emp32 = self._load_empirical(indir, self.d, 16)
+        points, rows = [], []
         for theta in theta_range:
             for shift in shift_range:
                 for alpha_scale in alpha_range:
                     if self.verbose:
                         print('Theta %f, shift %f, alpha %d' % (theta, shift, alpha_scale))
-                    result = self.evaluate(theta, shift, alpha_scale, d=self.d, indir=indir, outfile=outfile,
-                                           write_header=0)
-                    for idx in range(4):
-                        if result[idx] <= list_tuples[idx][0]:
-                            list_tuples[idx] = [result[idx], theta, shift, alpha_scale]
+                    self.theta = theta
+                    self.shift = shift
+                    self.alpha_scale = alpha_scale
+                    points.append((theta, shift, alpha_scale))
+                    rows.append(self._eval_metrics_dev(emp64, emp32))
+        list_tuples = [[100, 0, 0, 0], [100, 0, 0, 0], [100, 0, 0, 0], [100, 0, 0, 0]]
+        if not rows:
+            return list_tuples
+        table = torch.stack(rows).cpu().numpy()                                # the only synchronisation of the sweep
+        with open(outfile, 'a') as f:
+            for (theta, shift, alpha_scale), res in zip(points, table):
+                f.write('%f,%f,%f,%.3e,%.3e,%.3e,%.3e,%.3e,%.3e,%.3e,%.3e\n' % ((theta, shift, alpha_scale) + tuple(res)))
+                result = (res[0], res[2], res[4], res[6])
+                for idx in range(4):
+                    if result[idx] <= list_tuples[idx][0]:
+                        list_tuples[idx] = [float(result[idx]), theta, shift, alpha_scale]
         if self.verbose:
             print(list_tuples)
         return list_tuples

@@ -412,3 +412,31 @@ def test_training_step_is_hip_graph_capturable(dev):
     torch.cuda.synchronize()
     assert torch.equal(th_e, th_g) and torch.equal(w_e, w_g)
     assert float(th_g) != 8.86349
+
+
+def test_gridsearch_equals_pointwise_evaluate(dev, tmp_path, monkeypatch):
+    """gridsearch (mfg_ac2.py:673-689) evaluates every grid point on the device without per-point host round trips;
+    its CSV lines and its argmin table are those of calling evaluate() point by point."""
+    d = 21
+    rs = np.random.RandomState(4)
+    monkeypatch.chdir(tmp_path)
+    os.makedirs('test_normalized_round2'); os.makedirs('out')
+    for day in range(22, 27):
+        np.savetxt('test_normalized_round2/trend_distribution_day%d.csv' % day, rs.dirichlet(np.ones(d), size=16),
+                   fmt='%.3e', delimiter=' ')
+    thetas, shifts, alphas = [6.0, 8.0, 9.5], [0.1, 0.5], [1e3, 1e4]
+    a = AC(d=d, pi0=rs.dirichlet(np.ones(d), size=4), seed=9, verbose=0)
+    best = a.gridsearch(thetas, shifts, alphas, indir='test_normalized_round2', outfile='out/grid.csv')
+    b = AC(d=d, pi0=a.mat_pi0, seed=9, verbose=0)
+    ref = [[100, 0, 0, 0] for _ in range(4)]
+    for th in thetas:
+        for sh in shifts:
+            for al in alphas:
+                r = b.evaluate(th, sh, al, d=d, indir='test_normalized_round2', outfile='out/point.csv')
+                for k in range(4):
+                    if r[k] <= ref[k][0]:
+                        ref[k] = [r[k], th, sh, al]
+    assert open('out/grid.csv').read() == open('out/point.csv').read()
+    assert len(open('out/grid.csv').read().strip().split('\n')) == 12
+    for k in range(4):
+        assert best[k][1:] == ref[k][1:] and abs(best[k][0] - ref[k][0]) < 1e-12
