@@ -440,3 +440,46 @@ def test_gridsearch_equals_pointwise_evaluate(dev, tmp_path, monkeypatch):
     assert len(open('out/grid.csv').read().strip().split('\n')) == 12
     for k in range(4):
         assert best[k][1:] == ref[k][1:] and abs(best[k][0] - ref[k][0]) < 1e-12
+
+
+@pytest.mark.parametrize('mode', ['step', 'rollout'])
+def test_ac_irl_philox_train_matches_oracle_replay(dev, mode):
+    """AC_IRL.train with the in-kernel sampler (rollout with external reward -> reward -> gradient kernel): one
+    episode replayed by the oracle on the sampled actions (1-indexed episode, running discount gamma^t, batch-mean
+    updates per step or once per episode)."""
+    from discrete_mean_field_game_amd import ops
+    d, B, gamma = 15, 10, 0.9
+    rs = np.random.RandomState(8)
+    mat = rs.dirichlet(np.ones(d), size=6)
+    np.random.seed(31)
+    ac = IRL(theta=8.64, shift=0.0, alpha_scale=1e4, d=d, pi0=mat, demonstrations=[], batch=B, rng='philox', seed=13,
+             update_every=mode, precision='f64', verbose=0)
+    w0 = ac.w[:, 0].copy(); theta0 = float(np.ravel(ac.theta)[0])
+    np.random.seed(32)
+    ac.train(max_episodes=1, stop_criteria=-1, gamma=gamma, constant=False, lr_critic=0.1, lr_actor=0.001,
+             reward_fn=fake_reward_dev)
+    np.random.seed(32)
+    idx = np.random.randint(6, size=B)
+    pi = mat[idx].astype(np.float32)
+    w, theta = w0.copy(), theta0
+    sc, sa = O().lr_scales(1, False)
+    Gw_acc = np.zeros_like(w); Gt_acc = 0.0
+    disc = 1.0
+    for t in range(15):
+        th = torch.tensor([theta], dtype=torch.float64, device=dev)
+        P = ops.sample_dirichlet(torch.as_tensor(pi, device=dev), th, 0.0, 1e4, seed=13, step=t, precision='f64').cpu().numpy()
+        pn = O().transition(P, pi).astype(np.float32)
+        r = fake_reward_dev(torch.as_tensor(pi, device=dev), torch.as_tensor(P, device=dev)).cpu().numpy().astype(np.float64)
+        delta, g, G_w, G_t, _ = O().batched_td_pg(pi, pn, P, r, w, theta, 0.0, disc)
+        if mode == 'step':
+            w = w + 0.1 * sc * G_w / B
+            theta = theta + 0.001 * sa * G_t / B
+        else:
+            Gw_acc += G_w; Gt_acc += G_t
+        disc *= gamma
+        pi = pn
+    if mode == 'rollout':
+        w = w + 0.1 * sc * Gw_acc / (15 * B)
+        theta = theta + 0.001 * sa * Gt_acc / (15 * B)
+    assert abs(float(np.ravel(ac.theta)[0]) - theta) < 1e-9
+    assert np.max(np.abs(ac.w[:, 0] - w)) < 1e-9
