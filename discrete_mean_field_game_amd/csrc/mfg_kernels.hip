@@ -905,6 +905,157 @@ __global__ __launch_bounds__(BLOCK) void k_grad_small(GradArgs a) {
   if (tid == 0) *a.counter = 0u;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Critic-gradient sums on the fp64 matrix cores for d a multiple of 16 (d >= 64): the one GEMM-shaped piece of the
+// path, M = sum_n delta_n pi_n pi_n^T = A B with A = (delta pi)^T [d x N], B = pi [N x d].  v_mfma_f64_16x16x4_f64:
+// a wave owns up to 8 upper-triangle 16x16 tiles of M (4 fp64 accumulators per lane per tile), a block stages 32
+// samples (fp32 rows + delta) in LDS and runs 8 K-steps of 4 samples over them; operands are widened / scaled on
+// the way from LDS (2 LDS reads + 2 cvt + 1 mul per 2 048-flop MFMA instead of 3 LDS reads per FMA in
+// k_grad_partial, which ran at 4.5 % of the fp64 peak: 3.1 ms per C3 rollout).  Split-K over grid.x with one partial
+// row per x, tiles split over grid.y; the linear / scalar sums ride on the y = 0 blocks.  Deterministic.
+// ---------------------------------------------------------------------------------------------
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+constexpr int GM_KC = 32;    // samples staged per chunk
+constexpr int GM_TPW = 8;    // max tiles per wave
+
+__global__ __launch_bounds__(BLOCK) void k_grad_mfma(GradArgs a, int tpw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int d = a.d, nt = d >> 4, pitch = d + 16;  // pitch = 16 mod 32: the four k-rows of an operand hit distinct banks
+  const int Q = d * (d + 1) / 2, F = Q + d + 1, FO = F + 3;
+  double* dl = reinterpret_cast<double*>(smem_raw);                  // [KC] delta
+  double* red = dl + GM_KC;                                          // [4][BLOCK] scalar reduction scratch
+  float* sp = reinterpret_cast<float*>(red + 4 * BLOCK);             // [KC][pitch] pi rows
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  const int ntiles = nt * (nt + 1) / 2;
+  // this wave's tiles: linear ids t0 .. t0+nmine-1 of the row-major upper-triangle tile list
+  const int t0 = ((int)blockIdx.y * WAVES + wv) * tpw;
+  int nmine = ntiles - t0;
+  nmine = nmine < 0 ? 0 : (nmine > tpw ? tpw : nmine);
+  int tr[GM_TPW], tc[GM_TPW];
+#pragma unroll
+  for (int i = 0; i < GM_TPW; ++i) {
+    int t = t0 + i, r = 0;
+    if (i < nmine) {
+      while (t >= nt - r) {  // row r of the tile triangle holds nt - r tiles
+        t -= nt - r;
+        ++r;
+      }
+    } else {
+      t = 0;
+    }
+    tr[i] = r;
+    tc[i] = r + t;
+  }
+  v4d_t acc[GM_TPW];
+#pragma unroll
+  for (int i = 0; i < GM_TPW; ++i) acc[i] = (v4d_t)(0.0);
+  const bool side = blockIdx.y == 0;  // also owns the linear and scalar sums
+  double lin[4] = {0.0, 0.0, 0.0, 0.0}, s_d = 0.0, s_dg = 0.0, s_r = 0.0, s_n = 0.0;
+  const int li = lane & 15, lk = lane >> 4;
+  const double invT = 1.0 / (double)a.T;
+  for (int64_t n0 = (int64_t)blockIdx.x * GM_KC; n0 < a.N; n0 += (int64_t)gridDim.x * GM_KC) {
+    const int cn = (int)((a.N - n0) < GM_KC ? (a.N - n0) : GM_KC);
+    __syncthreads();
+    if (a.chunk) {
+      // rows are 16-byte aligned and BLOCK is a multiple of d/4: thread -> (row, float4 column) without divisions
+      const int dq = d >> 2, rpp = BLOCK / dq;
+      const int q0 = tid / dq, c4 = tid - q0 * dq;
+      for (int q = q0; q < GM_KC; q += rpp) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < cn) {
+          const int64_t n = n0 + q;
+          const int64_t b = (int64_t)(((double)n + 0.5) * invT);
+          v = *reinterpret_cast<const float4*>(a.pi + b * a.stride_b + (n - b * a.T) * d + 4 * c4);
+        }
+        *reinterpret_cast<float4*>(sp + q * pitch + 4 * c4) = v;  // rows past the end are zero: they add nothing
+      }
+    } else {
+      for (int k = tid; k < GM_KC * d; k += BLOCK) {
+        const int q = k / d, c = k - q * d;
+        float v = 0.0f;
+        if (q < cn) {
+          const int64_t n = n0 + q;
+          const int64_t b = (int64_t)(((double)n + 0.5) * invT);
+          v = a.pi[b * a.stride_b + (n - b * a.T) * d + c];
+        }
+        sp[q * pitch + c] = v;
+      }
+    }
+    if (tid < GM_KC) {
+      double de = 0.0;
+      if (tid < cn) {
+        const int64_t n = n0 + tid;
+        de = a.delta[n];
+        const double rr = a.reward ? (double)a.reward[n] : 0.0;
+        if (side) {
+          s_d += de;
+          if (a.g) s_dg = fma(de, a.g[n], s_dg);
+          s_r += rr;
+          s_n += 1.0;
+        }
+      }
+      dl[tid] = de;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < GM_KC / 4; ++ks) {
+      const int k = ks * 4 + lk;
+      const double dk = dl[k];
+      const float* row = sp + k * pitch + li;
+#pragma unroll
+      for (int i = 0; i < GM_TPW; ++i) {
+        if (i < nmine) {
+          const double av = dk * (double)row[tr[i] << 4];   // A[i = li][k] = delta_k pi_k[16 r + li]
+          const double bv = (double)row[tc[i] << 4];        // B[k][j = li] = pi_k[16 c + li]
+          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i], 0, 0, 0);
+        }
+      }
+    }
+    if (side) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = tid + u * BLOCK;
+        if (c < d) {
+          double t = lin[u];
+          for (int q = 0; q < GM_KC; ++q) t = fma(dl[q], (double)sp[q * pitch + c], t);
+          lin[u] = t;
+        }
+      }
+    }
+  }
+  // D[i][j] of a tile: lane holds rows i = 4 v + lane / 16, v = 0..3, column j = lane % 16
+  double* out = a.partial + (int64_t)blockIdx.x * FO;
+#pragma unroll
+  for (int i = 0; i < GM_TPW; ++i) {
+    if (i < nmine) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int gi = (tr[i] << 4) + 4 * v + lk, gj = (tc[i] << 4) + li;
+        if (gi <= gj) out[feat_idx(gi, gj, d)] = acc[i][v];
+      }
+    }
+  }
+  if (side) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = tid + u * BLOCK;
+      if (c < d) out[Q + c] = lin[u];
+    }
+    __syncthreads();
+    red[tid] = s_d;
+    red[BLOCK + tid] = s_dg;
+    red[2 * BLOCK + tid] = s_r;
+    red[3 * BLOCK + tid] = s_n;
+    __syncthreads();
+    if (tid < 4) {
+      double t = 0.0;
+      for (int q = 0; q < GM_KC; ++q) t += red[tid * BLOCK + q];  // only threads < KC hold scalar partials
+      out[Q + d + tid] = t;
+    }
+  }
+}
+
 // Sum nsb partial rows in a fixed order: block = 16 slices (waves) x 64 outputs (lanes, coalesced);
 // slice s adds rows s, s+16, ... ; the 16 slice sums are combined in slice order through LDS.
 constexpr int RP_SLICES = 16;
@@ -996,6 +1147,8 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
   a.chunk = chunk;
   a.nsb = nsb;
   a.partial = reinterpret_cast<double*>((char*)ws + MFG_WS_CONTROL_BYTES);
+  // (the packed kernel folds delta += reward into its own load: every sample is read by exactly one wave there; the
+  //  other kernels read a sample from several blocks, so the update is a separate elementwise launch first)
   if (add_reward && !(d == 21 || d == 15))
     hipLaunchKernelGGL(k_add_reward, dim3(grid_for(N, 256, 8)), dim3(256), 0, st, const_cast<double*>(delta), reward, N);
   if (d == 21 || d == 15) {
@@ -1034,6 +1187,17 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
     hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
                        (const double*)a.partial, blocks, FO, accumulate, G);
     return check_launch("grad_small");
+  }
+  if (d % 16 == 0 && d >= 64 && d <= 4 * BLOCK) {
+    const int nt = d / 16, ntiles = nt * (nt + 1) / 2;
+    const int ny = (ntiles + WAVES * GM_TPW - 1) / (WAVES * GM_TPW);
+    const int tpw = (ntiles + ny * WAVES - 1) / (ny * WAVES);
+    a.chunk = (BLOCK % (d / 4) == 0 && (((uintptr_t)pi & 15) == 0) && (stride_b % 4 == 0)) ? 1 : 0;  // float4 staging
+    const size_t lds_m = (size_t)GM_KC * 8 + (size_t)4 * BLOCK * 8 + (size_t)GM_KC * (d + 16) * 4;
+    hipLaunchKernelGGL(k_grad_mfma, dim3((unsigned)nsb, (unsigned)ny), dim3(BLOCK), lds_m, st, a, tpw);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
+                       (const double*)a.partial, nsb, FO, accumulate, G);
+    return check_launch("grad_mfma");
   }
   const size_t lds = (size_t)chunk * 3 * 8 + (size_t)chunk * d * 4;
   hipLaunchKernelGGL(k_grad_partial, dim3((unsigned)nsb, (unsigned)nob), dim3(BLOCK), lds, st, a);

@@ -624,3 +624,39 @@ def test_sampler_marginals_are_beta_distributed(dev, d, scale, theta):
     # independence across rows: correlation of entries of different rows is sampling noise
     c = np.corrcoef(P[:, 0, 0], P[:, 1, 0])[0, 1]
     assert abs(c) < 5.0 / np.sqrt(B)
+
+
+@pytest.mark.parametrize('d,B,T', [(64, 37, 3), (80, 21, 2), (96, 50, 1), (128, 333, 2), (144, 9, 1), (256, 70, 2), (512, 5, 1),
+                                   (21, 1000, 4), (15, 77, 3), (47, 40, 2)])
+@pytest.mark.parametrize('add_reward', [False, True])
+def test_grad_accumulate_all_kernels(dev, d, B, T, add_reward):
+    """The batch sums on their own (a6/a8) for every gradient kernel: fp64-MFMA tiles (d multiple of 16, >= 64; d = 80
+    and 144 take its scalar staging path), the packed d = 21/15 kernel, the generic one; trajectory-major layout with
+    stride (T+1) d, ragged sample counts, optional delta += reward."""
+    o_ = ops()
+    rs = np.random.RandomState(d * 3 + B)
+    traj = t32(rs.dirichlet(np.ones(d), size=(B, T + 1)), dev)                 # [B, T+1, d]
+    N = B * T
+    delta = t64(rs.randn(B, T), dev)
+    g = t64(rs.randn(B, T), dev)
+    r = t32(rs.rand(B, T), dev)
+    F = o_.num_features(d)
+    G = torch.full((F + 3,), 7.0, dtype=torch.float64, device=dev)
+    ws = o_.workspace(N, d, dev)
+    dl = delta.clone()
+    o_.grad_accumulate(traj, dl, g, r, G, ws, T=T, add_reward=add_reward)
+    de = (delta + r.double()) if add_reward else delta
+    assert torch.equal(dl, de)
+    x = traj[:, :T].double().reshape(N, d)
+    dv = de.reshape(N)
+    M = (x * dv[:, None]).T @ x
+    iu = torch.triu_indices(d, d, device=dev)
+    Q = d * (d + 1) // 2
+    ref = torch.cat([M[iu[0], iu[1]], (x * dv[:, None]).sum(0), dv.sum()[None], (dv * g.reshape(N)).sum()[None],
+                     r.double().sum()[None], torch.tensor([float(N)], dtype=torch.float64, device=dev)])
+    scale = float(ref[:Q].abs().max())
+    assert float((G[:Q] - ref[:Q]).abs().max()) <= 1e-12 * max(scale, 1e-300)
+    assert float((G[Q:] - ref[Q:]).abs().max()) <= 1e-11 * max(1.0, float(ref[Q:].abs().max()))
+    # accumulate = True adds onto G
+    o_.grad_accumulate(traj, de.clone(), g, r, G, ws, T=T, accumulate=True)
+    assert float((G[:Q] - 2 * ref[:Q]).abs().max()) <= 1e-12 * max(scale, 1e-300)
