@@ -254,11 +254,19 @@ __device__ __forceinline__ float htab_eval(const float4* __restrict__ tab, float
 // wave-level reductions
 // ---------------------------------------------------------------------------
 // DPP move of a 64-bit value (two 32-bit DPP movs); lanes outside row_mask / without a source get 0.
+// ROW_MASK == 0xF with a permutation inside rows: every lane has a source, so the "old" operand is dead; bound_ctrl with
+// full masks lets the compiler drop it (a live "old" costs one extra v_mov per half: 36 instructions per row of the
+// large-d kernels).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_mov_f64(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  if (ROW_MASK == 0xF) {
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);  // bound_ctrl + full masks: no tied "old" register
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  } else {
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+  }
   return __hiloint2double(hi, lo);
 }
 
