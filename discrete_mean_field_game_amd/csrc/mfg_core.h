@@ -432,13 +432,17 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
           }
         }
         double invS = 1.0;
-        if (SAMPLE) {
+        if (SAMPLE && TD) {
+          wave_sum3_dpp(Ssum, A, D);
+          invS = 1.0 / Ssum;
+        } else if (SAMPLE) {
           Ssum = wave_sum_dpp(Ssum);
           invS = 1.0 / Ssum;
-        }
-        if (TD) {
+        } else if (TD) {
           A = wave_sum_dpp(A);
           D = wave_sum_dpp(D);
+        }
+        if (TD) {
           if (lane == 0) {
             rowq[3 * i] = A;
             rowq[3 * i + 1] = D;

@@ -285,6 +285,31 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
   return __hiloint2double(hi, lo);
 }
 
+
+// Three independent wave sums, step-interleaved: between a lane's write of a partial sum and the DPP read of it sit
+// the other two chains, so the DPP read-after-write hazard costs no s_nop (18 per row in the large-d kernels).
+__device__ __forceinline__ void wave_sum3_dpp(double& a, double& b, double& c) {
+#define MFG_SUM3_STEP(CTRL, MASK)                 \
+  {                                               \
+    const double ta = dpp_mov_f64<CTRL, MASK>(a); \
+    const double tb = dpp_mov_f64<CTRL, MASK>(b); \
+    const double tc = dpp_mov_f64<CTRL, MASK>(c); \
+    a += ta;                                      \
+    b += tb;                                      \
+    c += tc;                                      \
+  }
+  MFG_SUM3_STEP(0xB1, 0xF)
+  MFG_SUM3_STEP(0x4E, 0xF)
+  MFG_SUM3_STEP(0x141, 0xF)
+  MFG_SUM3_STEP(0x140, 0xF)
+  MFG_SUM3_STEP(0x142, 0xA)
+  MFG_SUM3_STEP(0x143, 0xC)
+#undef MFG_SUM3_STEP
+  a = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 63), __builtin_amdgcn_readlane(__double2loint(a), 63));
+  b = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(b), 63), __builtin_amdgcn_readlane(__double2loint(b), 63));
+  c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c), 63), __builtin_amdgcn_readlane(__double2loint(c), 63));
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
