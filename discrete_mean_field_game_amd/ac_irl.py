@@ -265,6 +265,25 @@ class AC_IRL(actor_critic):
         self._gen_traj_counter = off + n
         return off
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self):
+        """actor_critic.state_dict() plus the reward network, its optimiser, the policy FIFO and the counters of the
+        outer loop (the reference only saves the TF reward net, ac_irl.py:948)."""
+        st = super().state_dict()
+        st.update({'reward_net': self.reward_net.state_dict(), 'optimizer': self.optimizer.state_dict(),
+                   'list_policies': [float(np.ravel(t)[0]) for t in self.list_policies],
+                   'reward_update_count': int(getattr(self, 'reward_update_count', 0)),
+                   'gen_traj_counter': int(getattr(self, '_gen_traj_counter', 1 << 40))})
+        return st
+
+    def load_state_dict(self, state, restore_np_random=True):
+        super().load_state_dict(state, restore_np_random)
+        self.reward_net.load_state_dict(state['reward_net'])
+        self.optimizer.load_state_dict(state['optimizer'])
+        self.list_policies = list(state['list_policies'])
+        self.reward_update_count = int(state['reward_update_count'])
+        self._gen_traj_counter = int(state['gen_traj_counter'])
+
     # ------------------------------------------------------------------ importance weights (ac_irl.py:270-379)
     def calc_pdf_action(self, theta, action, state, log=False):
         """q(a_t; s_t, theta) of the product-Dirichlet policy (ac_irl.py:270-289); `log=True` returns ln q (the

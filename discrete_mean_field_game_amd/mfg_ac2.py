@@ -202,6 +202,29 @@ class actor_critic:
         a = t.cpu().numpy().astype(dtype)
         return a[0] if single else a
 
+    # ------------------------------------------------------------------ checkpoint / resume
+    def state_dict(self):
+        """Everything a run needs to resume bit for bit: theta, w (fp64, device values copied to the host), the Philox
+        step counter and seed, the policy hyper-parameters and the global np.random state (start-state draws).
+        The reference keeps no RL checkpoint at all (only CSV logs); `torch.save(obj.state_dict(), path)` is ours."""
+        return {'theta': float(self._theta.cpu()[0]), 'theta_is_array': bool(self._theta_is_array),
+                'w': self._w.cpu().clone(), 'rng_step': int(self._rng_step), 'seed': int(self.seed),
+                'shift': float(self.shift), 'alpha_scale': float(self.alpha_scale), 'd': int(self.d),
+                'np_random_state': np.random.get_state()}
+
+    def load_state_dict(self, state, restore_np_random=True):
+        if int(state['d']) != int(self.d):
+            raise ValueError('checkpoint is for d=%d, object has d=%d' % (state['d'], self.d))
+        self._theta.copy_(torch.tensor([state['theta']], dtype=torch.float64))
+        self._theta_is_array = bool(state['theta_is_array'])
+        self._w.copy_(state['w'].to(self._w.device))
+        self._rng_step = int(state['rng_step'])
+        self.seed = int(state['seed'])
+        self.shift = state['shift']
+        self.alpha_scale = state['alpha_scale']
+        if restore_np_random and state.get('np_random_state') is not None:
+            np.random.set_state(state['np_random_state'])
+
     # ------------------------------------------------------------------ a1 + a2
     def _host_gamma(self, pi_dev):
         """Gamma variates for [B,d] states from the global legacy np.random stream, in the reference's order:
@@ -292,9 +315,11 @@ class actor_critic:
 
     def train(self, num_episodes=4000, gamma=1, constant=0, lr_critic=0.1, lr_actor=0.001, consecutive=100,
               file_theta='results/theta.csv', file_pi='results/pi.csv', file_reward='results/reward.csv',
-              write_file=0, write_all=0):
+              write_file=0, write_all=0, *, first_episode=0):
         """Actor-critic training (mfg_ac2.py:448-539) over ``batch`` lock-step trajectories.
-        batch=1, rng='numpy', update_every='step' retraces the reference's seeded run."""
+        batch=1, rng='numpy', update_every='step' retraces the reference's seeded run.
+        first_episode: episode number the 1/(episode+1) learning-rate schedule starts from (resume after
+        load_state_dict)."""
         d, T = self.d, EPISODE_STEPS
         shard = current_shard(self.batch, self.group)
         Bl = shard.local_batch
@@ -313,7 +338,7 @@ class actor_critic:
                 with open('temp.csv', 'a') as f:
                     f.write('Episode %d \n\n' % episode)
             pi = ops.gather_start(self._mat_pi0_dev, self._draw_start(shard))
-            sc, sa = lr_scales(episode, constant == 1)
+            sc, sa = lr_scales(episode + first_episode, constant == 1)
             if native_episode:
                 ops.train_episode(pi, T, self._theta, self.shift, self.alpha_scale, self._w, gamma, lr_critic * sc,
                                   lr_actor * sa, G, ws, ebufs, reward_kind=self.reward_kind, seed=self.seed,

@@ -483,3 +483,28 @@ def test_ac_irl_philox_train_matches_oracle_replay(dev, mode):
         theta = theta + 0.001 * sa * Gt_acc / (15 * B)
     assert abs(float(np.ravel(ac.theta)[0]) - theta) < 1e-9
     assert np.max(np.abs(ac.w[:, 0] - w)) < 1e-9
+
+
+@pytest.mark.parametrize('mode', ['step', 'rollout'])
+def test_checkpoint_resume_is_bit_identical(dev, mode, tmp_path):
+    """state_dict / load_state_dict (theta, w, Philox counter, np.random state): 2 + 2 episodes through a saved file
+    equal 4 uninterrupted episodes bit for bit."""
+    d, B = 21, 64
+    rs = np.random.RandomState(1)
+    mat = rs.dirichlet(np.ones(d), size=7)
+    np.random.seed(3)
+    a = AC(d=d, pi0=mat, batch=B, seed=4, update_every=mode, verbose=0)
+    np.random.seed(5)
+    a.train(num_episodes=4, gamma=0.9)
+    np.random.seed(3)
+    b = AC(d=d, pi0=mat, batch=B, seed=4, update_every=mode, verbose=0)
+    np.random.seed(5)
+    b.train(num_episodes=2, gamma=0.9)
+    torch.save(b.state_dict(), str(tmp_path / 'ck.pt'))
+    np.random.seed(999)                                   # scramble everything that is not in the checkpoint
+    c = AC(d=d, pi0=mat, batch=B, seed=77, update_every=mode, verbose=0)
+    c.load_state_dict(torch.load(str(tmp_path / 'ck.pt'), weights_only=False))
+    c.train(num_episodes=2, gamma=0.9, first_episode=2)     # the lr/(episode+1) schedule continues at episode 2
+    assert np.array_equal(np.ravel(a.theta), np.ravel(c.theta))
+    assert np.array_equal(a.w, c.w)
+    assert a._rng_step == c._rng_step
