@@ -34,10 +34,10 @@ class AC_IRL(actor_critic):
     def __init__(self, theta=8.64, shift=0, alpha_scale=1e4, d=15, lr_reward=1e-4, num_policies=10, c=2e11,
                  reg='dropout_l1l2', n_fc3=8, n_fc4=4, saved_network=None, use_tf=True, summarize=False, *,
                  pi0=None, pi0_test=None, demonstrations=None, demonstrations_test=None, batch=1, rng='philox',
-                 seed=0, update_every='step', precision='mixed', device=None, group=None, verbose=1):
+                 seed=0, update_every='step', precision='mixed', device=None, group=None, verbose=1, check_finite=False):
         super().__init__(theta=theta, shift=shift, alpha_scale=alpha_scale, d=d, pi0=pi0, batch=batch, rng=rng,
                          seed=seed, update_every=update_every, precision=precision, device=device, group=group,
-                         verbose=verbose)
+                         verbose=verbose, check_finite=check_finite)
         self.summarize = summarize
         self.theta_initial = theta                      # reset value used by outerloop (ac_irl.py:45, :942)
         self.lr_reward = lr_reward
@@ -208,6 +208,8 @@ class AC_IRL(actor_critic):
                 total_reward = total_reward * T
                 self._theta_is_array = True
             list_reward.append(total_reward)
+            if self.check_finite:
+                self._raise_if_not_finite(pi, episode)
             if episode % consecutive == 0:
                 reward_avg = float(torch.cat(list_reward).sum().cpu()) / consecutive
                 list_reward = []

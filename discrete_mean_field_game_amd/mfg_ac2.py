@@ -45,7 +45,7 @@ class actor_critic:
 
     def __init__(self, theta=8.86349, shift=0.16, alpha_scale=12000, d=21, *, pi0=None, path_to_dir=None,
                  batch=1, rng='philox', seed=0, update_every='step', reward='mfg_ac2', precision='mixed', device=None,
-                 group=None, verbose=1):
+                 group=None, verbose=1, check_finite=False):
         if rng not in ('philox', 'numpy'):
             raise ValueError("rng must be 'philox' or 'numpy'")
         if update_every not in ('step', 'rollout'):
@@ -67,6 +67,9 @@ class actor_critic:
         self.precision = precision
         self.group = group
         self.verbose = verbose
+        # numeric sanitiser: the reference turns every NumPy FP warning into an exception (mfg_ac2.py:21); with
+        # check_finite=True train() verifies theta, w and the states after every episode and raises FloatingPointError
+        self.check_finite = bool(check_finite)
         self.batch = int(batch)
         self._theta = torch.zeros(1, dtype=torch.float64, device=self.device)
         self._theta_is_array = False
@@ -201,6 +204,12 @@ class actor_critic:
             return t[0] if single else t
         a = t.cpu().numpy().astype(dtype)
         return a[0] if single else a
+
+    def _raise_if_not_finite(self, pi, episode):
+        ok = torch.isfinite(self._theta).all() & torch.isfinite(self._w).all() & torch.isfinite(pi).all()
+        if not bool(ok):
+            raise FloatingPointError('non-finite theta / w / state after episode %d (theta = %r)'
+                                     % (episode, float(self._theta.cpu()[0])))
 
     # ------------------------------------------------------------------ checkpoint / resume
     def state_dict(self):
@@ -391,6 +400,8 @@ class actor_critic:
                         self.trace.append(float(self._theta.cpu()[0]))
             if self.update_every == 'rollout':
                 ep_reward[episode] *= T            # mean over B*T transitions -> mean episode return
+            if self.check_finite:
+                self._raise_if_not_finite(pi, episode)
             if episode % consecutive == 0:
                 # the reference divides the sum over the window by `consecutive` even at episode 0 (:530-534)
                 reward_avg = float(ep_reward[window_start:episode + 1].sum().cpu()) / consecutive

@@ -508,3 +508,17 @@ def test_checkpoint_resume_is_bit_identical(dev, mode, tmp_path):
     assert np.array_equal(np.ravel(a.theta), np.ravel(c.theta))
     assert np.array_equal(a.w, c.w)
     assert a._rng_step == c._rng_step
+
+
+def test_check_finite_raises_like_the_reference_warning_filter(dev):
+    """check_finite=True is the stand-in for the reference's warnings-as-errors (mfg_ac2.py:21): a run that blows up
+    raises FloatingPointError at the end of the offending episode instead of silently carrying NaNs."""
+    d = 21
+    rs = np.random.RandomState(0)
+    ac = AC(d=d, pi0=rs.dirichlet(np.ones(d), size=4), batch=32, seed=1, update_every='rollout', check_finite=True, verbose=0)
+    ac.train(num_episodes=2)                                   # healthy run: no exception
+    with pytest.raises(FloatingPointError):
+        ac.train(num_episodes=3, lr_actor=1e300, lr_critic=1e300)
+    ok = AC(d=d, pi0=rs.dirichlet(np.ones(d), size=4), batch=32, seed=1, update_every='rollout', verbose=0)
+    ok.train(num_episodes=3, lr_actor=1e300, lr_critic=1e300)  # default: unchecked, like running with warnings ignored
+    assert not np.isfinite(np.ravel(ok.theta)[0]) or not np.all(np.isfinite(ok.w))
