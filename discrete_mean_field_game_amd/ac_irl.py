@@ -160,6 +160,14 @@ class AC_IRL(actor_critic):
         rbufs = {'pi_traj': torch.empty(Bl, 2, d, dtype=torch.float32, device=self.device),
                  'P': torch.empty(Bl, 1, d, d, dtype=torch.float32, device=self.device),
                  'delta': dg[0].view(Bl, 1), 'g': dg[1].view(Bl, 1)}
+        fused_episode = (self.update_every == 'rollout' and self.rng == 'philox' and not write_all)
+        if fused_episode:
+            ws_ep = ops.workspace(Bl * T, d, self.device)
+            ebufs = {'pi_traj': torch.empty(Bl, T + 1, d, dtype=torch.float32, device=self.device),
+                     'pi_last': torch.empty(Bl, d, dtype=torch.float32, device=self.device),
+                     'P': torch.empty(Bl, T, d, d, dtype=torch.float32, device=self.device),
+                     'delta': torch.empty(Bl, T, dtype=torch.float64, device=self.device),
+                     'g': torch.empty(Bl, T, dtype=torch.float64, device=self.device)}
         prev_theta = float(self._theta.cpu()[0])
         list_reward = []
         episode = 0
@@ -169,7 +177,24 @@ class AC_IRL(actor_critic):
             discount = 1.0
             total_reward = torch.zeros(1, dtype=torch.float64, device=self.device)
             sc, sa = lr_scales(episode, constant)          # lr/(episode+1) with the 1-indexed episode (:700)
-            for step in range(T):
+            if fused_episode:
+                # one update per episode: theta and w are fixed over the 15 steps, so the whole episode is THREE launches:
+                # the fused rollout (running discount gamma^t, P of every step materialised for the network), one
+                # reward-net pass over all B*T transitions, one gradient pass that folds the rewards into delta
+                o = ops.rollout(pi, T, self._theta, self.shift, self.alpha_scale, w=self._w, gamma=gamma,
+                                reward_kind=L.REWARD_EXTERNAL, seed=self.seed, first_step=self._rng_step,
+                                traj_offset=shard.traj_offset, td=True, write_P=True, discount_pow=True,
+                                precision=self.precision, out=ebufs)
+                self._rng_step += T
+                states = o['pi_traj'][:, :T].reshape(Bl * T, d)
+                r = rfn(states, o['P'].view(Bl * T, d, d))
+                ops.grad_accumulate(o['pi_traj'], o['delta'].view(-1), o['g'].view(-1), r, G, ws_ep, T=T, add_reward=True)
+                all_reduce_gradients_(G, self.group)
+                ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta, total_reward)
+                total_reward = total_reward * T
+                self._theta_is_array = True
+                pi = o['pi_last']
+            for step in range(0 if fused_episode else T):
                 acc = (self.update_every == 'rollout' and step > 0)
                 if self.rng == 'philox':
                     # ONE launch samples P, takes the transition and evaluates everything of the TD step that does not
@@ -202,7 +227,7 @@ class AC_IRL(actor_critic):
                         self.trace.append(float(self._theta.cpu()[0]))
                 discount = discount * gamma
                 pi = pi_next
-            if self.update_every == 'rollout':
+            if self.update_every == 'rollout' and not fused_episode:
                 all_reduce_gradients_(G, self.group)
                 ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta, total_reward)
                 total_reward = total_reward * T

@@ -20,3 +20,5 @@ d = 21
 demos = [[(rs.dirichlet(np.ones(d)), rs.dirichlet(np.ones(d), size=d)) for _ in range(15)] for _ in range(6)]
 irl = AC_IRL(theta=8.64, d=d, batch=B, demonstrations=demos, verbose=0)
 run('ac_irl d=21 B=%d (reward net per step)' % B, irl, 10, stop_criteria=-1, consecutive=1000)
+irl2 = AC_IRL(theta=8.64, d=d, batch=B, demonstrations=demos, update_every='rollout', verbose=0)
+run('ac_irl d=21 B=%d (one update per episode)' % B, irl2, 10, stop_criteria=-1, consecutive=1000)
