@@ -72,6 +72,8 @@ class AC_IRL(actor_critic):
         self.num_sampled_trajectories = self.num_gen_samples
         self.list_policies = [theta] * self.num_policies
         self.reward_update_count = 0
+        self._reward_calls = 0                           # number of reward() calls so far (dropout-mask counter)
+        self._reward_sample_offset = 0                   # global index of the first sample of the next reward() call
         self.reward_net = None
         if use_tf:
             self.create_network()
@@ -125,9 +127,12 @@ class AC_IRL(actor_critic):
     def reward(self, pi, P):
         """r(pi, P) from the reward network: [B,d], [B,d,d] -> [B] (ac_irl.py:683)."""
         if ops.reward_net_supported(self.reward_net) and pi.is_cuda:
-            self._reward_calls = getattr(self, '_reward_calls', 0) + 1           # fresh dropout masks per call
-            return ops.reward_net_forward(self.reward_net, pi.contiguous(), P.contiguous(), seed=self.seed + 0x5EED,
-                                          sample_offset=(self._reward_calls & 0xFFFF) << 32)
+            # fresh dropout masks per call: the FULL call counter goes into the 64-bit Philox key (no wrap-around within
+            # a run), the counter's sample index is the GLOBAL one (rank shard offset + n), so ranks draw different masks
+            self._reward_calls += 1
+            key = ((self.seed + 0x5EED) ^ (self._reward_calls * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+            return ops.reward_net_forward(self.reward_net, pi.contiguous(), P.contiguous(), seed=key,
+                                          sample_offset=int(self._reward_sample_offset))
         with torch.no_grad():                                                    # shapes outside the kernel's range
             return self.reward_net(pi, P).reshape(-1).float().contiguous()
 
@@ -142,13 +147,18 @@ class AC_IRL(actor_critic):
     # ------------------------------------------------------------------ a9 (IRL flavour)
     def train(self, max_episodes=4000, stop_criteria=0.01, gamma=1, constant=False, lr_critic=0.1, lr_actor=0.001,
               consecutive=100, file_theta='results/theta.csv', file_pi='results/pi.csv',
-              file_reward='results/reward.csv', write_file=0, write_all=0, reward_fn=None):
+              file_reward='results/reward.csv', write_file=0, write_all=0, reward_fn=None, *, first_episode=0):
         """Forward actor-critic under the learned reward (ac_irl.py:634-732).  ``reward_fn(pi, P) -> [B]``
-        overrides the reward network (used by the parity tests with a closed-form reward)."""
+        overrides the reward network (used by the parity tests with a closed-form reward).
+        first_episode: episodes already run before a resume (the lr/(episode+1) schedule and the episode counter
+        continue from there; the reference always starts at 1)."""
         d, T = self.d, EPISODE_STEPS
         if self.verbose:
             print('----- Starting train -----')
         shard = current_shard(self.batch, self.group)
+        if shard.world > self.batch:
+            raise ValueError('batch=%d is smaller than the world size %d: every rank needs a trajectory'
+                             % (self.batch, shard.world))
         F = ops.num_features(d)
         G = torch.zeros(F + 3, dtype=torch.float64, device=self.device)
         ws = ops.workspace(shard.local_batch, d, self.device)
@@ -172,7 +182,7 @@ class AC_IRL(actor_critic):
         list_reward = []
         episode = 0
         pi = None
-        for episode in range(1, max_episodes + 1):
+        for episode in range(1 + first_episode, max_episodes + 1):
             pi = ops.gather_start(self._mat_pi0_dev, self._draw_start(shard))
             discount = 1.0
             total_reward = torch.zeros(1, dtype=torch.float64, device=self.device)
@@ -187,6 +197,7 @@ class AC_IRL(actor_critic):
                                 precision=self.precision, out=ebufs)
                 self._rng_step += T
                 states = o['pi_traj'][:, :T].reshape(Bl * T, d)
+                self._reward_sample_offset = shard.traj_offset * T
                 r = rfn(states, o['P'].view(Bl * T, d, d))
                 ops.grad_accumulate(o['pi_traj'], o['delta'].view(-1), o['g'].view(-1), r, G, ws_ep, T=T, add_reward=True)
                 all_reduce_gradients_(G, self.group)
@@ -209,6 +220,7 @@ class AC_IRL(actor_critic):
                     pi_next = o['pi_last']
                     if write_all:
                         self._write_all(pi, P, step + 1)
+                    self._reward_sample_offset = shard.traj_offset
                     r = rfn(pi, P)
                     ops.grad_accumulate(pi, dg[0], dg[1], r, G, ws, add_reward=True, accumulate=acc)
                 else:
@@ -216,6 +228,7 @@ class AC_IRL(actor_critic):
                     pi_next, _ = ops.step_given_P(pi, P, want_reward=False)
                     if write_all:
                         self._write_all(pi, P, step + 1)
+                    self._reward_sample_offset = shard.traj_offset
                     r = rfn(pi, P)
                     ops.td_pg_accumulate(pi, pi_next, P, r, self._w, self._theta, self.shift, discount, G=G, ws=ws,
                                          precision=self.precision, out=dg, accumulate=acc)
@@ -297,10 +310,24 @@ class AC_IRL(actor_critic):
         """actor_critic.state_dict() plus the reward network, its optimiser, the policy FIFO and the counters of the
         outer loop (the reference only saves the TF reward net, ac_irl.py:948)."""
         st = super().state_dict()
+        ver, internal, gauss = random.getstate()
+        gen_pi = [[np.asarray(p[0], dtype=np.float64) for p in traj] for traj in self.list_generated]
+        gen_P = [[np.asarray(p[1], dtype=np.float64) for p in traj] for traj in self.list_generated]
         st.update({'reward_net': self.reward_net.state_dict(), 'optimizer': self.optimizer.state_dict(),
                    'list_policies': [float(np.ravel(t)[0]) for t in self.list_policies],
+                   'theta_initial': float(np.ravel(self.theta_initial)[0]),
                    'reward_update_count': int(getattr(self, 'reward_update_count', 0)),
-                   'gen_traj_counter': int(getattr(self, '_gen_traj_counter', 1 << 40))})
+                   'reward_calls': int(self._reward_calls),
+                   'gen_traj_counter': int(getattr(self, '_gen_traj_counter', 1 << 40)),
+                   # D_samp (ac_irl.py:79, :927-932) as two tensors [M,15,d], [M,15,d,d]
+                   'list_generated_pi': torch.as_tensor(np.array(gen_pi)) if gen_pi else torch.zeros(0),
+                   'list_generated_P': torch.as_tensor(np.array(gen_P)) if gen_P else torch.zeros(0),
+                   # host RNG streams a resumed run consumes: Python `random` (update_reward's random.sample) and
+                   # torch's CPU / device generators (dropout in the training-mode reward net)
+                   'py_random_version': int(ver), 'py_random_state': torch.tensor(internal, dtype=torch.int64),
+                   'py_random_gauss': gauss,
+                   'torch_rng_state': torch.get_rng_state(),
+                   'torch_cuda_rng_state': torch.cuda.get_rng_state(self.device)})
         return st
 
     def load_state_dict(self, state, restore_np_random=True):
@@ -310,6 +337,18 @@ class AC_IRL(actor_critic):
         self.list_policies = list(state['list_policies'])
         self.reward_update_count = int(state['reward_update_count'])
         self._gen_traj_counter = int(state['gen_traj_counter'])
+        self.theta_initial = state.get('theta_initial', self.theta_initial)
+        self._reward_calls = int(state.get('reward_calls', 0))
+        if 'list_generated_pi' in state and state['list_generated_pi'].numel():
+            gp, gP = state['list_generated_pi'].numpy(), state['list_generated_P'].numpy()
+            self.list_generated = [[(gp[m, t], gP[m, t]) for t in range(gp.shape[1])] for m in range(gp.shape[0])]
+        elif 'list_generated_pi' in state:
+            self.list_generated = []
+        if restore_np_random and 'py_random_state' in state:
+            random.setstate((int(state['py_random_version']), tuple(int(v) for v in state['py_random_state']),
+                             state['py_random_gauss']))
+            torch.set_rng_state(state['torch_rng_state'].cpu())
+            torch.cuda.set_rng_state(state['torch_cuda_rng_state'].cpu(), self.device)
 
     # ------------------------------------------------------------------ importance weights (ac_irl.py:270-379)
     def calc_pdf_action(self, theta, action, state, log=False):

@@ -150,6 +150,9 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
   if (want_v) {
     for (int k = tid; k < F; k += BLOCK) wl[k] = a.w[k];
   }
+  // wl is staged block-wide but read by every wave; the per-step barriers below may be wave-local, so order the
+  // staging against all later reads once, here (one block barrier per launch)
+  __syncthreads();
   // A wave only ever touches the tile rows / state slots of its OWN G trajectories, so when nothing is staged
   // or copied out block-wide (SAMPLE without P_out) the per-step barriers need not span the block: waves of a
   // block then run their serial chains without waiting for the slowest of the four.

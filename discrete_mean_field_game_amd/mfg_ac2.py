@@ -32,7 +32,7 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .parallel import all_reduce_gradients_, current_shard, lr_scales
+from .parallel import all_reduce_gradients_, broadcast_start_indices, current_shard, lr_scales
 
 EPISODE_STEPS = 15  # mfg_ac2.py:478
 
@@ -90,6 +90,7 @@ class actor_critic:
         self.num_start_samples = self.mat_pi0.shape[0]
         self._single = False
         self._pi_alpha = None      # state of the last sample_action (hidden coupling of mfg_ac2.py:219-234)
+        self._theta_at_sample = self._theta.clone()   # theta the last sample_action ran with (mat_alpha attributes)
         self._rng_step = 0         # Philox step counter (advances once per env step)
         self.trace = None          # set to [] to record theta after every update (parity tests)
 
@@ -216,10 +217,14 @@ class actor_critic:
         """Everything a run needs to resume bit for bit: theta, w (fp64, device values copied to the host), the Philox
         step counter and seed, the policy hyper-parameters and the global np.random state (start-state draws).
         The reference keeps no RL checkpoint at all (only CSV logs); `torch.save(obj.state_dict(), path)` is ours."""
+        # tensors and plain Python scalars only, so torch.load(weights_only=True) can read the file: the legacy MT19937
+        # state tuple ('MT19937', key[624] uint32, pos, has_gauss, cached_gaussian) is stored field by field
+        name, key, pos, has_gauss, cached = np.random.get_state()
         return {'theta': float(self._theta.cpu()[0]), 'theta_is_array': bool(self._theta_is_array),
                 'w': self._w.cpu().clone(), 'rng_step': int(self._rng_step), 'seed': int(self.seed),
                 'shift': float(self.shift), 'alpha_scale': float(self.alpha_scale), 'd': int(self.d),
-                'np_random_state': np.random.get_state()}
+                'np_random_key': torch.as_tensor(key.astype(np.int64)), 'np_random_pos': int(pos),
+                'np_random_has_gauss': int(has_gauss), 'np_random_cached_gaussian': float(cached)}
 
     def load_state_dict(self, state, restore_np_random=True):
         if int(state['d']) != int(self.d):
@@ -231,8 +236,9 @@ class actor_critic:
         self.seed = int(state['seed'])
         self.shift = state['shift']
         self.alpha_scale = state['alpha_scale']
-        if restore_np_random and state.get('np_random_state') is not None:
-            np.random.set_state(state['np_random_state'])
+        if restore_np_random and state.get('np_random_key') is not None:
+            np.random.set_state(('MT19937', state['np_random_key'].numpy().astype(np.uint32), int(state['np_random_pos']),
+                                 int(state['np_random_has_gauss']), float(state['np_random_cached_gaussian'])))
 
     # ------------------------------------------------------------------ a1 + a2
     def _host_gamma(self, pi_dev):
@@ -315,10 +321,15 @@ class actor_critic:
 
     # ------------------------------------------------------------------ a9: train
     def _draw_start(self, shard):
+        """Start-state indices of this rank's trajectories.  The GLOBAL index vector is drawn from the process-global
+        legacy np.random stream (one scalar draw at batch 1, the reference's :466); with several ranks, rank 0's draw
+        is broadcast, so the ranks need not share a host seed, and every rank keeps its shard of it."""
         if self.batch == 1:
             idx = np.array([np.random.randint(self.num_start_samples)])      # the reference's single draw (:466)
         else:
             idx = np.random.randint(self.num_start_samples, size=self.batch)
+        if shard.world > 1:
+            idx = broadcast_start_indices(idx, self.group, self.device)
             idx = idx[shard.traj_offset:shard.traj_offset + shard.local_batch]
         return torch.as_tensor(idx.astype(np.int32), device=self.device)
 
@@ -332,6 +343,9 @@ class actor_critic:
         d, T = self.d, EPISODE_STEPS
         shard = current_shard(self.batch, self.group)
         Bl = shard.local_batch
+        if shard.world > self.batch:
+            raise ValueError('batch=%d is smaller than the world size %d: every rank needs a trajectory'
+                             % (self.batch, shard.world))
         F = ops.num_features(d)
         G = torch.zeros(F + 3, dtype=torch.float64, device=self.device)
         ws = ops.workspace(Bl * T, d, self.device)
@@ -451,13 +465,18 @@ class actor_critic:
             self._rng_step += T
             traj = out['pi_traj']
         else:
-            rows = [pi_dev]
-            pi = pi_dev
-            for _ in range(T):
-                P = self._sample(pi)
-                pi, _r = ops.step_given_P(pi, P, want_reward=False)
-                rows.append(pi)
-            traj = torch.stack(rows, dim=1)
+            # rng='numpy': the reference generates each trajectory to completion before the next one starts
+            # (evaluate, mfg_ac2.py:629-633 -> :585-590), so the legacy np.random stream is consumed trajectory-major
+            trajs = []
+            for b in range(pi_dev.shape[0]):
+                pi = pi_dev[b:b + 1].contiguous()
+                rows = [pi]
+                for _ in range(T):
+                    P = self._sample(pi)
+                    pi, _r = ops.step_given_P(pi, P, want_reward=False)
+                    rows.append(pi)
+                trajs.append(torch.cat(rows, dim=0))
+            traj = torch.stack(trajs, dim=0)
         return self._out(traj, pi0, single)
 
     _EVAL_HEADER = ('theta,shift,alpha_scale,mean_l1_final,std_l1_final,mean_l1_mean,std_l1_mean,'

@@ -51,6 +51,18 @@ def all_reduce_gradients_(G: torch.Tensor, group=None) -> torch.Tensor:
     return G
 
 
+def broadcast_start_indices(idx, group=None, device=None):
+    """Rank 0's start-state index vector for every rank (int64 numpy in, int64 numpy out).  A few KB once per episode;
+    goes through a device tensor under RCCL ("nccl" has no host tensors) and through the host under gloo."""
+    import numpy as np
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return idx
+    on_dev = dist.get_backend(group) == 'nccl'
+    t = torch.as_tensor(np.ascontiguousarray(idx, dtype=np.int64), device=device if on_dev else 'cpu')
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return t.cpu().numpy()
+
+
 def lr_scales(episode: int, constant) -> tuple:
     """(critic, actor) learning-rate multipliers of the reference schedule in `episode`
     (mfg_ac2.py:511-522: 1/(episode+1) and 1/((episode+1) ln ln(episode+20)); 1, 1 if constant)."""

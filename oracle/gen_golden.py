@@ -64,6 +64,11 @@ def quiet():
     return contextlib.redirect_stdout(io.StringIO())
 
 
+def read_text(path):
+    with open(path) as f:
+        return f.read()
+
+
 # --------------------------------------------------------------------------
 def part_mfg_ac2(scratch):
     sys.dont_write_bytecode = True
@@ -193,6 +198,137 @@ def part_mfg_ac2(scratch):
     traj = a.generate_trajectory(a.mat_pi0[1], 16)
     np.savez_compressed(os.path.join(OUT, 'generate_trajectory_mfg_ac2.npz'), seed=6, pi0=a.mat_pi0[1],
                         theta=8.86349, shift=0.16, alpha_scale=12000., total_hours=16, traj=traj)
+
+
+# --------------------------------------------------------------------------
+def part_host_io(scratch):
+    """Rows a12 / f2 / f4: the reference's own file bookkeeping and evaluation, run unmodified on
+    synthetic files in its on-disk formats.  Stored: the input files' numbers, the directory order the reference saw
+    (os.listdir order decides the np.random consumption order of evaluate), every returned value and every text line
+    it wrote."""
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    os.chdir(scratch)
+    d = 21
+    write_start_states(scratch, d, 4, seed=0)
+    import mfg_ac2
+    out = {}
+
+    # ---- normalize (mfg_ac2.py:116-137) -> init_pi0 (:179-208) round trip: raw count files with a header line ----
+    rs = np.random.RandomState(31)
+    os.makedirs('train_round2'); os.makedirs('norm_out')
+    raw = rs.randint(0, 500, size=(3, 16, d + 3)).astype(np.float64)
+    raw[:, :, 0] += 1                                      # no all-zero row
+    for k in range(3):
+        with open('train_round2/trend_distribution_day%d.csv' % (k + 1), 'w') as f:
+            f.write(','.join('topic%d' % j for j in range(d + 3)) + '\n')
+            for row in raw[k]:
+                f.write(','.join('%d' % v for v in row) + '\n')
+    a = mfg_ac2.actor_critic()
+    a.normalize(indir='train_round2', outdir='norm_out', header=True)
+    out['normalize_raw'] = raw
+    out['normalize_text'] = np.array([read_text('norm_out/trend_distribution_day%d.csv' % (k + 1)) for k in range(3)])
+    a.init_pi0(path_to_dir=os.getcwd() + '/norm_out')
+    out['normalize_mat_pi0'] = a.mat_pi0.copy()
+
+    # ---- evaluate (mfg_ac2.py:595-670) and gridsearch (:673-689) on a synthetic test set --------------------------
+    rs = np.random.RandomState(32)
+    os.makedirs('test_normalized_round2'); os.makedirs('eval_mfg_round2')
+    emp = []
+    for day in range(22, 26):
+        m = rs.dirichlet(np.ones(d + 2), size=16)
+        if day == 23:
+            m[5, 3] = 0.0                                  # a zero entry: the 1e-100 rule of JSD (:556-557)
+        np.savetxt('test_normalized_round2/trend_distribution_day%d.csv' % day, m, fmt='%.3e', delimiter=' ')
+        emp.append(np.loadtxt('test_normalized_round2/trend_distribution_day%d.csv' % day, delimiter=' '))
+    order = os.listdir(os.getcwd() + '/test_normalized_round2')
+    out['eval_files'] = np.array(sorted(order))
+    out['eval_listdir_order'] = np.array(order)
+    out['eval_emp'] = np.array(emp)                        # [4,16,d+2], files in sorted-name order (day 22..25)
+    np.random.seed(91)
+    a = mfg_ac2.actor_critic()
+    np.random.seed(92)
+    res = a.evaluate(theta=8.86349, shift=0.5, alpha_scale=1e4, d=d, outfile='eval_mfg_round2/e.csv', write_header=1)
+    out['eval_seed'] = 92
+    out['eval_args'] = np.array([8.86349, 0.5, 1e4])
+    out['eval_result'] = np.array(res)
+    out['eval_csv'] = np.array(read_text('eval_mfg_round2/e.csv'))
+    thetas, shifts, alphas = [7.0, 8.86349], [0.16, 0.5], [1e3, 1e4]
+    np.random.seed(93)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        a.gridsearch(thetas, shifts, alphas, indir='test_normalized_round2', outfile='eval_mfg_round2/g.csv')
+    best = eval(buf.getvalue().strip().split('\n')[-1], {'np': np, 'array': np.array, 'float64': np.float64})
+    out['grid_seed'] = 93
+    out['grid_thetas'] = np.array(thetas); out['grid_shifts'] = np.array(shifts); out['grid_alphas'] = np.array(alphas)
+    out['grid_best'] = np.array([[float(v) for v in row] for row in best])     # printed argmin table (:689)
+    out['grid_csv'] = np.array(read_text('eval_mfg_round2/g.csv'))
+
+    # ---- train(write_file=1): the CSV log schema (mfg_ac2.py:441-445, :536-539) -----------------------------------
+    os.makedirs('results')
+    np.random.seed(2025)
+    a = mfg_ac2.actor_critic()
+    out['log_w0'] = a.w.copy()
+    out['log_mat_pi0'] = a.mat_pi0.copy()
+    with quiet():
+        a.train(num_episodes=5, gamma=0.9, constant=0, consecutive=2, write_file=1)
+    out['log_seed'] = 2025
+    for name in ('theta', 'pi', 'reward'):
+        out['log_' + name] = np.array(read_text('results/%s.csv' % name))
+    out['log_theta_final'] = np.ravel(a.theta)[0]
+    np.savez_compressed(os.path.join(OUT, 'host_io_mfg_ac2.npz'), **out)
+
+
+def part_demonstrations(scratch):
+    """f4: ac_irl.read_demonstrations / init_pi0_test / get_eval_transitions (ac_irl.py:164-219, :476-506) on files in
+    the reference's layout.  read_demonstrations calls `pd.read_table(...).as_matrix()`; `pd` is only imported on
+    Windows (ac_irl.py:16-22) and pandas 2.x removed DataFrame.as_matrix (it was an alias of `.values`), so the module
+    global `pd` is bound to the REAL pandas with that one alias restored -- parsing is pandas' own."""
+    import types
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    os.chdir(scratch)
+    d, dim_action = 15, 20
+    sys.modules['tensorflow'] = types.ModuleType('tensorflow')
+    import pandas
+    import ac_irl
+
+    class _Frame:
+        def __init__(self, df):
+            self.df = df
+
+        def as_matrix(self):
+            return self.df.values
+
+    pd_alias = types.SimpleNamespace(read_table=lambda *a, **k: _Frame(pandas.read_table(*a, **k)))
+    ac_irl.pd = pd_alias
+    rs = np.random.RandomState(41)
+    os.makedirs('states'); os.makedirs('actions')
+    states, actions = [], []
+    for day in range(22, 25):
+        st = rs.dirichlet(np.ones(dim_action), size=16)
+        np.savetxt('states/trend_distribution_day%d.csv' % day, st, fmt='%.3e', delimiter=' ')
+        with open('actions/action_day%d.txt' % day, 'w') as f:        # 15 blocks of dim_action rows, blank line after each
+            for hour in range(15):
+                blk = rs.dirichlet(np.ones(dim_action), size=dim_action)
+                for row in blk:
+                    row.tofile(f, sep=' ', format='%.3e')
+                    f.write('\n')
+                f.write('\n')
+        states.append(read_text('states/trend_distribution_day%d.csv' % day))
+        actions.append(read_text('actions/action_day%d.txt' % day))
+    a = object.__new__(ac_irl.AC_IRL)
+    a.d = d
+    with quiet():
+        demos = a.read_demonstrations('states', 'actions', dim_action, 22)
+    a.init_pi0_test(path_to_dir=os.getcwd() + '/states', day_start=22)
+    ev = a.get_eval_transitions(demos * 6)                              # 18 trajectories: index mod 15 wraps
+    np.savez_compressed(os.path.join(OUT, 'demonstrations_ac_irl.npz'), d=d, dim_action=dim_action, start_day=22,
+                        state_text=np.array(states), action_text=np.array(actions),
+                        demo_pi=np.array([[p[0] for p in t] for t in demos]),
+                        demo_P=np.array([[p[1] for p in t] for t in demos]),
+                        mat_pi0_test=a.mat_pi0_test,
+                        eval_pi=np.array([p[0] for p in ev]), eval_P=np.array([p[1] for p in ev]))
 
 
 # --------------------------------------------------------------------------
@@ -346,13 +482,14 @@ def main():
         if not os.path.isdir(REF):
             sys.exit('reference not present at %s: fixtures can only be regenerated in the build container' % REF)
         os.makedirs(OUT, exist_ok=True)
-        for part in ('mfg_ac2', 'synthetic', 'ac_irl'):
+        for part in ('mfg_ac2', 'host_io', 'demonstrations', 'synthetic', 'ac_irl'):
             with tempfile.TemporaryDirectory() as scratch:
                 subprocess.run([sys.executable, os.path.abspath(__file__), '--part', part, '--scratch', scratch],
                                check=True)
         print('wrote', sorted(os.listdir(OUT)))
         return
-    {'mfg_ac2': part_mfg_ac2, 'synthetic': part_synthetic, 'ac_irl': part_ac_irl}[args.part](args.scratch)
+    {'mfg_ac2': part_mfg_ac2, 'host_io': part_host_io, 'demonstrations': part_demonstrations,
+     'synthetic': part_synthetic, 'ac_irl': part_ac_irl}[args.part](args.scratch)
 
 
 if __name__ == '__main__':

@@ -372,6 +372,26 @@ def train_mfg_ac2(mat_pi0, w, theta, shift, alpha_scale, num_episodes, gamma=1,
     return out
 
 
+def train_log_lines(out, consecutive):
+    """Text the reference appends to file_theta / file_pi / file_reward with write_file=1 (mfg_ac2.py:441-445,
+    :530-539) for a finished ``train_mfg_ac2`` trace: every ``consecutive``-th episode (from 0) one line each with theta
+    ('%.5e'), the episode's final pi ('%.3e') and sum(returns since the last line) / consecutive ('%.3e')."""
+    import io
+
+    def line(vec, fmt):
+        return ','.join(fmt % v for v in np.ravel(vec)) + '\n'
+    th = pi = rw = ''
+    acc = []
+    for ep in range(len(out['total_reward'])):
+        acc.append(out['total_reward'][ep])
+        if ep % consecutive == 0:
+            th += line([out['theta'][EPISODE_STEPS * (ep + 1) - 1]], '%.5e')
+            pi += line(out['pi_final'][ep], '%.3e')
+            rw += line([sum(acc) / consecutive], '%.3e')
+            acc = []
+    return th, pi, rw
+
+
 def train_ac_irl(mat_pi0, w, theta, shift, alpha_scale, max_episodes, reward_fn,
                  stop_criteria=0.01, gamma=1, constant=False, lr_critic=0.1,
                  lr_actor=0.001, rng=np.random):
@@ -449,6 +469,74 @@ def generate_trajectories(n, mat_pi0, theta, shift, alpha_scale, rng=np.random):
             pi = transition(P, pi)
         out.append(traj)
     return out
+
+
+# --------------------------------------------------------------------------
+# f2: evaluate / gridsearch (mfg_ac2.py:595-689)
+# --------------------------------------------------------------------------
+def evaluate(list_empirical, theta, shift, alpha_scale, d, episode_length=16, rng=np.random):
+    """Restatement of ``actor_critic.evaluate`` (mfg_ac2.py:595-670) on the test matrices in the order the reference
+    met them (its ``os.listdir`` order: every test trajectory is generated to completion before the next file is read,
+    which fixes the np.random consumption order).  Returns the eight statistics
+    (mean_l1_final, std_l1_final, mean_l1_mean, std_l1_mean, mean_JSD_final, std_JSD_final, mean_JSD_mean, std_JSD_mean).
+    """
+    n = len(list_empirical)
+    a_l1f, a_l1m, a_jf, a_jm = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
+    for idx, mat in enumerate(list_empirical):
+        mat_empirical = np.array(mat, dtype=np.float64)[:, 0:d]
+        traj = generate_trajectory(mat_empirical[0], episode_length, theta, shift, alpha_scale, rng)
+        a_l1f[idx] = np.sum(np.abs(traj[-1] - mat_empirical[-1]))                   # norm(., ord=1), :636
+        diff = mat_empirical - traj
+        a_l1m[idx] = np.mean(np.sum(np.abs(diff), axis=1))                          # :640-641
+        a_jf[idx] = JSD(traj[-1], mat_empirical[-1])                                # :645
+        jm = 0
+        for idx2 in range(episode_length):                                          # :649-653
+            jm += JSD(mat_empirical[idx2], traj[idx2])
+        a_jm[idx] = jm / episode_length
+    return (np.mean(a_l1f), np.std(a_l1f), np.mean(a_l1m), np.std(a_l1m),
+            np.mean(a_jf), np.std(a_jf), np.mean(a_jm), np.std(a_jm))
+
+
+def format_eval_line(theta, shift, alpha_scale, stats):
+    """The CSV line evaluate() appends (mfg_ac2.py:668)."""
+    return "%f,%f,%f,%.3e,%.3e,%.3e,%.3e,%.3e,%.3e,%.3e,%.3e\n" % ((theta, shift, alpha_scale) + tuple(stats))
+
+
+def gridsearch(list_empirical, theta_range, shift_range, alpha_range, d, rng=np.random):
+    """mfg_ac2.py:673-689: evaluate every (theta, shift, alpha_scale) in nested-loop order, keep the argmin (ties go
+    to the LATER point: ``<=``) of mean_l1_final, mean_l1_mean, mean_JSD_final, mean_JSD_mean.  Returns
+    (list_tuples, csv_text)."""
+    list_tuples = [[100, 0, 0, 0], [100, 0, 0, 0], [100, 0, 0, 0], [100, 0, 0, 0]]
+    text = ''
+    for theta in theta_range:
+        for shift in shift_range:
+            for alpha_scale in alpha_range:
+                st = evaluate(list_empirical, theta, shift, alpha_scale, d, 16, rng)
+                text += format_eval_line(theta, shift, alpha_scale, st)
+                result = (st[0], st[2], st[4], st[6])
+                for idx in range(4):
+                    if result[idx] <= list_tuples[idx][0]:
+                        list_tuples[idx] = [result[idx], theta, shift, alpha_scale]
+    return list_tuples, text
+
+
+def normalize_rows_text(matrix):
+    """mfg_ac2.py:116-137: rows divided by their sums, written as '%.3e' space separated text."""
+    import io
+    matrix = np.asarray(matrix, dtype=np.float64)
+    matrix = matrix / np.sum(matrix, axis=1, keepdims=True)
+    buf = io.BytesIO()
+    np.savetxt(buf, matrix, fmt='%.3e', delimiter=' ')
+    return buf.getvalue().decode()
+
+
+def read_demonstration_day(state_text, action_text, d, dim_action=20):
+    """ac_irl.py:164-200 for one day: 15 (state [d], action [d,d]) pairs from the text of a state file (16 rows) and
+    of an action file (15 blocks of dim_action rows, blank lines skipped by the parser)."""
+    states = np.array([[float(v) for v in line.split(' ')] for line in state_text.strip().split('\n')])
+    rows = [line for line in action_text.split('\n') if line.strip() != '']
+    actions = np.array([[float(v) for v in line.split(' ')] for line in rows])
+    return [(states[hour, 0:d], actions[hour * dim_action:(hour * dim_action + d), 0:d]) for hour in range(15)]
 
 
 # --------------------------------------------------------------------------

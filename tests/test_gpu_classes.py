@@ -503,7 +503,7 @@ def test_checkpoint_resume_is_bit_identical(dev, mode, tmp_path):
     torch.save(b.state_dict(), str(tmp_path / 'ck.pt'))
     np.random.seed(999)                                   # scramble everything that is not in the checkpoint
     c = AC(d=d, pi0=mat, batch=B, seed=77, update_every=mode, verbose=0)
-    c.load_state_dict(torch.load(str(tmp_path / 'ck.pt'), weights_only=False))
+    c.load_state_dict(torch.load(str(tmp_path / 'ck.pt'), weights_only=True))   # tensors + scalars only
     c.train(num_episodes=2, gamma=0.9, first_episode=2)     # the lr/(episode+1) schedule continues at episode 2
     assert np.array_equal(np.ravel(a.theta), np.ravel(c.theta))
     assert np.array_equal(a.w, c.w)
@@ -522,3 +522,157 @@ def test_check_finite_raises_like_the_reference_warning_filter(dev):
     ok = AC(d=d, pi0=rs.dirichlet(np.ones(d), size=4), batch=32, seed=1, update_every='rollout', verbose=0)
     ok.train(num_episodes=3, lr_actor=1e300, lr_critic=1e300)  # default: unchecked, like running with warnings ignored
     assert not np.isfinite(np.ravel(ok.theta)[0]) or not np.all(np.isfinite(ok.w))
+
+
+@pytest.mark.parametrize('mode', ['step', 'rollout'])
+def test_ac_irl_checkpoint_resume_is_bit_identical(dev, mode, tmp_path):
+    """AC_IRL.state_dict carries everything a resumed IRL run consumes: the reward net + Adam state, the dropout-mask
+    call counter of the HIP reward net, Python's `random` state (random.sample in update_reward), torch's generators
+    (training-mode dropout), theta_initial, D_samp (list_generated) and the policy FIFO.  reward updates + 2 + 2
+    forward episodes through a saved file equal the uninterrupted run bit for bit (dropout active: reg='dropout_l1l2')."""
+    import random
+    d, B = 15, 48
+    rs = np.random.RandomState(2)
+    mat = rs.dirichlet(np.ones(d), size=5)
+    demos = [[(rs.dirichlet(np.ones(d)), rs.dirichlet(np.ones(d), size=d)) for _ in range(15)] for _ in range(6)]
+
+    def fresh(seed):
+        np.random.seed(3); torch.manual_seed(3); random.seed(3)
+        return IRL(d=d, pi0=mat, demonstrations=demos, batch=B, num_policies=2, seed=seed, update_every=mode, verbose=0)
+
+    def phase1(ac):
+        ac.list_generated = ac.generate_trajectories(6)
+        ac.list_eval_gen_transitions = [p for t in ac.list_generated for p in t]
+        ac.reward_iteration(max_iterations=4, stop_criteria=-1, iter_check=2)
+        ac.train(max_episodes=2, stop_criteria=-1, gamma=0.9)
+
+    def phase2(ac, first):
+        ac.reward_iteration(max_iterations=3, stop_criteria=-1, iter_check=2)
+        ac.train(max_episodes=4, stop_criteria=-1, gamma=0.9, first_episode=first)
+
+    a = fresh(4)
+    phase1(a)
+    ac_state_after_1 = (a._reward_calls, a._rng_step)
+    phase2(a, 2)
+    b = fresh(4)
+    phase1(b)
+    assert (b._reward_calls, b._rng_step) == ac_state_after_1
+    torch.save(b.state_dict(), str(tmp_path / 'irl.pt'))
+    np.random.seed(999); torch.manual_seed(999); random.seed(999)        # scramble what is not in the checkpoint
+    torch.rand(7, device=dev)
+    c = IRL(d=d, pi0=mat, demonstrations=demos, batch=B, num_policies=2, seed=77, update_every=mode, verbose=0)
+    c.load_state_dict(torch.load(str(tmp_path / 'irl.pt'), weights_only=True))
+    c.list_eval_gen_transitions = [p for t in c.list_generated for p in t]
+    assert len(c.list_generated) == 6 and np.array_equal(c.list_generated[3][7][1], b.list_generated[3][7][1])
+    phase2(c, 2)
+    assert np.array_equal(np.ravel(a.theta), np.ravel(c.theta))
+    assert np.array_equal(a.w, c.w)
+    for pa, pc in zip(a.reward_net.parameters(), c.reward_net.parameters()):
+        assert torch.equal(pa, pc)
+    assert a._reward_calls == c._reward_calls and a._rng_step == c._rng_step
+    assert [float(np.ravel(t)[0]) for t in a.list_policies] == [float(np.ravel(t)[0]) for t in c.list_policies]
+
+
+# ---- f2 / f4 pinned to the unmodified reference (tests/golden/host_io_mfg_ac2.npz) ---------------------------------------
+def _eval_setup(z, tmp_path, monkeypatch):
+    """Recreate the test files the reference evaluated and make os.listdir return them in the order the reference's
+    filesystem did: evaluate() generates one trajectory per file in listdir order, so that order IS the np.random
+    consumption order."""
+    import discrete_mean_field_game_amd.mfg_ac2 as M
+    monkeypatch.chdir(tmp_path)
+    os.makedirs('test_normalized_round2'); os.makedirs('out')
+    for name, m in zip(z['eval_files'], z['eval_emp']):
+        np.savetxt('test_normalized_round2/' + str(name), m, fmt='%.3e', delimiter=' ')
+    real = os.listdir
+    order = [str(n) for n in z['eval_listdir_order']]
+    monkeypatch.setattr(M.os, 'listdir', lambda p: order if str(p).rstrip('/').endswith('test_normalized_round2') else real(p))
+
+
+def _csv_close(got, want, rel=2.5e-3):
+    """Same number of lines / fields, leading (theta, shift, alpha_scale) text identical, '%.3e' fields within one unit
+    of the last printed digit (fp32 storage of states and actions vs the reference's fp64)."""
+    gl, wl = got.strip().split('\n'), want.strip().split('\n')
+    assert len(gl) == len(wl)
+    for a, b in zip(gl, wl):
+        fa, fb = a.split(','), b.split(',')
+        assert len(fa) == len(fb)
+        if not fb[0][0].isdigit():
+            assert a == b                                              # header line
+            continue
+        assert fa[:3] == fb[:3]
+        for x, y in zip(fa[3:], fb[3:]):
+            assert len(x) == len(y) and abs(float(x) - float(y)) <= rel * abs(float(y))
+
+
+@pytest.mark.parametrize('precision', ['mixed', 'f64'])
+def test_evaluate_retraces_reference(dev, tmp_path, monkeypatch, precision):
+    """evaluate() with rng='numpy' consumes np.random trajectory-major like mfg_ac2.py:629-633 and reproduces the
+    reference's returned tuple and CSV line."""
+    z = np.load(os.path.join(G, 'host_io_mfg_ac2.npz'))
+    _eval_setup(z, tmp_path, monkeypatch)
+    theta, shift, scale = (float(v) for v in z['eval_args'])
+    np.random.seed(0)
+    ac = AC(d=21, pi0=np.eye(21)[:2], rng='numpy', precision=precision)
+    np.random.seed(int(z['eval_seed']))
+    res = ac.evaluate(theta=theta, shift=shift, alpha_scale=scale, d=21, outfile='out/e.csv', write_header=1)
+    assert np.max(np.abs(np.array(res) - z['eval_result']) / z['eval_result']) < 2e-6
+    with open('out/e.csv') as f:
+        _csv_close(f.read(), str(z['eval_csv']))
+
+
+def test_gridsearch_retraces_reference(dev, tmp_path, monkeypatch):
+    z = np.load(os.path.join(G, 'host_io_mfg_ac2.npz'))
+    _eval_setup(z, tmp_path, monkeypatch)
+    np.random.seed(0)
+    ac = AC(d=21, pi0=np.eye(21)[:2], rng='numpy')
+    np.random.seed(int(z['grid_seed']))
+    best = ac.gridsearch(list(z['grid_thetas']), list(z['grid_shifts']), list(z['grid_alphas']),
+                         indir='test_normalized_round2', outfile='out/g.csv')
+    with open('out/g.csv') as f:
+        _csv_close(f.read(), str(z['grid_csv']))
+    want = z['grid_best']
+    for k in range(4):
+        assert abs(best[k][0] - want[k, 0]) < 2e-6 * want[k, 0]
+        assert tuple(best[k][1:]) == tuple(want[k, 1:])                # same argmin grid point
+
+
+def test_train_write_file_csv_schema_matches_reference(dev, tmp_path, monkeypatch):
+    """train(write_file=1) appends the reference's three CSV logs (mfg_ac2.py:441-445, :536-539): one line per
+    `consecutive` episodes with theta '%.5e', the final pi '%.3e', the windowed average return '%.3e'."""
+    z = np.load(os.path.join(G, 'host_io_mfg_ac2.npz'))
+    monkeypatch.chdir(tmp_path)
+    os.makedirs('results')
+    np.random.seed(int(z['log_seed']))
+    ac = AC(d=21, pi0=z['log_mat_pi0'], batch=1, rng='numpy', update_every='step', precision='f64')
+    assert np.array_equal(ac.w, z['log_w0'])
+    ac.train(num_episodes=5, gamma=0.9, constant=0, consecutive=2, write_file=1)
+    for name, rel in (('theta', 2e-6), ('pi', 2.5e-3), ('reward', 2.5e-3)):
+        with open('results/%s.csv' % name) as f:
+            got = f.read()
+        want = str(z['log_' + name])
+        gl, wl = got.strip().split('\n'), want.strip().split('\n')
+        assert len(gl) == len(wl) == 3
+        for a, b in zip(gl, wl):
+            fa, fb = a.split(','), b.split(',')
+            assert len(fa) == len(fb)
+            for x, y in zip(fa, fb):
+                assert len(x) == len(y) and abs(float(x) - float(y)) <= rel * abs(float(y)) + 1e-12
+    assert abs(float(np.ravel(ac.theta)[0]) - float(z['log_theta_final'])) < 2e-7
+
+
+def test_ac_irl_generate_trajectories_numpy_rng_retraces_reference(dev):
+    """AC_IRL.generate_trajectories(rng='numpy') on the GPU vs the unmodified reference's (pi, P) pairs
+    (ac_irl.py:735-767: randint then 15 x d gamma vector draws per trajectory, trajectory after trajectory)."""
+    z = np.load(os.path.join(G, 'generate_trajectories_ac_irl.npz'))
+    np.random.seed(0)
+    ac = IRL(theta=float(z['theta']), shift=float(z['shift']), alpha_scale=float(z['alpha_scale']), d=21,
+             pi0=z['mat_pi0'], rng='numpy', use_tf=False, num_policies=3)
+    np.random.seed(int(z['seed']))
+    trajs = ac.generate_trajectories(int(z['n']))
+    assert len(trajs) == 2 and all(len(t) == 15 for t in trajs)
+    pis = np.array([[p[0] for p in t] for t in trajs]); Ps = np.array([[p[1] for p in t] for t in trajs])
+    assert pis.dtype == np.float64 and Ps.shape == (2, 15, 21, 21)
+    assert np.allclose(pis, z['pi'], rtol=5e-6, atol=1e-9)
+    assert np.allclose(Ps, z['P'], rtol=2e-6, atol=1e-12)
+    g = np.array([[ac.calc_gradient_vectorized(Ps[b, t].copy(), pis[b, t]) for t in range(15)] for b in range(2)])
+    assert np.max(np.abs(g - z['gradient']) / np.abs(z['gradient'])) < 1e-4   # mixed-precision score on fp32 inputs
