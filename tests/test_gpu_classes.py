@@ -674,5 +674,8 @@ def test_ac_irl_generate_trajectories_numpy_rng_retraces_reference(dev):
     assert pis.dtype == np.float64 and Ps.shape == (2, 15, 21, 21)
     assert np.allclose(pis, z['pi'], rtol=5e-6, atol=1e-9)
     assert np.allclose(Ps, z['P'], rtol=2e-6, atol=1e-12)
+    ac._pi_alpha = None                        # concentrations from the pi passed in (the fixture recomputed alpha per state)
     g = np.array([[ac.calc_gradient_vectorized(Ps[b, t].copy(), pis[b, t]) for t in range(15)] for b in range(2)])
-    assert np.max(np.abs(g - z['gradient']) / np.abs(z['gradient'])) < 1e-4   # mixed-precision score on fp32 inputs
+    # mixed-precision score on fp32-rounded (pi, P): late in a trajectory g is a 1e-5-sized sum of cancelling O(1e-2) terms,
+    # so the bound is relative to the leading terms, not to g itself
+    assert np.allclose(g, z['gradient'], rtol=1e-5, atol=2e-8)
