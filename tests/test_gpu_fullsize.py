@@ -153,3 +153,134 @@ def test_fullsize_transition_linearity_and_reward_kinds(dev, d, B):
     assert float(((ra[idx].double() - ref_r).abs() / ref_r.abs().clamp_min(1e-4)).max()) < 1e-5
     p3, none = o.step_given_P(a, P, want_reward=False)
     assert none is None and torch.equal(p3, pa)
+
+
+# ---- BASELINE.json configs C3 / C5 (per-GPU share) / C4 at their stated (d, T, B) ----------------------------------------
+def _config_rollout(o, pi0, theta, w, T, seed, lo=0, hi=None, write_P=False):
+    hi = pi0.shape[0] if hi is None else hi
+    out = o.rollout(pi0[lo:hi].contiguous(), T, theta, SHIFT, SCALE, w=w, gamma=0.9, seed=seed, traj_offset=lo, td=True,
+                    write_P=write_P)
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize('d,B,T,nsub', [(128, 16384, 40, 32), (256, 16384, 40, 16)], ids=['C3', 'C5_share'])
+def test_config_full_T_large_d(dev, d, B, T, nsub):
+    """C3 (d=128, T=40, B=16384) and C5's per-GPU share (d=256, T=40, B=131072/8) at their FULL (d, T, B), fused TD
+    rollout without materialised actions (4.3 GB / step at d=256): finiteness, mass conservation over all 40 steps,
+    run-to-run determinism, the gradient checksum, invariance to a ragged split of the batch (what ranks run), and --
+    because the Philox stream is keyed by (global trajectory id, step) -- an `nsub`-trajectory slice re-run with
+    traj_offset + WRITE_P reproduces the big run bit for bit and is then replayed step by step by the oracle
+    (pi_traj indexing, running state, Philox step counters at T=40 on the large-d kernel)."""
+    o = ops()
+    pi0 = start_states(B, d, dev)
+    theta = torch.tensor([THETA], dtype=torch.float64, device=dev)
+    w = torch.as_tensor(np.random.RandomState(1).rand(o.num_features(d)), device=dev)
+    whole = _config_rollout(o, pi0, theta, w, T, seed=23)
+    traj, r, delta, g, G = whole['pi_traj'], whole['reward'], whole['delta'], whole['g'], whole['G']
+    assert tuple(traj.shape) == (B, T + 1, d) and tuple(r.shape) == (B, T)
+    assert torch.isfinite(traj).all() and torch.isfinite(r).all() and torch.isfinite(delta).all() and torch.isfinite(g).all()
+    assert float(traj.min()) >= 0.0
+    mass = traj.double().sum(-1)
+    assert float((mass - mass[:, :1]).abs().max()) < 2e-5
+    assert torch.equal(traj[:, 0], pi0) and torch.equal(traj[:, T], whole['pi_last'])
+    # determinism
+    again = _config_rollout(o, pi0, theta, w, T, seed=23)
+    for k in ('pi_traj', 'reward', 'delta', 'g', 'G'):
+        assert torch.equal(whole[k], again[k]), k
+    del again
+    # gradient checksum (fp64 recomputation of the sums from the per-sample outputs)
+    N = B * T
+    x = traj[:, :T].double().reshape(N, d)
+    dl = delta.reshape(N)
+    M = (x * dl[:, None]).T @ x
+    iu = torch.triu_indices(d, d, device=dev)
+    Q = d * (d + 1) // 2
+    ref_q = M[iu[0], iu[1]]
+    assert float((G[:Q] - ref_q).abs().max()) <= 1e-9 * float(ref_q.abs().max())
+    assert float((G[Q:Q + d] - (x * dl[:, None]).sum(0)).abs().max()) <= 1e-9 * max(1.0, float(dl.abs().sum()))
+    assert abs(float(G[Q + d + 1]) - float((dl * g.reshape(N)).sum())) <= 1e-9 * float((dl * g.reshape(N)).abs().sum())
+    assert abs(float(G[Q + d + 2]) - float(r.double().sum())) <= 1e-9 * float(r.double().abs().sum())
+    assert float(G[Q + d + 3]) == float(N)
+    del x, M
+    # ragged split: shards with traj_offset reproduce the whole run; their gradient buffers add up
+    cuts = [0, 5000, 5000 + 4097, B]
+    Gsum = torch.zeros_like(G)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        part = _config_rollout(o, pi0, theta, w, T, seed=23, lo=lo, hi=hi)
+        assert torch.equal(part['pi_traj'], traj[lo:hi]) and torch.equal(part['delta'], delta[lo:hi])
+        assert torch.equal(part['g'], g[lo:hi]) and torch.equal(part['reward'], r[lo:hi])
+        Gsum += part['G']
+        del part
+    assert float(((Gsum - G).abs() / G.abs().clamp_min(1e-6)).max()) < 1e-9
+    # slice with materialised actions == the big run; oracle replay of the slice on its own actions
+    lo = 7777
+    sub = _config_rollout(o, pi0, theta, w, T, seed=23, lo=lo, hi=lo + nsub, write_P=True)
+    for k in ('pi_traj', 'reward', 'delta', 'g'):
+        assert torch.equal(sub[k], whole[k][lo:lo + nsub]), k
+    P = sub['P'].cpu().numpy()
+    rows = P.astype(np.float64).sum(-1)
+    assert P.min() >= 0.0 and np.abs(rows - 1.0).max() < 4e-6
+    otraj, orr, odl, ogg, _, _ = O().batched_rollout_given_P(pi0[lo:lo + nsub].cpu().numpy(), P, w.cpu().numpy(), THETA,
+                                                            SHIFT, gamma=0.9)
+    np.testing.assert_allclose(sub['pi_traj'].cpu().numpy(), otraj, rtol=0, atol=1e-7)
+    got_r = sub['reward'].cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(got_r - orr) / np.maximum(np.abs(orr), 1e-4)) < 1e-5
+    got_d = sub['delta'].cpu().numpy()
+    assert np.max(np.abs(got_d - odl) / np.maximum(np.abs(odl), 1e-2)) < 1e-5
+    got_g = sub['g'].cpu().numpy()
+    assert np.max(np.abs(got_g - ogg) / np.maximum(np.abs(ogg), 1.0)) < 1e-5
+
+
+@pytest.mark.parametrize('mode', ['step', 'rollout'])
+def test_config_C4_irl_train_with_reward_net_in_the_loop(dev, mode):
+    """C4: AC_IRL.train at d=21, B=4096 with the HIP reward-net kernel inside the loop (reg='l1l2': no dropout, so the
+    run is replayable), one episode with gamma=0.9, replayed by the oracle: actions re-drawn from the same Philox
+    counters, reward = oracle/reward_net_oracle.forward on them, 1-indexed episode schedule, running discount
+    (ac_irl.py:664-712), batch-mean updates per step / once per episode."""
+    from discrete_mean_field_game_amd.ac_irl import AC_IRL
+    from oracle import reward_net_oracle as RO
+    o = ops()
+    d, B, gamma = 21, 4096, 0.9
+    rs = np.random.RandomState(8)
+    mat = rs.dirichlet(np.ones(d), size=64)
+    np.random.seed(31); torch.manual_seed(31)
+    ac = AC_IRL(theta=8.64, shift=0.0, alpha_scale=1e4, d=d, pi0=mat, demonstrations=[], batch=B, rng='philox', seed=13,
+                reg='l1l2', update_every=mode, precision='f64', verbose=0)
+    with torch.no_grad():                                           # non-trivial biases (zero by default)
+        for p in ac.reward_net.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.2, 0.2)
+    assert o.reward_net_supported(ac.reward_net)
+    params = RO.params_from_torch(ac.reward_net)
+    w0 = ac.w[:, 0].copy(); theta0 = float(np.ravel(ac.theta)[0])
+    np.random.seed(32)
+    ac.train(max_episodes=1, stop_criteria=-1, gamma=gamma, constant=False, lr_critic=0.1, lr_actor=0.001)
+    assert ac._reward_calls == (15 if mode == 'step' else 1)        # the kernel path ran (not the torch module)
+    np.random.seed(32)
+    idx = np.random.randint(64, size=B)
+    pi = mat[idx].astype(np.float32)
+    w, theta = w0.copy(), theta0
+    sc, sa = O().lr_scales(1, False)
+    Gw_acc = np.zeros_like(w); Gt_acc = 0.0
+    disc = 1.0
+    for t in range(15):
+        th = torch.tensor([theta], dtype=torch.float64, device=dev)
+        P = o.sample_dirichlet(torch.as_tensor(pi, device=dev), th, 0.0, 1e4, seed=13, step=t, precision='f64').cpu().numpy()
+        pn = O().transition(P, pi).astype(np.float32)
+        r = RO.forward(params, pi.astype(np.float64), P.astype(np.float64))[:, 0]
+        r = r.astype(np.float32).astype(np.float64)                 # the kernel hands the reward over as fp32
+        delta, g, G_w, G_t, _ = O().batched_td_pg(pi, pn, P, r, w, theta, 0.0, disc)
+        if mode == 'step':
+            w = w + 0.1 * sc * G_w / B
+            theta = theta + 0.001 * sa * G_t / B
+        else:
+            Gw_acc += G_w; Gt_acc += G_t
+        disc *= gamma
+        pi = pn
+    if mode == 'rollout':
+        w = w + 0.1 * sc * Gw_acc / (15 * B)
+        theta = theta + 0.001 * sa * Gt_acc / (15 * B)
+    # fp32 reward kernel vs fp64 restatement: rewards agree to ~1e-6 absolute, so the updates agree to ~1e-9
+    assert abs(float(np.ravel(ac.theta)[0]) - theta) < 5e-8
+    assert np.max(np.abs(ac.w[:, 0] - w)) < 5e-8
