@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/mfg_hip.h"
 #include "mfg_device.h"
 
@@ -98,6 +100,35 @@ __device__ __forceinline__ void policy_accumulate(const PolicyElem<FAST>& e, con
     D += e.ad_d;
     gacc = fma(-digamma_pos(e.al_d) + lnv, e.ad_d, gacc);
   }
+}
+
+// Contributions of one finished element to (A, D, g) without folding them: the sampling loops add the terms of a quad
+// (up to four elements) in the working precision -- fp32 in mixed mode -- and fold ONE fp64 add per quantity per quad
+// (a cvt + add_f64 pair costs as much issue time as four fp32 adds).
+template <bool FAST>
+struct PolicyTerms {
+  using T = typename std::conditional<FAST, float, double>::type;
+  T al, ad, gt;
+};
+template <bool SAMPLE, bool FAST>
+__device__ __forceinline__ PolicyTerms<FAST> policy_terms(const PolicyElem<FAST>& e, const float4* __restrict__ htab, float th,
+                                                          float v) {
+  PolicyTerms<FAST> o;
+  if constexpr (FAST) {
+    const float lnv = (!SAMPLE && v == 0.0f) ? (float)LOG_ZERO_P : fast_ln(v);
+    const float z = th * e.x_f;
+    float psi_ad = e.x_f * htab_eval(htab, z);
+    if (z >= HTAB_ZMAX) psi_ad = digamma_pos_fast(e.al_f) * e.ad_f;
+    o.al = e.al_f;
+    o.ad = e.ad_f;
+    o.gt = fmaf(lnv, e.ad_f, -psi_ad);
+  } else {
+    const double lnv = (!SAMPLE && v == 0.0f) ? LOG_ZERO_P : log((double)v);
+    o.al = e.al_d;
+    o.ad = e.ad_d;
+    o.gt = (-digamma_pos(e.al_d) + lnv) * e.ad_d;
+  }
+  return o;
 }
 
 // V(pi) = phi(pi).w, one wavefront per trajectory, lanes own columns c, rows i <= c.  For fixed i the
@@ -210,25 +241,52 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
         const uint64_t traj = a.traj_offset + (uint64_t)b;
         PolicyElem<FAST> pe;
         if (SAMPLE) {
-          // two matrix elements per iteration (one Philox block, two interleaved dependency chains).
-          // Not unrolled further: the body is ~400 instructions and unrolling blows the register budget.
+          // FOUR matrix elements per iteration: one Philox block (quad_rand) feeds two Box-Muller pairs; the row sums
+          // of the quad are formed in the working precision and folded with one fp64 add each.
+          // Not unrolled further: the body is large and unrolling blows the register budget.
+          using TT = typename PolicyTerms<FAST>::T;
           PolicyElem<FAST> pe1;
 #pragma unroll 1
-          for (int j = 0; j < d; j += 2) {
-            const bool has1 = j + 1 < d;
-            policy_setup<SAMPLE, TD, FAST>(pe, a, theta, ts, pav[j], pai);
-            policy_setup<SAMPLE, TD, FAST>(pe1, a, theta, ts, pav[has1 ? j + 1 : j], pai);
-            float y0, y1;
-            gamma_pair(pe.gs, pe1.gs, has1, a.seed, (uint32_t)(i * d + j), step, traj, y0, y1);
-            if (y0 == 0.0f) y0 = ZERO_GAMMA_REPLACEMENT;
-            if (y1 == 0.0f) y1 = ZERO_GAMMA_REPLACEMENT;
-            Ssum += (double)y0;
-            trow[j] = y0;
-            policy_accumulate<SAMPLE, TD, FAST>(pe, a.htab, ts.th, y0, A, D_, gacc);
-            if (has1) {
-              Ssum += (double)y1;
-              trow[j + 1] = y1;
-              policy_accumulate<SAMPLE, TD, FAST>(pe1, a.htab, ts.th, y1, A, D_, gacc);
+          for (int j = 0; j < d; j += 4) {
+            QuadRand q;
+            quad_rand(q, a.seed, (uint32_t)(i * d + j), step, traj);
+            float ys = 0.0f;
+            TT as = 0, ds = 0, gs = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int j0 = j + 2 * h;
+              if (j0 < d) {
+                const bool has1 = j0 + 1 < d;
+                policy_setup<SAMPLE, TD, FAST>(pe, a, theta, ts, pav[j0], pai);
+                policy_setup<SAMPLE, TD, FAST>(pe1, a, theta, ts, pav[has1 ? j0 + 1 : j0], pai);
+                float y0, y1;
+                gamma_pair_q(pe.gs, pe1.gs, has1, q, h, a.seed, (uint32_t)(i * d + j0), (uint32_t)(i * d + j0 + 1), step,
+                             traj, y0, y1);
+                trow[j0] = y0;
+                ys += y0;
+                if (TD) {
+                  const PolicyTerms<FAST> t0 = policy_terms<SAMPLE, FAST>(pe, a.htab, ts.th, y0);
+                  as += t0.al;
+                  ds += t0.ad;
+                  gs += t0.gt;
+                }
+                if (has1) {
+                  trow[j0 + 1] = y1;
+                  ys += y1;
+                  if (TD) {
+                    const PolicyTerms<FAST> t1 = policy_terms<SAMPLE, FAST>(pe1, a.htab, ts.th, y1);
+                    as += t1.al;
+                    ds += t1.ad;
+                    gs += t1.gt;
+                  }
+                }
+              }
+            }
+            Ssum += (double)ys;
+            if (TD) {
+              A += (double)as;
+              D_ += (double)ds;
+              gacc += (double)gs;
             }
           }
         } else {

@@ -140,6 +140,89 @@ __device__ __forceinline__ void gamma_pair(const GammaState& g0, const GammaStat
 }
 
 // ---------------------------------------------------------------------------
+// Quad sampler (round 2): ONE Philox block serves FOUR matrix elements (two Box-Muller pairs), and the acceptance
+// test of an element is decided from 12 random bits in all but ~1e-3 of the cases -- without giving up exactness.
+//
+//  * Bits of the block r = (x, y, z, w):  pair h (h = 0, 1): radius uniform = top 24 bits of r.x / r.y, angle = 16 bits of
+//    r.z (high / low half); acceptance: 48 bits = r.w and the low bytes of r.x, r.y, cut into four 12-bit integers k.
+//    The true acceptance uniform of an element is u = (k + u') / 4096 with u' uniform in (0,1), drawn ONLY when the 12
+//    leading bits do not decide the test.
+//  * Squeeze for the shapes the policy actually has (hundreds ... tens of thousands):  with t = c x, d = 1/(9 c^2) the
+//    Marsaglia-Tsang exponent is  x^2/2 + d (ln v - (v - 1)) = 3 d [ln(1+t) - t + t^2/2 - t^3/3]
+//    = -3 d int_0^t s^3/(1+s) ds >= -(3/4) d t^4 / (1 - |t|) >= -1.5 d t^4 = -x^2 t^2 / 6  for |t| <= 1/2,
+//    so  u < 1 - x^2 (0.19 t^2 + 1e-6)  implies acceptance (0.19 > 1/6 and the 1e-6 absorb the rounding of c, x).  The
+//    bound is missed with probability ~0.06 / shape (MT's generic 1 - 0.0331 x^4 squeeze fails for every |x| > 2 and
+//    sent the whole wave through the log test on every draw).
+//  * Exact path (|t| > 1/2, squeeze undecided, or k in the top cell): u' from block 1 of the ELEMENT's own counter, the
+//    original MT test; on rejection fresh normals from blocks 2, 3, ... of that counter.  Shapes < 1: boost uniform
+//    from block 0xFFFF of the element's counter.
+// Counters: the quad block is (elem of the quad's first element, block 0); everything else is keyed by the element.
+// ---------------------------------------------------------------------------
+struct QuadRand {
+  float radu[2];   // radius uniforms in (0,1)
+  float ang[2];    // angles in revolutions, (0,1)
+  float kf[4];     // 12-bit acceptance integers as floats, 0 .. 4095
+};
+
+__device__ __forceinline__ void quad_rand(QuadRand& q, uint64_t seed, uint32_t elem0, uint32_t step, uint64_t traj) {
+  const u32x4 r = philox_elem(seed, elem0, step, traj, 0);
+  q.radu[0] = u01(r.x);
+  q.radu[1] = u01(r.y);
+  q.ang[0] = fmaf((float)(r.z >> 16), 1.52587890625e-5f, 7.62939453125e-6f);
+  q.ang[1] = fmaf((float)(r.z & 0xFFFFu), 1.52587890625e-5f, 7.62939453125e-6f);
+  q.kf[0] = (float)(r.w >> 20);
+  q.kf[1] = (float)((r.w >> 8) & 0xFFFu);
+  q.kf[2] = (float)(((r.w & 0xFFu) << 4) | (r.x & 0xFu));
+  q.kf[3] = (float)((((r.x >> 4) & 0xFu) << 8) | (r.y & 0xFFu));
+}
+
+// Exact continuation for one element: returns v = (1 + c x)^3 of the accepted draw.
+__device__ __forceinline__ float gamma_exact_path(const GammaState& g, float x, float kf, uint64_t seed, uint32_t elem,
+                                                  uint32_t step, uint64_t traj) {
+  float v = 1.0f;
+  {
+    const u32x4 r = philox_elem(seed, elem, step, traj, 1);
+    const float u = (kf + u01(r.x)) * 2.44140625e-4f;  // the element's full-precision acceptance uniform
+    if (mt_accept(g, x, u, v)) return v;
+  }
+  for (uint32_t block = 2; block < 64; ++block) {
+    const u32x4 r = philox_elem(seed, elem, step, traj, block);
+    const float xn = box_muller_radius(r.x) * __builtin_amdgcn_cosf(u01(r.y));
+    if (mt_accept(g, xn, u01(r.z), v)) return v;
+  }
+  return 1.0f;  // never reached in practice
+}
+
+// Gamma(shape) variate from the normal x and the 12 leading bits kf of its acceptance uniform.
+__device__ __forceinline__ float gamma_from_normal(const GammaState& g, float x, float kf, uint64_t seed, uint32_t elem,
+                                                   uint32_t step, uint64_t traj) {
+  const float t = g.c * x;
+  const float t2 = t * t;
+  const float x2 = x * x;
+  float v = 1.0f + t * (3.0f + t * (3.0f + t));
+  const float thr = fmaf(-x2, fmaf(t2, 0.19f, 1e-6f), 1.0f);
+  const bool sure = (t2 <= 0.25f) && (kf + 1.0f <= thr * 4096.0f);
+  if (!sure) v = gamma_exact_path(g, x, kf, seed, elem, step, traj);
+  float y = g.dd * v;
+  if (g.small) {
+    const u32x4 rb = philox_elem(seed, elem, step, traj, 0xFFFFu);
+    y *= __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01(rb.x)) * __builtin_amdgcn_rcpf(g.a));
+    if (y == 0.0f) y = ZERO_GAMMA_REPLACEMENT;  // underflow of the boost (mfg_ac2.py:244); y > 0 otherwise
+  }
+  return y;
+}
+
+// Two elements of one Box-Muller pair h of the quad (the second one only if has1).
+__device__ __forceinline__ void gamma_pair_q(const GammaState& g0, const GammaState& g1, bool has1, const QuadRand& q, int h,
+                                             uint64_t seed, uint32_t elem0, uint32_t elem1, uint32_t step, uint64_t traj,
+                                             float& y0, float& y1) {
+  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(q.radu[h]));
+  y0 = gamma_from_normal(g0, rad * __builtin_amdgcn_cosf(q.ang[h]), q.kf[2 * h], seed, elem0, step, traj);
+  y1 = 1.0f;
+  if (has1) y1 = gamma_from_normal(g1, rad * __builtin_amdgcn_sinf(q.ang[h]), q.kf[2 * h + 1], seed, elem1, step, traj);
+}
+
+// ---------------------------------------------------------------------------
 // fp64 special functions
 // ---------------------------------------------------------------------------
 // digamma for x > 0: recurrence to x >= 8 through one rational step, then the asymptotic series.
