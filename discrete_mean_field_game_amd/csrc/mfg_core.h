@@ -80,6 +80,18 @@ __device__ __forceinline__ void policy_setup(PolicyElem<FAST>& e, const CoreArgs
   }
 }
 
+// Mixed-precision sampling kernels: e^z = Ej * Fi (see exp_f64arg in mfg_device.h).
+template <bool SAMPLE, bool TD>
+__device__ __forceinline__ void policy_setup_sep(PolicyElem<true>& e, const CoreArgs& a, const ThetaSplit& ts, float pj, float Ej,
+                                                 float pi, float Fi) {
+  const float x = (pj - pi) - ts.sh;
+  float sg;
+  softplus_sigmoid_e(Ej * Fi, e.al_f, sg);
+  e.ad_f = x * sg;
+  if (TD) e.x_f = x;
+  if (SAMPLE) gamma_setup(e.gs, e.al_f * (float)a.alpha_scale);
+}
+
 // Fold one finished element into the row sums / score.  v = gamma variate (SAMPLE) or stored probability.
 template <bool SAMPLE, bool TD, bool FAST>
 __device__ __forceinline__ void policy_accumulate(const PolicyElem<FAST>& e, const float4* __restrict__ htab, float th,
@@ -168,16 +180,21 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
   const int Q = d * (d + 1) / 2, F = Q + d + 1;
   const bool want_v = TD && a.w != nullptr;
   double* wl = reinterpret_cast<double*>(smem_raw);
-  float* tile = reinterpret_cast<float*>(wl + (want_v ? F : 0));
+  double* pis64 = wl + (want_v ? F : 0);  // SAMPLE: the states as fp64 (column pass: transition + reward sums)
+  float* tile = reinterpret_cast<float*>(pis64 + (SAMPLE ? TB * d : 0));
   float* pis = tile + TB * d * dp;
   float* pin = pis + TB * d;
   float* pal = pin + TB * d;
+  float* pex = pal + TB * d;  // SAMPLE, mixed: E_j = e^{theta pi_j} (separable exponential, mfg_device.h)
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
   const int t = lane / d, i = lane - t * d;
   const int p2 = next_pow2(d);
   const double theta = *a.theta;
   const ThetaSplit ts = theta_split(theta, a.shift);
   const float inv_d = 1.0f / (float)d;
+  // mixed sampling kernels: separable e^z = E_j F_i (mfg_device.h).  The factors leave the fp32 range beyond
+  // |theta| (1 + |shift|) ~ 85 and the outputs then turn NaN -- loudly; precision 'f64' has no such limit.
+  constexpr bool sep = SAMPLE && FAST;
   if (want_v) {
     for (int k = tid; k < F; k += BLOCK) wl[k] = a.w[k];
   }
@@ -214,7 +231,15 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
     bool have_v = false;
     for (int s = 0; s < T; ++s) {
       tile_sync();
-      if (valid) pis[tlc * d + i] = pi_i;
+      float Fi = 0.0f;
+      if (valid) {
+        pis[tlc * d + i] = pi_i;
+        if (SAMPLE) pis64[tlc * d + i] = (double)pi_i;
+        if (sep) {
+          pex[tlc * d + i] = exp_f64arg(theta * (double)pi_i);
+          Fi = exp_f64arg(-theta * ((double)pi_i + a.shift));
+        }
+      }
       if (!SAMPLE) {
         // stage the given P tile (flat, coalesced) into the padded LDS tile
         const int n = nb * dd;
@@ -257,8 +282,15 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
               const int j0 = j + 2 * h;
               if (j0 < d) {
                 const bool has1 = j0 + 1 < d;
-                policy_setup<SAMPLE, TD, FAST>(pe, a, theta, ts, pav[j0], pai);
-                policy_setup<SAMPLE, TD, FAST>(pe1, a, theta, ts, pav[has1 ? j0 + 1 : j0], pai);
+                const int j1 = has1 ? j0 + 1 : j0;
+                if constexpr (FAST) {
+                  const float* ev = pex + tlc * d;
+                  policy_setup_sep<SAMPLE, TD>(pe, a, ts, pav[j0], ev[j0], pai, Fi);
+                  policy_setup_sep<SAMPLE, TD>(pe1, a, ts, pav[j1], ev[j1], pai, Fi);
+                } else {
+                  policy_setup<SAMPLE, TD, FAST>(pe, a, theta, ts, pav[j0], pai);
+                  policy_setup<SAMPLE, TD, FAST>(pe1, a, theta, ts, pav[j1], pai);
+                }
                 float y0, y1;
                 gamma_pair_q(pe.gs, pe1.gs, has1, q, h, a.seed, (uint32_t)(i * d + j0), (uint32_t)(i * d + j0 + 1), step,
                              traj, y0, y1);
@@ -299,24 +331,43 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
           }
         }
         if (SAMPLE) {
-          // normalise the row: P_ij = fl32(y_ij / S_i); the reward uses the stored fp32 P
-          const double invS = 1.0 / Ssum;
-          for (int j = 0; j < d; ++j) {
-            const float p32 = (float)((double)trow[j] * invS);
-            trow[j] = p32;
-            racc += reward_term(a.reward_kind, pid, (double)pv[j], (double)p32);
+          // normalise the row.  strict: P_ij = fl32(y_ij / S_i); mixed: P_ij = y_ij * fl32(1 / S_i) (one fp32 multiply per
+          // element, within 1.5 ulp of the strict value; rows still sum to 1 within a few 1e-7)
+          if (FAST) {
+            const float inv32 = (float)fast_rcp_f64(Ssum);
+            for (int j = 0; j < d; ++j) trow[j] *= inv32;
+            if (TD) gacc -= fast_log_f64(Ssum) * D_;
+          } else {
+            const double invS = 1.0 / Ssum;
+            for (int j = 0; j < d; ++j) trow[j] = (float)((double)trow[j] * invS);
+            if (TD) gacc -= log(Ssum) * D_;
           }
-          if (TD) gacc -= log(Ssum) * D_;
         }
-        if (TD) gacc = fma(digamma_pos(A), D_, gacc);
+        if (TD) gacc = fma(FAST ? digamma_pos_mixed(A) : digamma_pos(A), D_, gacc);
       }
       tile_sync();
       float pi_n;
+      double rcol = 0.0;
       if (SAMPLE) {
-        // pi'_i = sum_k pi_k P_ki : column read of the tile (consecutive lanes -> consecutive banks)
-        double acc = 0.0;
+        // column pass, lane = (trajectory, column i): pi'_i = sum_k pi_k P_ki and the reward sums of column i,
+        //   u = pi_k P_ki (exact in fp64),  pi'_i += u,  s1 += u P_ki,  s2 += u^2   =>   R = sum_i (pi_i s1_i - s2_i)
+        // -- the arithmetic of the given-P kernel k_step_small, so fused and unfused rewards agree bit for bit
+        // (consecutive lanes -> consecutive banks; pi_k as fp64 from LDS, one broadcast read per row).
+        double acc = 0.0, s1 = 0.0, s2 = 0.0;
         const float* tcol = tile + tlc * d * dp + i;
-        for (int k = 0; k < d; ++k) acc = fma((double)tcol[k * dp], (double)pv[k], acc);
+        const double* q64 = pis64 + tlc * d;
+#pragma unroll 3
+        for (int k = 0; k < d; ++k) {
+          const double p = (double)tcol[k * dp];
+          const double u = p * q64[k];
+          acc += u;
+          if (a.reward_kind != MFG_REWARD_EXTERNAL) {
+            s1 = fma(u, p, s1);
+            if (a.reward_kind == MFG_REWARD_MFG_AC2) s2 = fma(u, u, s2);
+          }
+        }
+        if (a.reward_kind == MFG_REWARD_MFG_AC2) rcol = fma(pid, s1, -s2);
+        if (a.reward_kind == MFG_REWARD_SYNTHETIC) rcol = s1;
         pi_n = (float)acc;
         if (valid) pin[tlc * d + i] = pi_n;
         if (a.P_out) {
@@ -342,12 +393,13 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
         }
       } else {
         pi_n = a.pi_next_in ? pin[tlc * d + i] : 0.0f;
+        rcol = pid * racc;
       }
       double r;
       if (a.reward_kind == MFG_REWARD_EXTERNAL) {
         r = a.reward_in ? (double)a.reward_in[b * T + s] : 0.0;
       } else {
-        r = seg_sum(pid * racc, i, d, p2);
+        r = seg_sum(rcol, i, d, p2);
         if (a.reward_kind == MFG_REWARD_SYNTHETIC) r *= -0.5;
       }
       if (valid && i == 0 && a.reward_out) a.reward_out[b * T + s] = (float)r;
@@ -380,11 +432,11 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
   }
 }
 
-inline size_t core_small_lds(int d, bool want_v) {
+inline size_t core_small_lds(int d, bool want_v, bool sample) {
   const int G = WAVE / d, TB = WAVES * G, dp = d | 1;
   const size_t F = (size_t)d * (d + 1) / 2 + d + 1;
-  const size_t fl = (size_t)TB * d * dp + 3 * (size_t)TB * d;  // floats: tile, pis, pin, pal
-  return (want_v ? F * 8 : 0) + fl * 4;
+  const size_t fl = (size_t)TB * d * dp + 4 * (size_t)TB * d;  // floats: tile, pis, pin, pal, pex
+  return (want_v ? F * 8 : 0) + (sample ? (size_t)TB * d * 8 : 0) + fl * 4;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -43,7 +43,7 @@ static void dispatch(const CoreArgs& a, bool sample, bool td, bool fast, int num
 int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st) {
   const int d = a.d;
   const bool want_v = td && a.w != nullptr;
-  const size_t lds = core_small_lds(d, want_v);
+  const size_t lds = core_small_lds(d, want_v, sample);
   if (d == 21) dispatch<21>(a, sample, td, fast, num_cus, lds, st);
   else if (d == 15) dispatch<15>(a, sample, td, fast, num_cus, lds, st);
   else dispatch<0>(a, sample, td, fast, num_cus, lds, st);

@@ -274,6 +274,76 @@ __device__ __forceinline__ void softplus_sigmoid_fast(float zh, float zl, float&
   sp = (e < 0.25f) ? ser : fast_ln(u);
 }
 
+// Round 2: the exponential is SEPARABLE, e^{theta (pi_j - pi_i - shift)} = E_j F_i with E_j = e^{theta pi_j},
+// F_i = e^{-theta (pi_i + shift)}: the lane that owns state entry i evaluates E_i, F_i once per env step (fp64 argument,
+// hardware exp2 on its fp32 head, first-order correction for the tail: ~1e-7 relative) and an element costs ONE multiply
+// instead of (hi/lo product, v_exp, correction).  Valid while |theta| (1 + |shift|) <= 80 (fp32 range); the kernels
+// keep the per-element form beyond that.
+__device__ __forceinline__ float exp_f64arg(double z) {
+  const double zl2 = z * 1.4426950408889634;
+  const float zh = (float)zl2;
+  const float zt = (float)(zl2 - (double)zh);
+  const float e = __builtin_amdgcn_exp2f(zh);
+  return fmaf(e, zt * 0.69314718055994531f, e);
+}
+
+// log1p(e) for 0 <= e <= 1/4: e * (degree-6 minimax polynomial of log1p(e)/e), 9.3e-8 relative in fp32 arithmetic
+// (replaces the atanh series and its reciprocal).
+__device__ __forceinline__ float log1p_small(float e) {
+  float p = fmaf(e, 0.0707516148686409f, -0.145447239279747f);
+  p = fmaf(e, p, 0.19665537774562836f);
+  p = fmaf(e, p, -0.24972063302993774f);
+  p = fmaf(e, p, 0.33332204818725586f);
+  p = fmaf(e, p, -0.4999998211860657f);
+  p = fmaf(e, p, 1.0f);
+  return e * p;
+}
+
+// alpha = log1p(e), sigmoid = e / (1 + e) from e = e^z.
+__device__ __forceinline__ void softplus_sigmoid_e(float e, float& sp, float& sg) {
+  const float u = 1.0f + e;
+  sg = e * __builtin_amdgcn_rcpf(u);
+  sp = (e < 0.25f) ? log1p_small(e) : fast_ln(u);
+}
+
+// fp64 helpers of the mixed-precision per-row epilogue (one call per matrix ROW per step, but IEEE fp64 division / log
+// expansions are ~30-45 instructions each at 4 cycles): reciprocal = v_rcp_f64 + two Newton steps; log = exponent * ln 2 +
+// hardware log2 of the fp32 head of the mantissa + first-order tail (absolute error ~4e-8, against rows sums of 1e3-1e5).
+__device__ __forceinline__ double fast_rcp_f64(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double fast_log_f64(double x) {
+  const double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  const int ex = __builtin_amdgcn_frexp_exp(x);
+  const float mh = (float)m;
+  const float ml = (float)(m - (double)mh);
+  const float lg2 = __builtin_amdgcn_logf(mh);
+  return fma((double)ex + (double)lg2, 0.6931471805599453, (double)(ml * __builtin_amdgcn_rcpf(mh)));
+}
+// digamma for x > 0, mixed precision: same recurrence / series as digamma_pos, with the fast reciprocal and log
+// (series cut after 1/(240 x^8): < 3e-10 for x >= 8).
+__device__ __forceinline__ double digamma_pos_mixed(double x) {
+  double corr = 0.0;
+  if (x < 8.0) {
+    double q = x, qp = 1.0;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const double xk = x + (double)k;
+      qp = fma(qp, xk, q);
+      q = q * xk;
+    }
+    corr = qp * fast_rcp_f64(q);
+    x += 8.0;
+  }
+  const double inv = fast_rcp_f64(x);
+  const double inv2 = inv * inv;
+  const double s = inv2 * (1.0 / 12.0 - inv2 * (1.0 / 120.0 - inv2 * (1.0 / 252.0 - inv2 * (1.0 / 240.0))));
+  return fast_log_f64(x) - 0.5 * inv - s - corr;
+}
+
 // Split-constant helper: z = theta * (pj - pi - shift) evaluated in fp32 with the rounding of the
 // product and of the constants carried in zl.
 struct ThetaSplit {
