@@ -56,7 +56,8 @@ template <bool FAST>
 struct PolicyElem {
   double al_d, ad_d;  // strict mode
   float al_f, ad_f;   // mixed mode
-  float x_f;          // mixed mode: x = pi_j - pi_i - shift (z = theta x is recomputed where needed)
+  float psi_ad;       // mixed mode, TD: psi(alpha) alpha' = x h(theta x), looked up AT SETUP so that the table load's
+                      // latency hides behind the sampling arithmetic instead of stalling the score update
   GammaState gs;
 };
 
@@ -69,7 +70,7 @@ __device__ __forceinline__ void policy_setup(PolicyElem<FAST>& e, const CoreArgs
     theta_times_x(ts, pj, pi, x, zh, zl);
     softplus_sigmoid_fast(zh, zl, e.al_f, sg);
     e.ad_f = x * sg;
-    if (TD) e.x_f = x;
+    if (TD) e.psi_ad = x * htab_eval(a.htab, ts.th * x);  // fp32 product is ample for a table lookup (|dh/dz| < 1)
     if (SAMPLE) gamma_setup(e.gs, e.al_f * (float)a.alpha_scale);
   } else {
     const double x = (double)pj - (double)pi - a.shift;
@@ -88,7 +89,7 @@ __device__ __forceinline__ void policy_setup_sep(PolicyElem<true>& e, const Core
   float sg;
   softplus_sigmoid_e(Ej * Fi, e.al_f, sg);
   e.ad_f = x * sg;
-  if (TD) e.x_f = x;
+  if (TD) e.psi_ad = x * htab_eval(a.htab, ts.th * x);
   if (SAMPLE) gamma_setup(e.gs, e.al_f * (float)a.alpha_scale);
 }
 
@@ -101,11 +102,7 @@ __device__ __forceinline__ void policy_accumulate(const PolicyElem<FAST>& e, con
     const float lnv = (!SAMPLE && v == 0.0f) ? (float)LOG_ZERO_P : fast_ln(v);
     A += (double)e.al_f;
     D += (double)e.ad_f;
-    // -psi(alpha) alpha' = -x h(z); beyond the table (z > 24, i.e. theta > ~28) fall back to the direct form
-    const float z = th * e.x_f;  // fp32 product is ample for a table lookup (|dh/dz| < 1)
-    float psi_ad = e.x_f * htab_eval(htab, z);
-    if (z >= HTAB_ZMAX) psi_ad = digamma_pos_fast(e.al_f) * e.ad_f;
-    gacc += (double)fmaf(lnv, e.ad_f, -psi_ad);
+    gacc += (double)fmaf(lnv, e.ad_f, -e.psi_ad);
   } else {
     const double lnv = (!SAMPLE && v == 0.0f) ? LOG_ZERO_P : log((double)v);
     A += e.al_d;
@@ -127,13 +124,14 @@ __device__ __forceinline__ PolicyTerms<FAST> policy_terms(const PolicyElem<FAST>
                                                           float v) {
   PolicyTerms<FAST> o;
   if constexpr (FAST) {
+#ifdef MFG_ABL_LNY
+    const float lnv = v;
+#else
     const float lnv = (!SAMPLE && v == 0.0f) ? (float)LOG_ZERO_P : fast_ln(v);
-    const float z = th * e.x_f;
-    float psi_ad = e.x_f * htab_eval(htab, z);
-    if (z >= HTAB_ZMAX) psi_ad = digamma_pos_fast(e.al_f) * e.ad_f;
+#endif
     o.al = e.al_f;
     o.ad = e.ad_f;
-    o.gt = fmaf(lnv, e.ad_f, -psi_ad);
+    o.gt = fmaf(lnv, e.ad_f, -e.psi_ad);
   } else {
     const double lnv = (!SAMPLE && v == 0.0f) ? LOG_ZERO_P : log((double)v);
     o.al = e.al_d;
@@ -141,6 +139,77 @@ __device__ __forceinline__ PolicyTerms<FAST> policy_terms(const PolicyElem<FAST>
     o.gt = (-digamma_pos(e.al_d) + lnv) * e.ad_d;
   }
   return o;
+}
+
+// NE (1..4) matrix elements of one row from ONE Philox block, written so that the NE dependency chains sit in one
+// basic block and interleave (measured on gfx950: a single dependent chain issues one VALU instruction per ~5 cycles
+// per SIMD at any occupancy, two or more independent chains per wave one per ~2): no branch on the hot path -- the
+// rare exact-acceptance / small-shape continuations of all NE elements hide behind one wave-uniform test.
+//   pj[e], ej[e]: state entry and E_j of the element's column (ej unused unless SEP); elem0 = id of the first element,
+//   estride = distance between consecutive element ids (1: neighbouring columns of the small-d tile; 64: a lane's
+//   columns in the wave-per-trajectory kernels).  y[e] receive the gamma variates; the row sums of the NE elements are
+//   ADDED to ys / as / ds / gs in the working precision.
+template <int NE, bool TD, bool FAST, bool SEP>
+__device__ __forceinline__ void sample_elems(const CoreArgs& a, double theta, const ThetaSplit& ts, const float* pj,
+                                             const float* ej, float pai, float Fi, uint32_t elem0, uint32_t estride,
+                                             uint32_t step, uint64_t traj, float* y, float& ys,
+                                             typename PolicyTerms<FAST>::T& as, typename PolicyTerms<FAST>::T& ds,
+                                             typename PolicyTerms<FAST>::T& gs) {
+  QuadRand q;
+  quad_rand(q, a.seed, elem0, step, traj);
+  // the two Box-Muller pairs one after the other (two interleaved chains each; four at once cost 36 spilled VGPRs at
+  // the 128-register cap and bought nothing at full occupancy)
+#pragma unroll
+  for (int h = 0; 2 * h < NE; ++h) {
+    const int n2 = (NE - 2 * h) >= 2 ? 2 : 1;
+    PolicyElem<FAST> pe[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u < n2) {
+        const int e = 2 * h + u;
+        if constexpr (SEP) policy_setup_sep<true, TD>(pe[u], a, ts, pj[e], ej[e], pai, Fi);
+        else policy_setup<true, TD, FAST>(pe[u], a, theta, ts, pj[e], pai);
+      }
+    }
+    float xn[2], v[2];
+    bool sure[2] = {true, true};
+#ifdef MFG_ABL_BM
+    xn[0] = (q.radu[h] - 0.5f) * 2.0f;
+    xn[1] = (q.radu[h] - 0.5f) * q.ang[h];
+#else
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(q.radu[h]));
+    xn[0] = rad * __builtin_amdgcn_cosf(q.ang[h]);
+    xn[1] = rad * __builtin_amdgcn_sinf(q.ang[h]);
+#endif
+    bool cold = false;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u < n2) {
+        v[u] = gamma_try(pe[u].gs, xn[u], q.kf[2 * h + u], sure[u]);
+        y[2 * h + u] = pe[u].gs.dd * v[u];
+        cold = cold || !sure[u] || pe[u].gs.small;
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(cold) != 0) {  // wave-uniform, ~1 % of the pairs at the reference policies
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (u < n2 && (!sure[u] || pe[u].gs.small))
+          y[2 * h + u] = gamma_fix(pe[u].gs, xn[u], q.kf[2 * h + u], sure[u], v[u], a.seed,
+                                   elem0 + (uint32_t)(2 * h + u) * estride, step, traj);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u < n2) {
+        ys += y[2 * h + u];
+        if (TD) {
+          const PolicyTerms<FAST> t = policy_terms<true, FAST>(pe[u], a.htab, ts.th, y[2 * h + u]);
+          as += t.al;
+          ds += t.ad;
+          gs += t.gt;
+        }
+      }
+    }
+  }
 }
 
 // V(pi) = phi(pi).w, one wavefront per trajectory, lanes own columns c, rows i <= c.  For fixed i the
@@ -179,16 +248,25 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
   const int G = WAVE / d, TB = WAVES * G;
   const int Q = d * (d + 1) / 2, F = Q + d + 1;
   const bool want_v = TD && a.w != nullptr;
+  // Value function: V = sum_{i<=k} U_ik pi_i pi_k + b.pi + c.  Lane (t, i) owns the terms of "its" entry i:
+  //   generic: column i of the upper triangle, k <= i  -- 1 .. d terms per lane, the wave waits for the longest;
+  //   CIRC (compile-time odd d, the reference's 21 and 15): the unordered pairs {i, i+m mod d}, m = 0 .. (d-1)/2 --
+  //   every pair exactly once, (d+1)/2 terms on EVERY lane, fixed trip count (unrolled, all LDS reads in flight).
+  //   Its weights sit in LDS as wc[m][i] = w[k(min, max)], the state as a doubled vector pn2[0 .. 2d) so that
+  //   pn2[i + m] needs no modulo.  (The triangular loop cost 12 % of the d = 21 training rollout.)
+  constexpr bool CIRC = SAMPLE && D > 0 && (D & 1);
+  constexpr int H = (D + 1) / 2;
+  const int pnw = CIRC ? 2 * d : d;  // floats per trajectory in pin
   double* wl = reinterpret_cast<double*>(smem_raw);
   double* pis64 = wl + (want_v ? F : 0);  // SAMPLE: the states as fp64 (column pass: transition + reward sums)
-  float* tile = reinterpret_cast<float*>(pis64 + (SAMPLE ? TB * d : 0));
+  double* red = pis64 + (SAMPLE ? TB * d : 0);  // [TB][3][d]: per-lane terms of reward / score / value, summed by lane 0 / 1
+  float* tile = reinterpret_cast<float*>(red + 3 * TB * d);
   float* pis = tile + TB * d * dp;
-  float* pin = pis + TB * d;
-  float* pal = pin + TB * d;
-  float* pex = pal + TB * d;  // SAMPLE, mixed: E_j = e^{theta pi_j} (separable exponential, mfg_device.h)
+  float* pin = pis + TB * d;       // [TB][pnw]
+  float* pal = pin + TB * 2 * d;
+  float* pex = pal + TB * d;       // SAMPLE, mixed: E_j = e^{theta pi_j} (separable exponential, mfg_device.h)
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
   const int t = lane / d, i = lane - t * d;
-  const int p2 = next_pow2(d);
   const double theta = *a.theta;
   const ThetaSplit ts = theta_split(theta, a.shift);
   const float inv_d = 1.0f / (float)d;
@@ -196,7 +274,17 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
   // |theta| (1 + |shift|) ~ 85 and the outputs then turn NaN -- loudly; precision 'f64' has no such limit.
   constexpr bool sep = SAMPLE && FAST;
   if (want_v) {
-    for (int k = tid; k < F; k += BLOCK) wl[k] = a.w[k];
+    if (CIRC) {
+      for (int k = tid; k < H * d; k += BLOCK) {
+        const int m = k / d, ii = k - m * d;
+        int kk = ii + m;
+        if (kk >= d) kk -= d;
+        wl[k] = a.w[feat_idx(ii < kk ? ii : kk, ii < kk ? kk : ii, d)];
+      }
+      for (int k = Q + tid; k < F; k += BLOCK) wl[k] = a.w[k];
+    } else {
+      for (int k = tid; k < F; k += BLOCK) wl[k] = a.w[k];
+    }
   }
   // wl is staged block-wide but read by every wave; the per-step barriers below may be wave-local, so order the
   // staging against all later reads once, here (one block barrier per launch)
@@ -217,6 +305,23 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
       __syncthreads();
     }
   };
+  // value term of this lane for the state in `vec` (CIRC: doubled vector) whose entry i is pi_e
+  auto value_term = [&](const float* vec, float pi_e) -> double {
+    double col = 0.0;
+    if (CIRC) {
+      double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+      for (int m = 0; m + 1 < H; m += 2) {
+        c0 = fma(wl[m * d + i], (double)vec[i + m], c0);
+        c1 = fma(wl[(m + 1) * d + i], (double)vec[i + m + 1], c1);
+      }
+      if (H & 1) c0 = fma(wl[(H - 1) * d + i], (double)vec[i + H - 1], c0);
+      col = c0 + c1;
+    } else {
+      for (int k = 0, idx = i; k <= i; idx += d - k - 1, ++k) col = fma(wl[idx], (double)vec[k], col);
+    }
+    return (double)pi_e * (col + wl[Q + i]);
+  };
   const int64_t ntiles = (a.B + TB - 1) / TB;
   for (int64_t tileid = blockIdx.x; tileid < ntiles; tileid += gridDim.x) {
     const int64_t b0 = tileid * TB;
@@ -225,10 +330,33 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
     const bool valid = (t < G) && (tl < nb);
     const int tlc = valid ? tl : 0;
     const int64_t b = b0 + tlc;
+    double* redq = red + (size_t)tlc * 3 * d;
+    float* pnv = pin + tlc * pnw;
     float pi_i = a.pi0[b * d + i];
     if (valid && a.pi_traj) a.pi_traj[b * (int64_t)(T + 1) * d + i] = pi_i;
-    double v_cur = 0.0, discount = 1.0;
-    bool have_v = false;
+    double v_cur = 0.0, discount = 1.0;  // meaningful on lane i == 0 only
+    if (want_v && SAMPLE) {
+      // V of the start state (GIVEN mode evaluates it inside its single step, below)
+      tile_sync();
+      if (valid) {
+        pnv[i] = pi_i;
+        if (CIRC) pnv[d + i] = pi_i;
+      }
+      tile_sync();
+      if (valid) redq[2 * d + i] = value_term(pnv, pi_i);
+      tile_sync();
+      if (i == 0) {
+        double v0 = 0.0, v1 = 0.0;
+        int k = 0;
+#pragma unroll 2
+        for (; k + 1 < d; k += 2) {
+          v0 += redq[2 * d + k];
+          v1 += redq[2 * d + k + 1];
+        }
+        if (k < d) v0 += redq[2 * d + k];
+        v_cur = (v0 + v1) + wl[Q + d];
+      }
+    }
     for (int s = 0; s < T; ++s) {
       tile_sync();
       float Fi = 0.0f;
@@ -264,56 +392,42 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
       if (valid) {
         const uint32_t step = a.first_step + (uint32_t)s;
         const uint64_t traj = a.traj_offset + (uint64_t)b;
-        PolicyElem<FAST> pe;
         if (SAMPLE) {
-          // FOUR matrix elements per iteration: one Philox block (quad_rand) feeds two Box-Muller pairs; the row sums
-          // of the quad are formed in the working precision and folded with one fp64 add each.
-          // Not unrolled further: the body is large and unrolling blows the register budget.
+          // FOUR matrix elements per iteration from one Philox block, their chains interleaved (sample_elems); the row
+          // sums of the quad are formed in the working precision and folded with one fp64 add each.
           using TT = typename PolicyTerms<FAST>::T;
-          PolicyElem<FAST> pe1;
+          const float* ev = pex + tlc * d;
+          const uint32_t erow = (uint32_t)(i * d);
+          const int dq = d & ~3;
 #pragma unroll 1
-          for (int j = 0; j < d; j += 4) {
-            QuadRand q;
-            quad_rand(q, a.seed, (uint32_t)(i * d + j), step, traj);
-            float ys = 0.0f;
+          for (int j = 0; j < dq; j += 4) {
+            float y[4], ys = 0.0f;
             TT as = 0, ds = 0, gs = 0;
+            sample_elems<4, TD, FAST, sep>(a, theta, ts, pav + j, ev + j, pai, Fi, erow + (uint32_t)j, 1u, step, traj, y, ys,
+                                           as, ds, gs);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const int j0 = j + 2 * h;
-              if (j0 < d) {
-                const bool has1 = j0 + 1 < d;
-                const int j1 = has1 ? j0 + 1 : j0;
-                if constexpr (FAST) {
-                  const float* ev = pex + tlc * d;
-                  policy_setup_sep<SAMPLE, TD>(pe, a, ts, pav[j0], ev[j0], pai, Fi);
-                  policy_setup_sep<SAMPLE, TD>(pe1, a, ts, pav[j1], ev[j1], pai, Fi);
-                } else {
-                  policy_setup<SAMPLE, TD, FAST>(pe, a, theta, ts, pav[j0], pai);
-                  policy_setup<SAMPLE, TD, FAST>(pe1, a, theta, ts, pav[j1], pai);
-                }
-                float y0, y1;
-                gamma_pair_q(pe.gs, pe1.gs, has1, q, h, a.seed, (uint32_t)(i * d + j0), (uint32_t)(i * d + j0 + 1), step,
-                             traj, y0, y1);
-                trow[j0] = y0;
-                ys += y0;
-                if (TD) {
-                  const PolicyTerms<FAST> t0 = policy_terms<SAMPLE, FAST>(pe, a.htab, ts.th, y0);
-                  as += t0.al;
-                  ds += t0.ad;
-                  gs += t0.gt;
-                }
-                if (has1) {
-                  trow[j0 + 1] = y1;
-                  ys += y1;
-                  if (TD) {
-                    const PolicyTerms<FAST> t1 = policy_terms<SAMPLE, FAST>(pe1, a.htab, ts.th, y1);
-                    as += t1.al;
-                    ds += t1.ad;
-                    gs += t1.gt;
-                  }
-                }
-              }
+            for (int e = 0; e < 4; ++e) trow[j + e] = y[e];
+            Ssum += (double)ys;
+            if (TD) {
+              A += (double)as;
+              D_ += (double)ds;
+              gacc += (double)gs;
             }
+          }
+          if (dq < d) {  // 1..3 trailing elements of the row (their own Philox block, keyed by the first of them)
+            float y[4], ys = 0.0f;
+            TT as = 0, ds = 0, gs = 0;
+            const int rem = d - dq;
+            if (rem == 1)
+              sample_elems<1, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pai, Fi, erow + (uint32_t)dq, 1u, step, traj, y,
+                                             ys, as, ds, gs);
+            else if (rem == 2)
+              sample_elems<2, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pai, Fi, erow + (uint32_t)dq, 1u, step, traj, y,
+                                             ys, as, ds, gs);
+            else
+              sample_elems<3, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pai, Fi, erow + (uint32_t)dq, 1u, step, traj, y,
+                                             ys, as, ds, gs);
+            for (int e = 0; e < rem; ++e) trow[dq + e] = y[e];
             Ssum += (double)ys;
             if (TD) {
               A += (double)as;
@@ -322,6 +436,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
             }
           }
         } else {
+          PolicyElem<FAST> pe;
 #pragma unroll 2
           for (int j = 0; j < d; ++j) {
             policy_setup<SAMPLE, TD, FAST>(pe, a, theta, ts, pav[j], pai);
@@ -336,14 +451,18 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
           if (FAST) {
             const float inv32 = (float)fast_rcp_f64(Ssum);
             for (int j = 0; j < d; ++j) trow[j] *= inv32;
+#ifndef MFG_ABL_EPI
             if (TD) gacc -= fast_log_f64(Ssum) * D_;
+#endif
           } else {
             const double invS = 1.0 / Ssum;
             for (int j = 0; j < d; ++j) trow[j] = (float)((double)trow[j] * invS);
             if (TD) gacc -= log(Ssum) * D_;
           }
         }
+#ifndef MFG_ABL_EPI
         if (TD) gacc = fma(FAST ? digamma_pos_mixed(A) : digamma_pos(A), D_, gacc);
+#endif
       }
       tile_sync();
       float pi_n;
@@ -361,7 +480,11 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
           const double p = (double)tcol[k * dp];
           const double u = p * q64[k];
           acc += u;
+#ifdef MFG_ABL_COLREW
+          if (false) {
+#else
           if (a.reward_kind != MFG_REWARD_EXTERNAL) {
+#endif
             s1 = fma(u, p, s1);
             if (a.reward_kind == MFG_REWARD_MFG_AC2) s2 = fma(u, u, s2);
           }
@@ -369,7 +492,10 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
         if (a.reward_kind == MFG_REWARD_MFG_AC2) rcol = fma(pid, s1, -s2);
         if (a.reward_kind == MFG_REWARD_SYNTHETIC) rcol = s1;
         pi_n = (float)acc;
-        if (valid) pin[tlc * d + i] = pi_n;
+        if (valid) {
+          pnv[i] = pi_n;
+          if (CIRC) pnv[d + i] = pi_n;
+        }
         if (a.P_out) {
           // coalesced copy-out of the block's P tile into [B,T,d,d]
           const int n = nb * dd;
@@ -392,38 +518,80 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
           }
         }
       } else {
-        pi_n = a.pi_next_in ? pin[tlc * d + i] : 0.0f;
+        pi_n = a.pi_next_in ? pnv[i] : 0.0f;
         rcol = pid * racc;
       }
-      double r;
-      if (a.reward_kind == MFG_REWARD_EXTERNAL) {
-        r = a.reward_in ? (double)a.reward_in[b * T + s] : 0.0;
-      } else {
-        r = seg_sum(rcol, i, d, p2);
-        if (a.reward_kind == MFG_REWARD_SYNTHETIC) r *= -0.5;
+      // Per-trajectory sums of the lane terms (reward, score, value): every lane parks its terms in an LDS line, lane 0
+      // of the trajectory adds up reward and value, lane 1 the score -- two LDS round trips per step instead of the six
+      // dependent cross-lane exchanges (ds_bpermute) of a shuffle tree per quantity, in a fixed order.
+      const bool ext = a.reward_kind == MFG_REWARD_EXTERNAL;
+      if (valid) {
+        if (!ext) redq[i] = rcol;
+        if (TD) redq[d + i] = gacc;
       }
-      if (valid && i == 0 && a.reward_out) a.reward_out[b * T + s] = (float)r;
-      if (TD) {
-        const double gsum = seg_sum(gacc, i, d, p2);
-        if (valid && i == 0 && a.g) a.g[b * T + s] = gsum;
-        if (want_v) {
-          tile_sync();  // pin complete
-          if (!have_v) {
-            double col = 0.0;
-            for (int k = 0, idx = i; k <= i; idx += d - k - 1, ++k) col = fma(wl[idx], (double)pv[k], col);
-            v_cur = seg_sum(pid * (col + wl[Q + i]), i, d, p2) + wl[Q + d];
-            have_v = true;
+#ifdef MFG_ABL_V
+      if (false) {
+#else
+      if (want_v) {
+#endif
+        tile_sync();  // pin complete
+        if (!SAMPLE && valid) {
+          // GIVEN mode: single step, V(pi) of the current state first
+          redq[2 * d + i] = value_term(pv, pi_i);
+          tile_sync();
+          if (i == 0) {
+            double v0 = 0.0;
+            for (int k = 0; k < d; ++k) v0 += redq[2 * d + k];
+            v_cur = v0 + wl[Q + d];
           }
-          const float* pn = pin + tlc * d;
-          double col = 0.0;
-          for (int k = 0, idx = i; k <= i; idx += d - k - 1, ++k) col = fma(wl[idx], (double)pn[k], col);
-          const double v_next = seg_sum((double)pi_n * (col + wl[Q + i]), i, d, p2) + wl[Q + d];
+          tile_sync();
+        }
+        if (valid) redq[2 * d + i] = value_term(pnv, pi_n);
+      }
+      tile_sync();
+      const int gl = d > 1 ? 1 : 0;  // lane of the trajectory that sums the score
+      if (valid && i == 0) {
+        double r0 = 0.0, r1 = 0.0, v0 = 0.0, v1 = 0.0;
+        if (ext) {
+          r0 = a.reward_in ? (double)a.reward_in[b * T + s] : 0.0;
+        } else {
+          int k = 0;
+#pragma unroll 4
+          for (; k + 1 < d; k += 2) {
+            r0 += redq[k];
+            r1 += redq[k + 1];
+          }
+          if (k < d) r0 += redq[k];
+        }
+        double r = r0 + r1;
+        if (a.reward_kind == MFG_REWARD_SYNTHETIC) r *= -0.5;
+        if (a.reward_out) a.reward_out[b * T + s] = (float)r;
+        if (want_v) {
+          int k = 0;
+#pragma unroll 4
+          for (; k + 1 < d; k += 2) {
+            v0 += redq[2 * d + k];
+            v1 += redq[2 * d + k + 1];
+          }
+          if (k < d) v0 += redq[2 * d + k];
+          const double v_next = (v0 + v1) + wl[Q + d];
           const double gd = a.discount_pow ? discount : a.gamma;
           const double del = r + gd * v_next - v_cur;
-          if (valid && i == 0 && a.delta) a.delta[b * T + s] = del;
+          if (a.delta) a.delta[b * T + s] = del;
           v_cur = v_next;
           discount *= a.gamma;
         }
+      }
+      if (TD && valid && i == gl && a.g) {
+        double g0 = 0.0, g1 = 0.0;
+        int k = 0;
+#pragma unroll 4
+        for (; k + 1 < d; k += 2) {
+          g0 += redq[d + k];
+          g1 += redq[d + k + 1];
+        }
+        if (k < d) g0 += redq[d + k];
+        a.g[b * T + s] = g0 + g1;
       }
       if (valid && a.pi_traj) a.pi_traj[(b * (int64_t)(T + 1) + s + 1) * d + i] = pi_n;
       pi_i = pi_n;
@@ -435,8 +603,8 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
 inline size_t core_small_lds(int d, bool want_v, bool sample) {
   const int G = WAVE / d, TB = WAVES * G, dp = d | 1;
   const size_t F = (size_t)d * (d + 1) / 2 + d + 1;
-  const size_t fl = (size_t)TB * d * dp + 4 * (size_t)TB * d;  // floats: tile, pis, pin, pal, pex
-  return (want_v ? F * 8 : 0) + (sample ? (size_t)TB * d * 8 : 0) + fl * 4;
+  const size_t fl = (size_t)TB * d * dp + 5 * (size_t)TB * d;  // floats: tile, pis, pin (doubled), pal, pex
+  return (want_v ? F * 8 : 0) + (sample ? (size_t)TB * d * 8 : 0) + (size_t)3 * TB * d * 8 + fl * 4;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -165,7 +165,15 @@ struct QuadRand {
 };
 
 __device__ __forceinline__ void quad_rand(QuadRand& q, uint64_t seed, uint32_t elem0, uint32_t step, uint64_t traj) {
+#ifdef MFG_ABL_PHILOX  // timing ablation only (tools/ablate.sh): a two-multiply hash instead of the Philox block
+  u32x4 r;
+  r.x = (elem0 + step) * 2654435761u ^ (uint32_t)traj;
+  r.y = r.x * 2246822519u + 12345u;
+  r.z = r.y ^ (r.x >> 7);
+  r.w = r.z * 3266489917u;
+#else
   const u32x4 r = philox_elem(seed, elem0, step, traj, 0);
+#endif
   q.radu[0] = u01(r.x);
   q.radu[1] = u01(r.y);
   q.ang[0] = fmaf((float)(r.z >> 16), 1.52587890625e-5f, 7.62939453125e-6f);
@@ -208,6 +216,34 @@ __device__ __forceinline__ float gamma_from_normal(const GammaState& g, float x,
     const u32x4 rb = philox_elem(seed, elem, step, traj, 0xFFFFu);
     y *= __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01(rb.x)) * __builtin_amdgcn_rcpf(g.a));
     if (y == 0.0f) y = ZERO_GAMMA_REPLACEMENT;  // underflow of the boost (mfg_ac2.py:244); y > 0 otherwise
+  }
+  return y;
+}
+
+// Branch-free half of gamma_from_normal for the interleaved quad loops: v = (1 + c x)^3 and whether the 12 leading
+// acceptance bits already decide the draw.
+__device__ __forceinline__ float gamma_try(const GammaState& g, float x, float kf, bool& sure) {
+#ifdef MFG_ABL_TRY
+  sure = true;
+  return 1.0f + 3.0f * g.c * x;
+#endif
+  const float t = g.c * x;
+  const float t2 = t * t;
+  const float x2 = x * x;
+  // (kf + 1) / 4096 <= 1 - x^2 (0.19 t^2 + 1e-6)   <=>   kf <= 4095 - x^2 (778.24 t^2 + 4.096e-3)
+  const float thr = fmaf(-x2, fmaf(t2, 778.24f, 4.096e-3f), 4095.0f);
+  sure = (t2 <= 0.25f) && (kf <= thr);
+  return 1.0f + t * (3.0f + t * (3.0f + t));
+}
+// Cold half: exact continuation and the shape < 1 boost; returns the variate.
+__device__ __forceinline__ float gamma_fix(const GammaState& g, float x, float kf, bool sure, float v, uint64_t seed,
+                                           uint32_t elem, uint32_t step, uint64_t traj) {
+  if (!sure) v = gamma_exact_path(g, x, kf, seed, elem, step, traj);
+  float y = g.dd * v;
+  if (g.small) {
+    const u32x4 rb = philox_elem(seed, elem, step, traj, 0xFFFFu);
+    y *= __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01(rb.x)) * __builtin_amdgcn_rcpf(g.a));
+    if (y == 0.0f) y = ZERO_GAMMA_REPLACEMENT;
   }
   return y;
 }
@@ -301,9 +337,17 @@ __device__ __forceinline__ float log1p_small(float e) {
 
 // alpha = log1p(e), sigmoid = e / (1 + e) from e = e^z.
 __device__ __forceinline__ void softplus_sigmoid_e(float e, float& sp, float& sg) {
+#ifdef MFG_ABL_SETUP
+  sg = e * 0.5f;
+  sp = e + 0.3f;
+  return;
+#endif
   const float u = 1.0f + e;
   sg = e * __builtin_amdgcn_rcpf(u);
-  sp = (e < 0.25f) ? log1p_small(e) : fast_ln(u);
+  float lp = log1p_small(e), ln = fast_ln(u);
+  asm("" : "+v"(lp), "+v"(ln));  // both sides evaluated: the select is a v_cndmask, not an exec-masked if/else that would
+                                 // cut the basic block (the sampling loop interleaves four elements' chains)
+  sp = (e < 0.25f) ? lp : ln;
 }
 
 // fp64 helpers of the mixed-precision per-row epilogue (one call per matrix ROW per step, but IEEE fp64 division / log
@@ -387,19 +431,24 @@ __device__ __forceinline__ float digamma_pos_fast(float x) {
 // z = theta x, and h is a smooth bounded function of ONE variable (h -> -1 for z -> -inf, ~ln z for z -> inf).
 // Mixed precision evaluates it from a table of per-interval cubics (fitted in fp64 by k_init_htab through
 // 4 equispaced points of each interval, |error| < 1e-8 + fp32 rounding) instead of a 40-instruction
-// digamma per matrix element: index + one 16-byte load + 3 FMAs.  The table lives in global memory (12 KB,
-// L1/L2 resident): the kernels are VALU-issue bound, the load rides on the otherwise idle memory pipe.
+// digamma per matrix element: index + one 16-byte load + 3 FMAs.  The table lives in global memory (28 KB, of
+// which a policy touches a few KB; L1/L2 resident): the kernels are VALU-issue bound, the load rides on the
+// otherwise idle memory pipe.  It spans the whole fp32 range of e^z, so there is no out-of-table branch.
 // ---------------------------------------------------------------------------
-constexpr float HTAB_ZMAX = 24.0f;
+constexpr float HTAB_ZMIN = -24.0f;                        // h(z) = -1 + O(e^z) below
+constexpr float HTAB_ZMAX = 88.0f;                         // fp32 range of e^z (the mixed mode's own limit)
 constexpr int HTAB_PER_UNIT = 16;                          // intervals per unit of z
-constexpr int HTAB_N = 2 * 24 * HTAB_PER_UNIT;             // 768 intervals over [-24, 24)
+constexpr int HTAB_N = (88 + 24) * HTAB_PER_UNIT;          // 1 792 intervals over [-24, 88)
 
 __device__ __forceinline__ float htab_eval(const float4* __restrict__ tab, float z) {
-  const float t = (z + HTAB_ZMAX) * (float)HTAB_PER_UNIT;
-  const float tc = fminf(fmaxf(t, 0.0f), (float)HTAB_N - 0.001f);
-  const float kf = floorf(tc);
-  const float f = tc - kf;
-  const float4 c = tab[(int)kf];
+#ifdef MFG_ABL_HTAB
+  return z * 0.1f;
+#endif
+  float t = fmaf(z, (float)HTAB_PER_UNIT, -HTAB_ZMIN * (float)HTAB_PER_UNIT);
+  t = __builtin_amdgcn_fmed3f(t, 0.0f, (float)HTAB_N - 0.001f);  // clamp: one instruction
+  const unsigned k = (unsigned)t;                                 // truncation == floor (t >= 0)
+  const float f = __builtin_amdgcn_fractf(t);
+  const float4 c = tab[k];
   return fmaf(fmaf(fmaf(c.w, f, c.z), f, c.y), f, c.x);
 }
 

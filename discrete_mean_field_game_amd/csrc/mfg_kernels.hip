@@ -1214,7 +1214,7 @@ __global__ void k_init_htab(float4* __restrict__ tab) {
   if (k >= HTAB_N) return;
   double y[4];
   for (int q = 0; q < 4; ++q) {
-    const double z = -(double)HTAB_ZMAX + ((double)k + (double)q / 3.0) / (double)HTAB_PER_UNIT;
+    const double z = (double)HTAB_ZMIN + ((double)k + (double)q / 3.0) / (double)HTAB_PER_UNIT;
     double sp, sg;
     softplus_sigmoid(z, sp, sg);
     y[q] = digamma_pos(sp) * sg;
