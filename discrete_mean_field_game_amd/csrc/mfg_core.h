@@ -141,24 +141,24 @@ __device__ __forceinline__ PolicyTerms<FAST> policy_terms(const PolicyElem<FAST>
   return o;
 }
 
-// NE (1..4) matrix elements of one row from ONE Philox block, written so that the NE dependency chains sit in one
-// basic block and interleave (measured on gfx950: a single dependent chain issues one VALU instruction per ~5 cycles
-// per SIMD at any occupancy, two or more independent chains per wave one per ~2): no branch on the hot path -- the
-// rare exact-acceptance / small-shape continuations of all NE elements hide behind one wave-uniform test.
-//   pj[e], ej[e]: state entry and E_j of the element's column (ej unused unless SEP); elem0 = id of the first element,
-//   estride = distance between consecutive element ids (1: neighbouring columns of the small-d tile; 64: a lane's
-//   columns in the wave-per-trajectory kernels).  y[e] receive the gamma variates; the row sums of the NE elements are
-//   ADDED to ys / as / ds / gs in the working precision.
+// NE (1..4) matrix elements from ONE Philox block (keyed by elem[0]).  Elements 2h, 2h+1 share a Box-Muller pair.
+// Written so that the two chains of a pair sit in one basic block and interleave (measured on gfx950: a single
+// dependent chain issues one VALU instruction per ~5 cycles per SIMD, two independent chains one per ~2): no branch on
+// the hot path -- the rare exact-acceptance / small-shape continuations hide behind one wave-uniform test per pair.
+//   Per element e: pj / ej = state entry and E_j of its column, pai / Fi = state entry and F_i of its ROW (ej, Fi unused
+//   unless SEP), elem = its element id (Philox counter of its own continuation draws), valid = whether it exists
+//   (lanes past the last column compute on clamped inputs and are masked out).
+//   Out: y = gamma variate (0 when !valid); al / ad / gt = its alpha, alpha', score term (0 when !valid; TD only).
 template <int NE, bool TD, bool FAST, bool SEP>
-__device__ __forceinline__ void sample_elems(const CoreArgs& a, double theta, const ThetaSplit& ts, const float* pj,
-                                             const float* ej, float pai, float Fi, uint32_t elem0, uint32_t estride,
-                                             uint32_t step, uint64_t traj, float* y, float& ys,
-                                             typename PolicyTerms<FAST>::T& as, typename PolicyTerms<FAST>::T& ds,
-                                             typename PolicyTerms<FAST>::T& gs) {
+__device__ __forceinline__ void sample_elems_g(const CoreArgs& a, double theta, const ThetaSplit& ts, const float* pj,
+                                               const float* ej, const float* pai, const float* Fi, const uint32_t* elem,
+                                               const bool* valid, uint32_t step, uint64_t traj, float* y,
+                                               typename PolicyTerms<FAST>::T* al, typename PolicyTerms<FAST>::T* ad,
+                                               typename PolicyTerms<FAST>::T* gt) {
   QuadRand q;
-  quad_rand(q, a.seed, elem0, step, traj);
+  quad_rand(q, a.seed, elem[0], step, traj);
   // the two Box-Muller pairs one after the other (two interleaved chains each; four at once cost 36 spilled VGPRs at
-  // the 128-register cap and bought nothing at full occupancy)
+  // the 128-register cap of the small-d kernel and bought nothing at full occupancy)
 #pragma unroll
   for (int h = 0; 2 * h < NE; ++h) {
     const int n2 = (NE - 2 * h) >= 2 ? 2 : 1;
@@ -167,8 +167,8 @@ __device__ __forceinline__ void sample_elems(const CoreArgs& a, double theta, co
     for (int u = 0; u < 2; ++u) {
       if (u < n2) {
         const int e = 2 * h + u;
-        if constexpr (SEP) policy_setup_sep<true, TD>(pe[u], a, ts, pj[e], ej[e], pai, Fi);
-        else policy_setup<true, TD, FAST>(pe[u], a, theta, ts, pj[e], pai);
+        if constexpr (SEP) policy_setup_sep<true, TD>(pe[u], a, ts, pj[e], ej[e], pai[e], Fi[e]);
+        else policy_setup<true, TD, FAST>(pe[u], a, theta, ts, pj[e], pai[e]);
       }
     }
     float xn[2], v[2];
@@ -185,29 +185,63 @@ __device__ __forceinline__ void sample_elems(const CoreArgs& a, double theta, co
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       if (u < n2) {
-        v[u] = gamma_try(pe[u].gs, xn[u], q.kf[2 * h + u], sure[u]);
-        y[2 * h + u] = pe[u].gs.dd * v[u];
-        cold = cold || !sure[u] || pe[u].gs.small;
+        const int e = 2 * h + u;
+        v[u] = gamma_try(pe[u].gs, xn[u], q.kf[e], sure[u]);
+        y[e] = pe[u].gs.dd * v[u];
+        cold = cold || (valid[e] && (!sure[u] || pe[u].gs.small));
       }
     }
     if (__builtin_amdgcn_ballot_w64(cold) != 0) {  // wave-uniform, ~1 % of the pairs at the reference policies
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
-        if (u < n2 && (!sure[u] || pe[u].gs.small))
-          y[2 * h + u] = gamma_fix(pe[u].gs, xn[u], q.kf[2 * h + u], sure[u], v[u], a.seed,
-                                   elem0 + (uint32_t)(2 * h + u) * estride, step, traj);
+      for (int u = 0; u < 2; ++u) {
+        const int e = 2 * h + u;
+        if (u < n2 && valid[e] && (!sure[u] || pe[u].gs.small))
+          y[e] = gamma_fix(pe[u].gs, xn[u], q.kf[e], sure[u], v[u], a.seed, elem[e], step, traj);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       if (u < n2) {
-        ys += y[2 * h + u];
+        const int e = 2 * h + u;
         if (TD) {
-          const PolicyTerms<FAST> t = policy_terms<true, FAST>(pe[u], a.htab, ts.th, y[2 * h + u]);
-          as += t.al;
-          ds += t.ad;
-          gs += t.gt;
+          const PolicyTerms<FAST> t = policy_terms<true, FAST>(pe[u], a.htab, ts.th, y[e]);
+          al[e] = valid[e] ? t.al : 0;
+          ad[e] = valid[e] ? t.ad : 0;
+          gt[e] = valid[e] ? t.gt : 0;
         }
+        if (!valid[e]) y[e] = 0.0f;
       }
+    }
+  }
+}
+
+// Small-d wrapper: NE neighbouring elements of ONE row (all valid); the row sums of the NE elements are ADDED to
+// ys / as / ds / gs in the working precision.
+template <int NE, bool TD, bool FAST, bool SEP>
+__device__ __forceinline__ void sample_elems(const CoreArgs& a, double theta, const ThetaSplit& ts, const float* pj,
+                                             const float* ej, float pai, float Fi, uint32_t elem0, uint32_t step,
+                                             uint64_t traj, float* y, float& ys, typename PolicyTerms<FAST>::T& as,
+                                             typename PolicyTerms<FAST>::T& ds, typename PolicyTerms<FAST>::T& gs) {
+  using TT = typename PolicyTerms<FAST>::T;
+  float pa[NE], fi[NE];
+  uint32_t el[NE];
+  bool ok[NE];
+  TT al[NE], ad[NE], gt[NE];
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    pa[e] = pai;
+    fi[e] = Fi;
+    el[e] = elem0 + (uint32_t)e;
+    ok[e] = true;
+  }
+  sample_elems_g<NE, TD, FAST, SEP>(a, theta, ts, pj, ej, pa, fi, el, ok, step, traj, y, al, ad, gt);
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    ys += y[e];
+    if (TD) {
+      as += al[e];
+      ds += ad[e];
+      gs += gt[e];
     }
   }
 }
@@ -403,7 +437,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
           for (int j = 0; j < dq; j += 4) {
             float y[4], ys = 0.0f;
             TT as = 0, ds = 0, gs = 0;
-            sample_elems<4, TD, FAST, sep>(a, theta, ts, pav + j, ev + j, pai, Fi, erow + (uint32_t)j, 1u, step, traj, y, ys,
+            sample_elems<4, TD, FAST, sep>(a, theta, ts, pav + j, ev + j, pai, Fi, erow + (uint32_t)j, step, traj, y, ys,
                                            as, ds, gs);
 #pragma unroll
             for (int e = 0; e < 4; ++e) trow[j + e] = y[e];
@@ -419,13 +453,13 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
             TT as = 0, ds = 0, gs = 0;
             const int rem = d - dq;
             if (rem == 1)
-              sample_elems<1, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pai, Fi, erow + (uint32_t)dq, 1u, step, traj, y,
+              sample_elems<1, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pai, Fi, erow + (uint32_t)dq, step, traj, y,
                                              ys, as, ds, gs);
             else if (rem == 2)
-              sample_elems<2, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pai, Fi, erow + (uint32_t)dq, 1u, step, traj, y,
+              sample_elems<2, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pai, Fi, erow + (uint32_t)dq, step, traj, y,
                                              ys, as, ds, gs);
             else
-              sample_elems<3, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pai, Fi, erow + (uint32_t)dq, 1u, step, traj, y,
+              sample_elems<3, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pai, Fi, erow + (uint32_t)dq, step, traj, y,
                                              ys, as, ds, gs);
             for (int e = 0; e < rem; ++e) trow[dq + e] = y[e];
             Ssum += (double)ys;
@@ -449,7 +483,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
           // normalise the row.  strict: P_ij = fl32(y_ij / S_i); mixed: P_ij = y_ij * fl32(1 / S_i) (one fp32 multiply per
           // element, within 1.5 ulp of the strict value; rows still sum to 1 within a few 1e-7)
           if (FAST) {
-            const float inv32 = (float)fast_rcp_f64(Ssum);
+            const float inv32 = fast_rcp_f32_of_f64(Ssum);
             for (int j = 0; j < d; ++j) trow[j] *= inv32;
 #ifndef MFG_ABL_EPI
             if (TD) gacc -= fast_log_f64(Ssum) * D_;
@@ -610,22 +644,30 @@ inline size_t core_small_lds(int d, bool want_v, bool sample) {
 // ---------------------------------------------------------------------------------------------
 // large d (d > 64): one wavefront per trajectory, lane owns columns c = lane + 64 m (m < R).
 // ---------------------------------------------------------------------------------------------
+// SAMPLE mode (round 2): rows are processed TWO at a time so that one Philox block feeds a quad
+// {(i, c), (i, c+64), (i+1, c), (i+1, c+64)} of the lane's columns (sample_elems_g); e^z is separable (E_c lives in the
+// registers of the lane that owns column c, F_i of the row comes from LDS); in mixed mode the per-row sums S, A, D of the
+// two rows are six interleaved fp32 DPP wave sums (a third of the instructions of three fp64 ones, per row); the
+// transition and reward sums use the u = pi_i P form (4 fp64 operations per element).
 template <int R, bool SAMPLE, bool TD, bool FAST>
 __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int d = a.d, T = a.T;
   const int64_t dd = (int64_t)d * d;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-  float* pis = smem + wv * 3 * d;  // current state
+  float* pis = smem + wv * 4 * d;  // current state
   float* pin = pis + d;            // next state
   float* pal = pin + d;            // state for alpha (GIVEN with pi_alpha)
+  float* pfs = pal + d;            // SAMPLE, mixed: F_i = e^{-theta (pi_i + shift)}
   // per-row (A_i, D_i, S_i) of this wave's trajectory: psi(A_i) D_i and ln(S_i) D_i are evaluated AFTER the row
   // loop, one row per lane, instead of once per row by the whole wave (a fp64 digamma + log per row amortised
   // over only d/64 elements per lane dominated the TD kernels at d = 128)
-  double* rowq = reinterpret_cast<double*>(smem + WAVES * 3 * d + ((WAVES * 3 * d) & 1)) + wv * 3 * d;
+  double* rowq = reinterpret_cast<double*>(smem + WAVES * 4 * d) + wv * 3 * d;
   const bool want_v = TD && a.w != nullptr;
   const double theta = *a.theta;
   const ThetaSplit ts = theta_split(theta, a.shift);
+  constexpr bool sep = SAMPLE && FAST;
+  using TT = typename PolicyTerms<FAST>::T;
   const int64_t nw = (int64_t)gridDim.x * WAVES;
   for (int64_t b = (int64_t)blockIdx.x * WAVES + wv; b < a.B; b += nw) {
     float pc[R];
@@ -640,67 +682,184 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
     const uint64_t traj = a.traj_offset + (uint64_t)b;
     for (int s = 0; s < T; ++s) {
       __builtin_amdgcn_wave_barrier();
+      float Ec[R];
 #pragma unroll
       for (int m = 0; m < R; ++m) {
         const int c = lane + m * WAVE;
+        Ec[m] = 0.0f;
         if (c < d) {
           pis[c] = pc[m];
           if (!SAMPLE && a.pi_next_in) pin[c] = a.pi_next_in[b * d + c];
           if (!SAMPLE && a.pi_alpha) pal[c] = a.pi_alpha[b * d + c];
+          if (sep) {
+            Ec[m] = exp_f64arg(theta * (double)pc[m]);
+            pfs[c] = exp_f64arg(-theta * ((double)pc[m] + a.shift));
+          }
         }
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
       const float* pav = (!SAMPLE && a.pi_alpha) ? pal : pis;
-      double pcd[R], acc[R];
+      double pcd[R], acc[R], s1[R];
       float pad[R];
+      bool okc[R];
 #pragma unroll
       for (int m = 0; m < R; ++m) {
         const int c = lane + m * WAVE;
+        okc[m] = c < d;
         pcd[m] = (double)pc[m];
         pad[m] = c < d ? pav[c] : 0.0f;
         acc[m] = 0.0;
+        s1[m] = 0.0;
       }
-      double racc = 0.0, gacc = 0.0, guni = 0.0;
+      double racc = 0.0, s2 = 0.0, gacc = 0.0, guni = 0.0;
       const float* Pb = SAMPLE ? nullptr : a.P_in + b * dd;
       float* Po = (SAMPLE && a.P_out) ? a.P_out + (b * (int64_t)T + s) * dd : nullptr;
       const uint32_t step = a.first_step + (uint32_t)s;
-      for (int i = 0; i < d; ++i) {
-        const double pii = (double)pis[i];
-        const float pai = pav[i];
-        float y[R];
-        double Ssum = 0.0, A = 0.0, D = 0.0;
-        PolicyElem<FAST> pe;
-        if (SAMPLE) {
-          // this lane's columns c = lane + 64 m, two per iteration (pair counter = element of the first one;
-          // the partner is 64 columns away, so it retries on ITS element id, passed explicitly)
+      if constexpr (SAMPLE) {
+        for (int i = 0; i < d; i += 2) {
+          const bool row1 = i + 1 < d;
+          const int i1 = row1 ? i + 1 : i;
+          const float pr[2] = {pis[i], pis[i1]};
+          float fr[2] = {0.0f, 0.0f};
+          if (sep) {
+            fr[0] = pfs[i];
+            fr[1] = pfs[i1];
+          }
+          float y[2][R];
+          TT ysum[2] = {0, 0}, asum[2] = {0, 0}, dsum[2] = {0, 0}, gsum = 0;
 #pragma unroll
           for (int m = 0; m < R; m += 2) {
-            const int c0 = lane + m * WAVE;
-            const bool has0 = c0 < d;
-            const bool has1 = (m + 1 < R) && (c0 + WAVE < d);
-            PolicyElem<FAST> pe1;
-            y[m] = 0.0f;
-            if (m + 1 < R) y[m + 1] = 0.0f;
-            if (has0) {
-              policy_setup<SAMPLE, TD, FAST>(pe, a, theta, ts, pad[m], pai);
-              policy_setup<SAMPLE, TD, FAST>(pe1, a, theta, ts, pad[(m + 1 < R) ? m + 1 : m], pai);
-              float y0, y1;
-              gamma_pair_strided(pe.gs, pe1.gs, has1, a.seed, (uint32_t)(i * d + c0), (uint32_t)(i * d + c0 + WAVE), step,
-                                 traj, y0, y1);
-              if (y0 == 0.0f) y0 = ZERO_GAMMA_REPLACEMENT;
-              if (y1 == 0.0f) y1 = ZERO_GAMMA_REPLACEMENT;
-              y[m] = y0;
-              Ssum += (double)y0;
-              policy_accumulate<SAMPLE, TD, FAST>(pe, a.htab, ts.th, y0, A, D, gacc);
-              if (has1) {
-                if (m + 1 < R) y[m + 1] = y1;
-                Ssum += (double)y1;
-                policy_accumulate<SAMPLE, TD, FAST>(pe1, a.htab, ts.th, y1, A, D, gacc);
+            const bool two = m + 1 < R;  // compile time
+            const int m1 = two ? m + 1 : m;
+            const uint32_t e00 = (uint32_t)(i * d + lane + m * WAVE), e10 = (uint32_t)(i1 * d + lane + m * WAVE);
+            if (two) {
+              const float pj[4] = {pad[m], pad[m1], pad[m], pad[m1]};
+              const float ej[4] = {Ec[m], Ec[m1], Ec[m], Ec[m1]};
+              const float pa[4] = {pr[0], pr[0], pr[1], pr[1]};
+              const float fi[4] = {fr[0], fr[0], fr[1], fr[1]};
+              const uint32_t el[4] = {e00, e00 + WAVE, e10, e10 + WAVE};
+              const bool ok[4] = {okc[m], okc[m1], okc[m] && row1, okc[m1] && row1};
+              float yy[4];
+              TT al[4], ad[4], gt[4];
+              sample_elems_g<4, TD, FAST, sep>(a, theta, ts, pj, ej, pa, fi, el, ok, step, traj, yy, al, ad, gt);
+              y[0][m] = yy[0];
+              y[0][m1] = yy[1];
+              y[1][m] = yy[2];
+              y[1][m1] = yy[3];
+              ysum[0] += (TT)yy[0] + (TT)yy[1];
+              ysum[1] += (TT)yy[2] + (TT)yy[3];
+              if (TD) {
+                asum[0] += al[0] + al[1];
+                asum[1] += al[2] + al[3];
+                dsum[0] += ad[0] + ad[1];
+                dsum[1] += ad[2] + ad[3];
+                gsum += (gt[0] + gt[1]) + (gt[2] + gt[3]);
+              }
+            } else {
+              // odd R: the lane's last column; its two rows share the Box-Muller pair
+              const float pj[2] = {pad[m], pad[m]};
+              const float ej[2] = {Ec[m], Ec[m]};
+              const float pa[2] = {pr[0], pr[1]};
+              const float fi[2] = {fr[0], fr[1]};
+              const uint32_t el[2] = {e00, e10};
+              const bool ok[2] = {okc[m], okc[m] && row1};
+              float yy[2];
+              TT al[2], ad[2], gt[2];
+              sample_elems_g<2, TD, FAST, sep>(a, theta, ts, pj, ej, pa, fi, el, ok, step, traj, yy, al, ad, gt);
+              y[0][m] = yy[0];
+              y[1][m] = yy[1];
+              ysum[0] += (TT)yy[0];
+              ysum[1] += (TT)yy[1];
+              if (TD) {
+                asum[0] += al[0];
+                asum[1] += al[1];
+                dsum[0] += ad[0];
+                dsum[1] += ad[1];
+                gsum += gt[0] + gt[1];
               }
             }
           }
-        } else {
+          if (TD) gacc += (double)gsum;
+          double Sr[2], Ar[2] = {0.0, 0.0}, Dr[2] = {0.0, 0.0};
+          if constexpr (FAST) {
+            if (TD) {
+              float x6[6] = {ysum[0], asum[0], dsum[0], ysum[1], asum[1], dsum[1]};
+              wave_sums_f32_dpp<6>(x6);
+              Sr[0] = (double)x6[0];
+              Ar[0] = (double)x6[1];
+              Dr[0] = (double)x6[2];
+              Sr[1] = (double)x6[3];
+              Ar[1] = (double)x6[4];
+              Dr[1] = (double)x6[5];
+            } else {
+              float x2[2] = {ysum[0], ysum[1]};
+              wave_sums_f32_dpp<2>(x2);
+              Sr[0] = (double)x2[0];
+              Sr[1] = (double)x2[1];
+            }
+          } else {
+            Sr[0] = ysum[0];
+            Sr[1] = ysum[1];
+            if (TD) {
+              Ar[0] = asum[0];
+              Dr[0] = dsum[0];
+              Ar[1] = asum[1];
+              Dr[1] = dsum[1];
+              wave_sum3_dpp(Sr[0], Ar[0], Dr[0]);
+              wave_sum3_dpp(Sr[1], Ar[1], Dr[1]);
+            } else {
+              Sr[0] = wave_sum_dpp(Sr[0]);
+              Sr[1] = wave_sum_dpp(Sr[1]);
+            }
+          }
+          if (!row1) Sr[1] = 1.0;
+          if (TD && lane == 0) {
+            rowq[3 * i] = Ar[0];
+            rowq[3 * i + 1] = Dr[0];
+            rowq[3 * i + 2] = Sr[0];
+            if (row1) {
+              rowq[3 * i1] = Ar[1];
+              rowq[3 * i1 + 1] = Dr[1];
+              rowq[3 * i1 + 2] = Sr[1];
+            }
+          }
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            if (rr == 1 && !row1) break;
+            const int ir = rr ? i1 : i;
+            const double pii = (double)pr[rr];
+            float inv32 = 0.0f;
+            double invS = 0.0;
+            if (FAST) inv32 = fast_rcp_f32_of_f64(Sr[rr]);
+            else invS = 1.0 / Sr[rr];
+#pragma unroll
+            for (int m = 0; m < R; ++m) {
+              if (okc[m]) {
+                const float p32 = FAST ? y[rr][m] * inv32 : (float)((double)y[rr][m] * invS);
+                const double p = (double)p32;
+                if (Po) Po[(int64_t)ir * d + lane + m * WAVE] = p32;
+                const double u = p * pii;
+                acc[m] += u;
+                if (a.reward_kind != MFG_REWARD_EXTERNAL) {
+                  s1[m] = fma(u, p, s1[m]);
+                  if (a.reward_kind == MFG_REWARD_MFG_AC2) s2 = fma(u, u, s2);
+                }
+              }
+            }
+          }
+        }
+        // R = sum_j (pi_j s1_j - s2_j)  (kind 0)  /  -1/2 sum_j s1_j  (kind 1)
+#pragma unroll
+        for (int m = 0; m < R; ++m) racc += (a.reward_kind == MFG_REWARD_MFG_AC2) ? pcd[m] * s1[m] : s1[m];
+        if (a.reward_kind == MFG_REWARD_MFG_AC2) racc -= s2;
+      } else {
+        for (int i = 0; i < d; ++i) {
+          const double pii = (double)pis[i];
+          const float pai = pav[i];
+          float y[R];
+          double A = 0.0, D = 0.0;
+          PolicyElem<FAST> pe;
 #pragma unroll
           for (int m = 0; m < R; ++m) {
             const int c = lane + m * WAVE;
@@ -711,34 +870,23 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
               policy_accumulate<SAMPLE, TD, FAST>(pe, a.htab, ts.th, y[m], A, D, gacc);
             }
           }
-        }
-        double invS = 1.0;
-        if (SAMPLE && TD) {
-          wave_sum3_dpp(Ssum, A, D);
-          invS = 1.0 / Ssum;
-        } else if (SAMPLE) {
-          Ssum = wave_sum_dpp(Ssum);
-          invS = 1.0 / Ssum;
-        } else if (TD) {
-          A = wave_sum_dpp(A);
-          D = wave_sum_dpp(D);
-        }
-        if (TD) {
-          if (lane == 0) {
-            rowq[3 * i] = A;
-            rowq[3 * i + 1] = D;
-            rowq[3 * i + 2] = SAMPLE ? Ssum : 1.0;
+          if (TD) {
+            A = wave_sum_dpp(A);
+            D = wave_sum_dpp(D);
+            if (lane == 0) {
+              rowq[3 * i] = A;
+              rowq[3 * i + 1] = D;
+              rowq[3 * i + 2] = 1.0;
+            }
           }
-        }
 #pragma unroll
-        for (int m = 0; m < R; ++m) {
-          const int c = lane + m * WAVE;
-          if (c < d) {
-            const float p32 = SAMPLE ? (float)((double)y[m] * invS) : y[m];
-            const double p = (double)p32;
-            if (Po) Po[(int64_t)i * d + c] = p32;
-            acc[m] = fma(p, pii, acc[m]);
-            racc += pii * reward_term(a.reward_kind, pii, pcd[m], p);
+          for (int m = 0; m < R; ++m) {
+            const int c = lane + m * WAVE;
+            if (c < d) {
+              const double p = (double)y[m];
+              acc[m] = fma(p, pii, acc[m]);
+              racc += pii * reward_term(a.reward_kind, pii, pcd[m], p);
+            }
           }
         }
       }
@@ -764,10 +912,15 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
       if (TD) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
-        for (int r = lane; r < d; r += WAVE) {
-          const double Dr = rowq[3 * r + 1];
-          guni = fma(digamma_pos(rowq[3 * r]), Dr, guni);
-          if (SAMPLE) guni -= log(rowq[3 * r + 2]) * Dr;
+        for (int rw = lane; rw < d; rw += WAVE) {
+          const double Dr = rowq[3 * rw + 1];
+          if (SAMPLE && FAST) {
+            guni = fma(digamma_pos_mixed(rowq[3 * rw]), Dr, guni);
+            guni -= fast_log_f64(rowq[3 * rw + 2]) * Dr;
+          } else {
+            guni = fma(digamma_pos(rowq[3 * rw]), Dr, guni);
+            if (SAMPLE) guni -= log(rowq[3 * rw + 2]) * Dr;
+          }
         }
         const double gsum = wave_sum_dpp(gacc + guni);
         if (lane == 0 && a.g) a.g[b * T + s] = gsum;
@@ -815,7 +968,7 @@ template <bool FAST>
 inline int launch_core_large_impl(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st) {
   const int d = a.d;
   const int R = (d + WAVE - 1) / WAVE;
-  const size_t lds = (size_t)WAVES * 3 * d * 4 + 8 + (size_t)WAVES * 3 * d * 8;
+  const size_t lds = (size_t)WAVES * 4 * d * 4 + (size_t)WAVES * 3 * d * 8;
   const int grid = core_grid(a.B, WAVES, 8 * MFG_CORE_OVERSUBSCRIBE, num_cus);
 #define MFG_CORE_LARGE_MODE(RR)                                                                              \
   if (sample && td) hipLaunchKernelGGL((k_core_large<RR, true, true, FAST>), dim3(grid), dim3(BLOCK), lds, st, a);        \

@@ -367,25 +367,34 @@ __device__ __forceinline__ double fast_log_f64(double x) {
   const float lg2 = __builtin_amdgcn_logf(mh);
   return fma((double)ex + (double)lg2, 0.6931471805599453, (double)(ml * __builtin_amdgcn_rcpf(mh)));
 }
-// digamma for x > 0, mixed precision: same recurrence / series as digamma_pos, with the fast reciprocal and log
-// (series cut after 1/(240 x^8): < 3e-10 for x >= 8).
+// digamma for x > 0, mixed precision (|error| < 1e-9 + the fast log's 4e-8): asymptotic series from x >= 4 (six
+// Bernoulli terms: the first omitted one is 3e-10 at x = 4), a FOUR-step recurrence below that.  Row sums A_i of the
+// concentrations are 5 .. 15 at the reference policies, so the recurrence (and its reciprocal) is skipped wave-wide
+// almost always; everything is a short fp64 chain (the per-row epilogue is latency bound).
 __device__ __forceinline__ double digamma_pos_mixed(double x) {
   double corr = 0.0;
-  if (x < 8.0) {
-    double q = x, qp = 1.0;
-#pragma unroll
-    for (int k = 1; k < 8; ++k) {
-      const double xk = x + (double)k;
-      qp = fma(qp, xk, q);
-      q = q * xk;
-    }
+  if (x < 4.0) {
+    // sum_{k<4} 1/(x+k) = q'(x)/q(x), q = x (x+1) (x+2) (x+3)
+    const double a = x * (x + 3.0);          // x^2 + 3x
+    const double q = a * (a + 2.0);          // (x^2+3x)(x^2+3x+2)
+    const double qp = (2.0 * x + 3.0) * (2.0 * a + 2.0);
     corr = qp * fast_rcp_f64(q);
-    x += 8.0;
+    x += 4.0;
   }
   const double inv = fast_rcp_f64(x);
-  const double inv2 = inv * inv;
-  const double s = inv2 * (1.0 / 12.0 - inv2 * (1.0 / 120.0 - inv2 * (1.0 / 252.0 - inv2 * (1.0 / 240.0))));
+  const double t = inv * inv;
+  // t (1/12 - t/120 + t^2/252 - t^3/240 + t^4/132 - t^5 691/32760)
+  const double s = t * (1.0 / 12.0 - t * (1.0 / 120.0 - t * (1.0 / 252.0 - t * (1.0 / 240.0 - t * (1.0 / 132.0 -
+                   t * (691.0 / 32760.0))))));
   return fast_log_f64(x) - 0.5 * inv - s - corr;
+}
+
+// 1 / x as fp32 for an fp64 x (row normaliser): hardware reciprocal of the fp32 head + one Newton step, ~1e-7 relative.
+__device__ __forceinline__ float fast_rcp_f32_of_f64(double x) {
+  const float xf = (float)x;
+  float r = __builtin_amdgcn_rcpf(xf);
+  r = fmaf(fmaf(-xf, r, 1.0f), r, r);
+  return r;
 }
 
 // Split-constant helper: z = theta * (pj - pi - shift) evaluated in fp32 with the rounding of the
@@ -510,6 +519,35 @@ __device__ __forceinline__ void wave_sum3_dpp(double& a, double& b, double& c) {
   a = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), 63), __builtin_amdgcn_readlane(__double2loint(a), 63));
   b = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(b), 63), __builtin_amdgcn_readlane(__double2loint(b), 63));
   c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c), 63), __builtin_amdgcn_readlane(__double2loint(c), 63));
+}
+
+// fp32 wave sums on the DPP path, NS independent values step-interleaved (mixed mode of the wave-per-trajectory kernels:
+// the per-row S, A, D of two rows = six sums; each step is ONE v_add_f32 with a DPP operand, against two moves and an
+// fp64 add for a double).  A tree sum of 64 fp32 terms: ~1e-7 relative, of the order of the terms' own rounding.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov_f32(float v) {
+  const int x = __float_as_int(v);
+  const int r = (ROW_MASK == 0xF) ? __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true)
+                                  : __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xF, false);
+  return __int_as_float(r);
+}
+template <int NS>
+__device__ __forceinline__ void wave_sums_f32_dpp(float* x) {
+#define MFG_SUMF_STEP(CTRL, MASK)                                          \
+  {                                                                        \
+    float t[NS];                                                           \
+    _Pragma("unroll") for (int q = 0; q < NS; ++q) t[q] = dpp_mov_f32<CTRL, MASK>(x[q]); \
+    _Pragma("unroll") for (int q = 0; q < NS; ++q) x[q] += t[q];           \
+  }
+  MFG_SUMF_STEP(0xB1, 0xF)
+  MFG_SUMF_STEP(0x4E, 0xF)
+  MFG_SUMF_STEP(0x141, 0xF)
+  MFG_SUMF_STEP(0x140, 0xF)
+  MFG_SUMF_STEP(0x142, 0xA)
+  MFG_SUMF_STEP(0x143, 0xC)
+#undef MFG_SUMF_STEP
+#pragma unroll
+  for (int q = 0; q < NS; ++q) x[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[q]), 63));
 }
 
 template <typename T>

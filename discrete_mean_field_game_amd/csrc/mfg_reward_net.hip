@@ -229,10 +229,7 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
 // The run's 2*RUN FC3 inputs are contiguous in the NHWC-flattened weight rows (8-byte reads), the FC3 reductions run on
 // the DPP path instead of ds_bpermute, and the conv weights sit in scalar registers.
 // ---------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_mov_f32(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
-}
+// (dpp_mov_f32 lives in mfg_device.h)
 __device__ __forceinline__ float wave_sum_f32_dpp(float v) {
   v += dpp_mov_f32<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
   v += dpp_mov_f32<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
