@@ -649,8 +649,13 @@ inline size_t core_small_lds(int d, bool want_v, bool sample) {
 // registers of the lane that owns column c, F_i of the row comes from LDS); in mixed mode the per-row sums S, A, D of the
 // two rows are six interleaved fp32 DPP wave sums (a third of the instructions of three fp64 ones, per row); the
 // transition and reward sums use the u = pi_i P form (4 fp64 operations per element).
+// registers: R <= 2 fits 168 VGPRs (3 waves / SIMD) without spilling; R >= 3 needs ~220 (2 waves / SIMD; capping it at
+// 168 spills 45 registers and measured slower)
+#ifndef MFG_CORE_LARGE_WAVES
+#define MFG_CORE_LARGE_WAVES(R) (((R) <= 2 || (R) == 4) ? 3 : 2)
+#endif
 template <int R, bool SAMPLE, bool TD, bool FAST>
-__global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
+__global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(CoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int d = a.d, T = a.T;
   const int64_t dd = (int64_t)d * d;
@@ -700,15 +705,14 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
       const float* pav = (!SAMPLE && a.pi_alpha) ? pal : pis;
-      double pcd[R], acc[R], s1[R];
-      float pad[R];
+      double acc[R], s1[R];
+      float pad[R];  // state the concentrations are computed from (== pc when sampling)
       bool okc[R];
 #pragma unroll
       for (int m = 0; m < R; ++m) {
         const int c = lane + m * WAVE;
         okc[m] = c < d;
-        pcd[m] = (double)pc[m];
-        pad[m] = c < d ? pav[c] : 0.0f;
+        pad[m] = SAMPLE ? pc[m] : (c < d ? pav[c] : 0.0f);
         acc[m] = 0.0;
         s1[m] = 0.0;
       }
@@ -717,8 +721,11 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
       float* Po = (SAMPLE && a.P_out) ? a.P_out + (b * (int64_t)T + s) * dd : nullptr;
       const uint32_t step = a.first_step + (uint32_t)s;
       if constexpr (SAMPLE) {
-        for (int i = 0; i < d; i += 2) {
-          const bool row1 = i + 1 < d;
+        // rows per iteration: R a multiple of 4 -> a row's elements of this lane fill whole quads; otherwise two rows
+        // per iteration and quads {(i, m), (i, m+1), (i+1, m), (i+1, m+1)} (odd R: last column {(i, m), (i+1, m)})
+        constexpr int NR = (R % 4 == 0) ? 1 : 2;
+        for (int i = 0; i < d; i += NR) {
+          const bool row1 = NR == 2 && i + 1 < d;
           const int i1 = row1 ? i + 1 : i;
           const float pr[2] = {pis[i], pis[i1]};
           float fr[2] = {0.0f, 0.0f};
@@ -726,94 +733,126 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
             fr[0] = pfs[i];
             fr[1] = pfs[i1];
           }
-          float y[2][R];
+          float y[NR][R];
           TT ysum[2] = {0, 0}, asum[2] = {0, 0}, dsum[2] = {0, 0}, gsum = 0;
+          if constexpr (NR == 1) {
 #pragma unroll
-          for (int m = 0; m < R; m += 2) {
-            const bool two = m + 1 < R;  // compile time
-            const int m1 = two ? m + 1 : m;
-            const uint32_t e00 = (uint32_t)(i * d + lane + m * WAVE), e10 = (uint32_t)(i1 * d + lane + m * WAVE);
-            if (two) {
-              const float pj[4] = {pad[m], pad[m1], pad[m], pad[m1]};
-              const float ej[4] = {Ec[m], Ec[m1], Ec[m], Ec[m1]};
-              const float pa[4] = {pr[0], pr[0], pr[1], pr[1]};
-              const float fi[4] = {fr[0], fr[0], fr[1], fr[1]};
-              const uint32_t el[4] = {e00, e00 + WAVE, e10, e10 + WAVE};
-              const bool ok[4] = {okc[m], okc[m1], okc[m] && row1, okc[m1] && row1};
+            for (int m = 0; m < R; m += 4) {
+              const uint32_t e0 = (uint32_t)(i * d + lane + m * WAVE);
+              const float pj[4] = {pad[m], pad[m + 1], pad[m + 2], pad[m + 3]};
+              const float ej[4] = {Ec[m], Ec[m + 1], Ec[m + 2], Ec[m + 3]};
+              const float pa[4] = {pr[0], pr[0], pr[0], pr[0]};
+              const float fi[4] = {fr[0], fr[0], fr[0], fr[0]};
+              const uint32_t el[4] = {e0, e0 + WAVE, e0 + 2 * WAVE, e0 + 3 * WAVE};
+              const bool ok[4] = {okc[m], okc[m + 1], okc[m + 2], okc[m + 3]};
               float yy[4];
               TT al[4], ad[4], gt[4];
               sample_elems_g<4, TD, FAST, sep>(a, theta, ts, pj, ej, pa, fi, el, ok, step, traj, yy, al, ad, gt);
-              y[0][m] = yy[0];
-              y[0][m1] = yy[1];
-              y[1][m] = yy[2];
-              y[1][m1] = yy[3];
-              ysum[0] += (TT)yy[0] + (TT)yy[1];
-              ysum[1] += (TT)yy[2] + (TT)yy[3];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) y[0][m + e] = yy[e];
+              ysum[0] += ((TT)yy[0] + (TT)yy[1]) + ((TT)yy[2] + (TT)yy[3]);
               if (TD) {
-                asum[0] += al[0] + al[1];
-                asum[1] += al[2] + al[3];
-                dsum[0] += ad[0] + ad[1];
-                dsum[1] += ad[2] + ad[3];
+                asum[0] += (al[0] + al[1]) + (al[2] + al[3]);
+                dsum[0] += (ad[0] + ad[1]) + (ad[2] + ad[3]);
                 gsum += (gt[0] + gt[1]) + (gt[2] + gt[3]);
               }
-            } else {
-              // odd R: the lane's last column; its two rows share the Box-Muller pair
-              const float pj[2] = {pad[m], pad[m]};
-              const float ej[2] = {Ec[m], Ec[m]};
-              const float pa[2] = {pr[0], pr[1]};
-              const float fi[2] = {fr[0], fr[1]};
-              const uint32_t el[2] = {e00, e10};
-              const bool ok[2] = {okc[m], okc[m] && row1};
-              float yy[2];
-              TT al[2], ad[2], gt[2];
-              sample_elems_g<2, TD, FAST, sep>(a, theta, ts, pj, ej, pa, fi, el, ok, step, traj, yy, al, ad, gt);
-              y[0][m] = yy[0];
-              y[1][m] = yy[1];
-              ysum[0] += (TT)yy[0];
-              ysum[1] += (TT)yy[1];
-              if (TD) {
-                asum[0] += al[0];
-                asum[1] += al[1];
-                dsum[0] += ad[0];
-                dsum[1] += ad[1];
-                gsum += gt[0] + gt[1];
+            }
+          } else {
+#pragma unroll
+            for (int m = 0; m < R; m += 2) {
+              const bool two = m + 1 < R;  // compile time
+              const int m1 = two ? m + 1 : m;
+              const uint32_t e00 = (uint32_t)(i * d + lane + m * WAVE), e10 = (uint32_t)(i1 * d + lane + m * WAVE);
+              if (two) {
+                const float pj[4] = {pad[m], pad[m1], pad[m], pad[m1]};
+                const float ej[4] = {Ec[m], Ec[m1], Ec[m], Ec[m1]};
+                const float pa[4] = {pr[0], pr[0], pr[1], pr[1]};
+                const float fi[4] = {fr[0], fr[0], fr[1], fr[1]};
+                const uint32_t el[4] = {e00, e00 + WAVE, e10, e10 + WAVE};
+                const bool ok[4] = {okc[m], okc[m1], okc[m] && row1, okc[m1] && row1};
+                float yy[4];
+                TT al[4], ad[4], gt[4];
+                sample_elems_g<4, TD, FAST, sep>(a, theta, ts, pj, ej, pa, fi, el, ok, step, traj, yy, al, ad, gt);
+                y[0][m] = yy[0];
+                y[0][m1] = yy[1];
+                y[NR - 1][m] = yy[2];
+                y[NR - 1][m1] = yy[3];
+                ysum[0] += (TT)yy[0] + (TT)yy[1];
+                ysum[1] += (TT)yy[2] + (TT)yy[3];
+                if (TD) {
+                  asum[0] += al[0] + al[1];
+                  asum[1] += al[2] + al[3];
+                  dsum[0] += ad[0] + ad[1];
+                  dsum[1] += ad[2] + ad[3];
+                  gsum += (gt[0] + gt[1]) + (gt[2] + gt[3]);
+                }
+              } else {
+                // odd R: the lane's last column; its two rows share the Box-Muller pair
+                const float pj[2] = {pad[m], pad[m]};
+                const float ej[2] = {Ec[m], Ec[m]};
+                const float pa[2] = {pr[0], pr[1]};
+                const float fi[2] = {fr[0], fr[1]};
+                const uint32_t el[2] = {e00, e10};
+                const bool ok[2] = {okc[m], okc[m] && row1};
+                float yy[2];
+                TT al[2], ad[2], gt[2];
+                sample_elems_g<2, TD, FAST, sep>(a, theta, ts, pj, ej, pa, fi, el, ok, step, traj, yy, al, ad, gt);
+                y[0][m] = yy[0];
+                y[NR - 1][m] = yy[1];
+                ysum[0] += (TT)yy[0];
+                ysum[1] += (TT)yy[1];
+                if (TD) {
+                  asum[0] += al[0];
+                  asum[1] += al[1];
+                  dsum[0] += ad[0];
+                  dsum[1] += ad[1];
+                  gsum += gt[0] + gt[1];
+                }
               }
             }
           }
           if (TD) gacc += (double)gsum;
-          double Sr[2], Ar[2] = {0.0, 0.0}, Dr[2] = {0.0, 0.0};
+          double Sr[2] = {1.0, 1.0}, Ar[2] = {0.0, 0.0}, Dr[2] = {0.0, 0.0};
           if constexpr (FAST) {
             if (TD) {
-              float x6[6] = {ysum[0], asum[0], dsum[0], ysum[1], asum[1], dsum[1]};
-              wave_sums_f32_dpp<6>(x6);
-              Sr[0] = (double)x6[0];
-              Ar[0] = (double)x6[1];
-              Dr[0] = (double)x6[2];
-              Sr[1] = (double)x6[3];
-              Ar[1] = (double)x6[4];
-              Dr[1] = (double)x6[5];
+              float x6[3 * NR];
+#pragma unroll
+              for (int rr = 0; rr < NR; ++rr) {
+                x6[3 * rr] = ysum[rr];
+                x6[3 * rr + 1] = asum[rr];
+                x6[3 * rr + 2] = dsum[rr];
+              }
+#ifndef MFG_ABL_ROWSUM
+              wave_sums_f32_dpp<3 * NR>(x6);
+#endif
+#pragma unroll
+              for (int rr = 0; rr < NR; ++rr) {
+                Sr[rr] = (double)x6[3 * rr];
+                Ar[rr] = (double)x6[3 * rr + 1];
+                Dr[rr] = (double)x6[3 * rr + 2];
+              }
             } else {
-              float x2[2] = {ysum[0], ysum[1]};
-              wave_sums_f32_dpp<2>(x2);
-              Sr[0] = (double)x2[0];
-              Sr[1] = (double)x2[1];
+              float x2[NR];
+#pragma unroll
+              for (int rr = 0; rr < NR; ++rr) x2[rr] = ysum[rr];
+              wave_sums_f32_dpp<NR>(x2);
+#pragma unroll
+              for (int rr = 0; rr < NR; ++rr) Sr[rr] = (double)x2[rr];
             }
           } else {
-            Sr[0] = ysum[0];
-            Sr[1] = ysum[1];
-            if (TD) {
-              Ar[0] = asum[0];
-              Dr[0] = dsum[0];
-              Ar[1] = asum[1];
-              Dr[1] = dsum[1];
-              wave_sum3_dpp(Sr[0], Ar[0], Dr[0]);
-              wave_sum3_dpp(Sr[1], Ar[1], Dr[1]);
-            } else {
-              Sr[0] = wave_sum_dpp(Sr[0]);
-              Sr[1] = wave_sum_dpp(Sr[1]);
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+              Sr[rr] = ysum[rr];
+              if (TD) {
+                Ar[rr] = asum[rr];
+                Dr[rr] = dsum[rr];
+                wave_sum3_dpp(Sr[rr], Ar[rr], Dr[rr]);
+              } else {
+                Sr[rr] = wave_sum_dpp(Sr[rr]);
+              }
             }
           }
-          if (!row1) Sr[1] = 1.0;
+          if (NR == 2 && !row1) Sr[1] = 1.0;
           if (TD && lane == 0) {
             rowq[3 * i] = Ar[0];
             rowq[3 * i + 1] = Dr[0];
@@ -825,7 +864,7 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
             }
           }
 #pragma unroll
-          for (int rr = 0; rr < 2; ++rr) {
+          for (int rr = 0; rr < NR; ++rr) {
             if (rr == 1 && !row1) break;
             const int ir = rr ? i1 : i;
             const double pii = (double)pr[rr];
@@ -851,7 +890,7 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
         }
         // R = sum_j (pi_j s1_j - s2_j)  (kind 0)  /  -1/2 sum_j s1_j  (kind 1)
 #pragma unroll
-        for (int m = 0; m < R; ++m) racc += (a.reward_kind == MFG_REWARD_MFG_AC2) ? pcd[m] * s1[m] : s1[m];
+        for (int m = 0; m < R; ++m) racc += (a.reward_kind == MFG_REWARD_MFG_AC2) ? (double)pc[m] * s1[m] : s1[m];
         if (a.reward_kind == MFG_REWARD_MFG_AC2) racc -= s2;
       } else {
         for (int i = 0; i < d; ++i) {
@@ -885,7 +924,7 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
             if (c < d) {
               const double p = (double)y[m];
               acc[m] = fma(p, pii, acc[m]);
-              racc += pii * reward_term(a.reward_kind, pii, pcd[m], p);
+              racc += pii * reward_term(a.reward_kind, pii, (double)pc[m], p);
             }
           }
         }
@@ -912,7 +951,11 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
       if (TD) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
+#ifdef MFG_ABL_EPI
+        for (int rw = d; rw < d; rw += WAVE) {
+#else
         for (int rw = lane; rw < d; rw += WAVE) {
+#endif
           const double Dr = rowq[3 * rw + 1];
           if (SAMPLE && FAST) {
             guni = fma(digamma_pos_mixed(rowq[3 * rw]), Dr, guni);
@@ -924,7 +967,11 @@ __global__ __launch_bounds__(BLOCK) void k_core_large(CoreArgs a) {
         }
         const double gsum = wave_sum_dpp(gacc + guni);
         if (lane == 0 && a.g) a.g[b * T + s] = gsum;
+#ifdef MFG_ABL_V
+        if (false) {
+#else
         if (want_v) {
+#endif
           __builtin_amdgcn_s_waitcnt(0xc07f);
           __builtin_amdgcn_wave_barrier();
           if (!have_v) {
