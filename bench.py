@@ -193,14 +193,14 @@ def main():
             dist.all_reduce(t, op=op)
 
     def one_step(k):
-        pi0 = ops.gather_start(mat_pi0, idx)
-        ops.rollout(pi0, T, theta, shift, alpha_scale, w=w, gamma=gamma, seed=2024, first_step=k * T,
-                    traj_offset=traj_offset, td=True, G=G, ws=ws, out=bufs)
-        if multi:
-            all_reduce_(G)                                               # one RCCL all-reduce per update
         sc = 1.0 / (k + 1)
         sa = 1.0 / ((k + 1) * np.log(np.log(k + 20)))                    # mfg_ac2.py:514,522
-        ops.apply_update(G, d, lr_c * sc, lr_a * sa, w, theta)
+        # start-state gather (in-kernel) + fused rollout + batch sums; on one GPU the update rides in the same call
+        ops.train_rollout(mat_pi0, idx, T, theta, shift, alpha_scale, w, gamma, G, ws, bufs, lr_c * sc, lr_a * sa,
+                          apply=not multi, seed=2024, first_step=k * T, traj_offset=traj_offset)
+        if multi:
+            all_reduce_(G)                                               # one RCCL all-reduce per update
+            ops.apply_update(G, d, lr_c * sc, lr_a * sa, w, theta)
 
     def sync():
         torch.cuda.synchronize()

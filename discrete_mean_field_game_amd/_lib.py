@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('MFG_HIP_LIB') or os.path.join(CSRC, 'libmfg_hip.so') 
 
 MFG_MAX_D = 512
 REWARD_MFG_AC2, REWARD_SYNTHETIC, REWARD_EXTERNAL = 0, 1, 2
-ROLLOUT_WRITE_P, ROLLOUT_TD, ROLLOUT_DISCOUNT_POW, ROLLOUT_F64 = 1, 2, 4, 8
+ROLLOUT_WRITE_P, ROLLOUT_TD, ROLLOUT_DISCOUNT_POW, ROLLOUT_F64, TRAIN_APPLY = 1, 2, 4, 8, 16
 PRECISION_F64, PRECISION_MIXED = 0, 1
 PRECISIONS = {'f64': PRECISION_F64, 'mixed': PRECISION_MIXED, 0: 0, 1: 1}
 
@@ -63,6 +63,8 @@ SIGNATURES = {
     'mfg_grad_accumulate': (_i32, [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _i32, _p, _sz, _p]),
     'mfg_train_episode': (_i32, [_p, _p, _i64, _i32, _i32, _p, _f64, _f64, _p, _f64, _i32, _u64, _u32, _u64, _i32, _f64, _f64,
                                  _p, _p, _p, _p, _p, _p, _sz, _p]),
+    'mfg_train_rollout': (_i32, [_p, _i64, _p, _i64, _i32, _i32, _p, _f64, _f64, _p, _f64, _i32, _u64, _u32, _u64, _i32, _f64,
+                                 _f64, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'mfg_policy_logpdf': (_i32, [_p, _p, _i64, _i32, _p, _i32, _f64, _f64, _f64, _f64, _p, _p]),
     'mfg_backward_value': (_i32, [_p, _i64, _i32, _i32, _p, _p, _p, _p]),
     'mfg_reward_net_forward': (_i32, [_p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p,

@@ -16,7 +16,8 @@ constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / WAVE;
 
 struct CoreArgs {
-  const float* pi0;         // [B,d]
+  const float* pi0;         // [B,d]; or, with start_idx != NULL, the start-state table [num_start,d]
+  const int32_t* start_idx; // [B] rows of the table (start-state gather folded into the kernel, mfg_ac2.py:466-469)
   const float* pi_alpha;    // GIVEN: state the concentrations are computed from (NULL -> pi0)
   const float* P_in;        // GIVEN: [B,d,d]
   const float* pi_next_in;  // GIVEN: [B,d] (may be NULL when no delta is wanted)
@@ -159,33 +160,45 @@ __device__ __forceinline__ void sample_elems_g(const CoreArgs& a, double theta, 
   quad_rand(q, a.seed, elem[0], step, traj);
   // the two Box-Muller pairs one after the other (two interleaved chains each; four at once cost 36 spilled VGPRs at
   // the 128-register cap of the small-d kernel and bought nothing at full occupancy)
+#ifndef MFG_QUAD_WIDTH
+#define MFG_QUAD_WIDTH 2  // elements whose chains are interleaved: 2 (one Box-Muller pair) or 4 (the whole quad)
+#endif
+  constexpr int PW = MFG_QUAD_WIDTH;
 #pragma unroll
-  for (int h = 0; 2 * h < NE; ++h) {
-    const int n2 = (NE - 2 * h) >= 2 ? 2 : 1;
-    PolicyElem<FAST> pe[2];
+  for (int h = 0; PW * h < NE; ++h) {
+    const int n2 = (NE - PW * h) >= PW ? PW : (NE - PW * h);
+    PolicyElem<FAST> pe[PW];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < PW; ++u) {
       if (u < n2) {
-        const int e = 2 * h + u;
+        const int e = PW * h + u;
         if constexpr (SEP) policy_setup_sep<true, TD>(pe[u], a, ts, pj[e], ej[e], pai[e], Fi[e]);
         else policy_setup<true, TD, FAST>(pe[u], a, theta, ts, pj[e], pai[e]);
       }
     }
-    float xn[2], v[2];
-    bool sure[2] = {true, true};
+    float xn[PW], v[PW];
+    bool sure[PW];
+#pragma unroll
+    for (int u = 0; u < PW; u += 2) {
+      const int hp = (PW * h + u) >> 1;  // Box-Muller pair index inside the quad
+      sure[u] = true;
+      if (u + 1 < PW) sure[u + 1] = true;
 #ifdef MFG_ABL_BM
-    xn[0] = (q.radu[h] - 0.5f) * 2.0f;
-    xn[1] = (q.radu[h] - 0.5f) * q.ang[h];
+      xn[u] = (q.radu[hp] - 0.5f) * 2.0f;
+      if (u + 1 < PW) xn[u + 1] = (q.radu[hp] - 0.5f) * q.ang[hp];
 #else
-    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(q.radu[h]));
-    xn[0] = rad * __builtin_amdgcn_cosf(q.ang[h]);
-    xn[1] = rad * __builtin_amdgcn_sinf(q.ang[h]);
+      if (u < n2) {
+        const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(q.radu[hp]));
+        xn[u] = rad * __builtin_amdgcn_cosf(q.ang[hp]);
+        if (u + 1 < PW) xn[u + 1] = rad * __builtin_amdgcn_sinf(q.ang[hp]);
+      }
 #endif
+    }
     bool cold = false;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < PW; ++u) {
       if (u < n2) {
-        const int e = 2 * h + u;
+        const int e = PW * h + u;
         v[u] = gamma_try(pe[u].gs, xn[u], q.kf[e], sure[u]);
         y[e] = pe[u].gs.dd * v[u];
         cold = cold || (valid[e] && (!sure[u] || pe[u].gs.small));
@@ -193,16 +206,16 @@ __device__ __forceinline__ void sample_elems_g(const CoreArgs& a, double theta, 
     }
     if (__builtin_amdgcn_ballot_w64(cold) != 0) {  // wave-uniform, ~1 % of the pairs at the reference policies
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int e = 2 * h + u;
+      for (int u = 0; u < PW; ++u) {
+        const int e = PW * h + u;
         if (u < n2 && valid[e] && (!sure[u] || pe[u].gs.small))
           y[e] = gamma_fix(pe[u].gs, xn[u], q.kf[e], sure[u], v[u], a.seed, elem[e], step, traj);
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < PW; ++u) {
       if (u < n2) {
-        const int e = 2 * h + u;
+        const int e = PW * h + u;
         if (TD) {
           const PolicyTerms<FAST> t = policy_terms<true, FAST>(pe[u], a.htab, ts.th, y[e]);
           al[e] = valid[e] ? t.al : 0;
@@ -268,11 +281,11 @@ __device__ __forceinline__ double value_wave(const float* pis, const double* __r
 // (The batch sums sum delta phi are NOT accumulated here: doing it per step in LDS cost 0.49 ms of a 2.5 ms rollout;
 // the separate k_grad_* pass over pi_traj / delta costs ~0.05 ms.)
 // D > 0: d is a compile-time constant (constant trip counts / strides); D == 0: generic runtime d.
-// PMC: VALU ~94 % busy at 4 waves per SIMD, so the mixed-precision build is capped at 128
-// VGPRs (4 waves/SIMD, matching the 4 blocks/CU that LDS allows); below that occupancy the serial Philox /
-// transcendental chains are not covered (measured 2.9 ms vs 3.4 ms per rollout at 3 vs 2 waves/SIMD).
+// Registers: the mixed-precision training kernel needs ~165 VGPRs; capped at 128 (4 waves / SIMD) it spills ~46 of them
+// and runs 1-8 % SLOWER at every batch size than at 168 (3 waves / SIMD, no spills): round-2 measurement, d = 21,
+// B = 4096 .. 65536.  LDS (36 KB / block) would allow 4 blocks per CU.
 #ifndef MFG_CORE_SMALL_WAVES
-#define MFG_CORE_SMALL_WAVES 4  // waves per SIMD the mixed-precision kernel is register-capped for (128 VGPRs)
+#define MFG_CORE_SMALL_WAVES 3  // waves per SIMD the mixed-precision kernel is register-capped for (168 VGPRs)
 #endif
 template <bool SAMPLE, bool TD, bool FAST, int D>
 __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core_small(CoreArgs a) {
@@ -366,7 +379,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
     const int64_t b = b0 + tlc;
     double* redq = red + (size_t)tlc * 3 * d;
     float* pnv = pin + tlc * pnw;
-    float pi_i = a.pi0[b * d + i];
+    float pi_i = a.pi0[(a.start_idx ? (int64_t)a.start_idx[b] : b) * d + i];
     if (valid && a.pi_traj) a.pi_traj[b * (int64_t)(T + 1) * d + i] = pi_i;
     double v_cur = 0.0, discount = 1.0;  // meaningful on lane i == 0 only
     if (want_v && SAMPLE) {
@@ -679,7 +692,7 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
 #pragma unroll
     for (int m = 0; m < R; ++m) {
       const int c = lane + m * WAVE;
-      pc[m] = c < d ? a.pi0[b * d + c] : 0.0f;
+      pc[m] = c < d ? a.pi0[(a.start_idx ? (int64_t)a.start_idx[b] : b) * d + c] : 0.0f;
       if (c < d && a.pi_traj) a.pi_traj[b * (int64_t)(T + 1) * d + c] = pc[m];
     }
     double v_cur = 0.0, discount = 1.0;

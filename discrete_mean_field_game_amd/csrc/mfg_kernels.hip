@@ -1059,8 +1059,17 @@ __global__ __launch_bounds__(BLOCK) void k_grad_mfma(GradArgs a, int tpw) {
 // Sum nsb partial rows in a fixed order: block = 16 slices (waves) x 64 outputs (lanes, coalesced);
 // slice s adds rows s, s+16, ... ; the 16 slice sums are combined in slice order through LDS.
 constexpr int RP_SLICES = 16;
+// `ap` != NULL (single-GPU training rollout, accumulate == 0): the parameter update rides along -- the number of samples
+// is known on the host (count), so every output updates its own parameter without waiting for another block's sum:
+// k < F: w[k] += lr_c G[k] / count; k == F: theta += lr_a G[F] / count; k == F+1: *reward_acc += G[F+1] / count
+// (the arithmetic of k_apply_update).
+struct ReduceApply {
+  double lr_c, lr_a, count;
+  double *w, *theta, *reward_acc;
+  int on;
+};
 __global__ __launch_bounds__(RP_SLICES* WAVE) void k_reduce_partials(const double* __restrict__ partial, int64_t nsb, int64_t FO,
-                                                                    int accumulate, double* __restrict__ G) {
+                                                                    int accumulate, double* __restrict__ G, ReduceApply ap) {
   __shared__ double red[RP_SLICES][WAVE];
   const int lane = threadIdx.x & (WAVE - 1), sl = threadIdx.x / WAVE;
   const int64_t k = (int64_t)blockIdx.x * WAVE + lane;
@@ -1083,7 +1092,15 @@ __global__ __launch_bounds__(RP_SLICES* WAVE) void k_reduce_partials(const doubl
     double tot = 0.0;
 #pragma unroll
     for (int q = 0; q < RP_SLICES; ++q) tot += red[q][lane];
-    G[k] = accumulate ? G[k] + tot : tot;
+    const double gk = accumulate ? G[k] + tot : tot;
+    G[k] = gk;
+    if (ap.on) {
+      const int64_t F = FO - 3;
+      const double inv = 1.0 / ap.count;
+      if (k < F) ap.w[k] += ap.lr_c * (gk * inv);
+      else if (k == F) *ap.theta += ap.lr_a * (gk * inv);
+      else if (k == F + 1 && ap.reward_acc) *ap.reward_acc += gk * inv;
+    }
   }
 }
 
@@ -1135,6 +1152,18 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
   const size_t need = (size_t)(nsb * FO * 8) + MFG_WS_CONTROL_BYTES;
   if (ws_bytes < need) return fail(MFG_EWORKSPACE, "%s: need %lld bytes, have %lld", "workspace", (long long)need,
                                    (long long)ws_bytes);
+  // the parameter update, when asked for, rides in the kernel that finishes the sums (fixed-order; needs accumulate == 0
+  // so that the sample count is the host-known N)
+  ReduceApply rap{};
+  if (apply && !accumulate) {
+    rap.on = 1;
+    rap.lr_c = apply->lr_c;
+    rap.lr_a = apply->lr_a;
+    rap.count = (double)N;
+    rap.w = apply->w;
+    rap.theta = apply->theta;
+    rap.reward_acc = apply->reward_acc;
+  }
   GradArgs a{};
   a.pi = pi;
   a.stride_b = stride_b;
@@ -1185,7 +1214,8 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
     else hipLaunchKernelGGL((k_grad_small<15>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
     if (fuse) return check_launch("grad_small");
     hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
-                       (const double*)a.partial, blocks, FO, accumulate, G);
+                       (const double*)a.partial, blocks, FO, accumulate, G, rap);
+    if (applied && rap.on) *applied = true;
     return check_launch("grad_small");
   }
   if (d % 16 == 0 && d >= 64 && d <= 4 * BLOCK) {
@@ -1196,13 +1226,15 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
     const size_t lds_m = (size_t)GM_KC * 8 + (size_t)4 * BLOCK * 8 + (size_t)GM_KC * (d + 16) * 4;
     hipLaunchKernelGGL(k_grad_mfma, dim3((unsigned)nsb, (unsigned)ny), dim3(BLOCK), lds_m, st, a, tpw);
     hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
-                       (const double*)a.partial, nsb, FO, accumulate, G);
+                       (const double*)a.partial, nsb, FO, accumulate, G, rap);
+    if (applied && rap.on) *applied = true;
     return check_launch("grad_mfma");
   }
   const size_t lds = (size_t)chunk * 3 * 8 + (size_t)chunk * d * 4;
   hipLaunchKernelGGL(k_grad_partial, dim3((unsigned)nsb, (unsigned)nob), dim3(BLOCK), lds, st, a);
   hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
-                     (const double*)a.partial, nsb, FO, accumulate, G);
+                     (const double*)a.partial, nsb, FO, accumulate, G, rap);
+  if (applied && rap.on) *applied = true;
   return check_launch("grad_reduce");
 }
 
@@ -1262,7 +1294,7 @@ static int launch_core(const CoreArgs& a_in, bool sample, bool td, int precision
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 8; }
+int mfg_abi_version(void) { return 9; }
 
 int mfg_init(void) {
   if (!htab_ptr()) return fail(MFG_ELAUNCH, "%s", "mfg_init: no HIP device / table initialisation failed");
@@ -1599,6 +1631,54 @@ int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, 
   REQUIRE(workspace, "workspace is null");
   return launch_grad(pi_traj, (int64_t)(T + 1) * d, delta, g, reward, B * T, T, d, G, accumulate, workspace,
                      workspace_bytes, S(stream));
+}
+
+int mfg_train_rollout(const float* mat_pi0, int64_t num_start, const int32_t* idx, int64_t B, int d, int T, double* theta,
+                      double shift, double alpha_scale, double* w, double gamma, int reward_kind, uint64_t seed,
+                      uint32_t first_step, uint64_t traj_offset, int flags, double lr_critic, double lr_actor,
+                      float* pi_traj, float* pi_last, float* reward, double* delta, double* g, double* G,
+                      double* reward_acc, void* workspace, size_t workspace_bytes, mfg_stream_t stream) {
+  CHECK_BD();
+  REQUIRE(T >= 1, "T < 1");
+  REQUIRE(mat_pi0 && idx && num_start > 0, "null start-state table / index");
+  REQUIRE(theta && w && pi_traj && reward && delta && g && G && workspace, "null pointer");
+  REQUIRE(reward_kind == MFG_REWARD_MFG_AC2 || reward_kind == MFG_REWARD_SYNTHETIC, "needs an in-kernel reward");
+  CoreArgs a{};
+  a.pi0 = mat_pi0;
+  a.start_idx = idx;
+  a.theta = theta;
+  a.w = w;
+  a.shift = shift;
+  a.alpha_scale = alpha_scale;
+  a.gamma = gamma;
+  a.B = B;
+  a.d = d;
+  a.T = T;
+  a.reward_kind = reward_kind;
+  a.discount_pow = (flags & MFG_ROLLOUT_DISCOUNT_POW) ? 1 : 0;
+  a.seed = seed;
+  a.first_step = first_step;
+  a.traj_offset = traj_offset;
+  a.pi_traj = pi_traj;
+  a.pi_next_out = pi_last;
+  a.reward_out = reward;
+  a.delta = delta;
+  a.g = g;
+  const int precision = (flags & MFG_ROLLOUT_F64) ? MFG_PRECISION_F64 : MFG_PRECISION_MIXED;
+  int rc = launch_core(a, true, true, precision, S(stream));
+  if (rc != MFG_OK) return rc;
+  const ApplyArgs ap{lr_critic, lr_actor, w, theta, reward_acc};
+  const bool want_apply = (flags & MFG_TRAIN_APPLY) != 0;
+  bool applied = false;
+  rc = launch_grad(pi_traj, (int64_t)(T + 1) * d, delta, g, reward, B * T, T, d, G, 0, workspace, workspace_bytes, S(stream),
+                   want_apply ? &ap : nullptr, &applied);
+  if (rc != MFG_OK) return rc;
+  if (want_apply && !applied) {
+    const int64_t F = mfg_num_features(d);
+    hipLaunchKernelGGL(k_apply_update, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, S(stream), G, F, lr_critic, lr_actor,
+                       w, theta, reward_acc);
+  }
+  return check_launch("train_rollout");
 }
 
 int mfg_grad_accumulate(const float* pi, int64_t stride_b, double* delta, const double* g, const float* reward, int64_t B,

@@ -356,11 +356,19 @@ class actor_critic:
         native_episode = (self.update_every == 'step' and self.rng == 'philox' and shard.world == 1
                           and self.trace is None and not write_all)
         ebufs = ops.episode_buffers(Bl, d, self.device) if native_episode else None
+        fused_rollout = self.update_every == 'rollout' and self.rng == 'philox'
+        if fused_rollout:
+            rbufs = {'pi_traj': torch.empty(Bl, T + 1, d, dtype=torch.float32, device=self.device),
+                     'pi_last': torch.empty(Bl, d, dtype=torch.float32, device=self.device),
+                     'reward': torch.empty(Bl, T, dtype=torch.float32, device=self.device),
+                     'delta': torch.empty(Bl, T, dtype=torch.float64, device=self.device),
+                     'g': torch.empty(Bl, T, dtype=torch.float64, device=self.device)}
         for episode in range(num_episodes):
             if write_all:
                 with open('temp.csv', 'a') as f:
                     f.write('Episode %d \n\n' % episode)
-            pi = ops.gather_start(self._mat_pi0_dev, self._draw_start(shard))
+            idx = self._draw_start(shard)
+            pi = None if fused_rollout else ops.gather_start(self._mat_pi0_dev, idx)
             sc, sa = lr_scales(episode + first_episode, constant == 1)
             if native_episode:
                 ops.train_episode(pi, T, self._theta, self.shift, self.alpha_scale, self._w, gamma, lr_critic * sc,
@@ -369,14 +377,19 @@ class actor_critic:
                                   reward_acc=ep_reward[episode:episode + 1], precision=self.precision)
                 self._rng_step += T
                 self._theta_is_array = True
-            elif self.update_every == 'rollout' and self.rng == 'philox':
-                out = ops.rollout(pi, T, self._theta, self.shift, self.alpha_scale, w=self._w, gamma=gamma,
-                                  reward_kind=self.reward_kind, seed=self.seed, first_step=self._rng_step,
-                                  traj_offset=shard.traj_offset, td=True, G=G, ws=ws, precision=self.precision)
+            elif fused_rollout:
+                # start-state gather + fused T-step rollout + batch sums (+ the update itself on one GPU): 2-3 launches
+                single = shard.world == 1
+                ops.train_rollout(self._mat_pi0_dev, idx, T, self._theta, self.shift, self.alpha_scale, self._w, gamma, G,
+                                  ws, rbufs, lr_critic * sc, lr_actor * sa, apply=single, reward_kind=self.reward_kind,
+                                  seed=self.seed, first_step=self._rng_step, traj_offset=shard.traj_offset,
+                                  reward_acc=ep_reward[episode:episode + 1], precision=self.precision)
                 self._rng_step += T
-                all_reduce_gradients_(G, self.group)
-                ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta, ep_reward[episode:episode + 1])
-                pi = out['pi_last']
+                if not single:
+                    all_reduce_gradients_(G, self.group)
+                    ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta,
+                                     ep_reward[episode:episode + 1])
+                pi = rbufs['pi_last']
                 self._theta_is_array = True
                 if self.trace is not None:
                     self.trace.append(float(self._theta.cpu()[0]))

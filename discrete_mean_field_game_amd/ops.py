@@ -207,6 +207,29 @@ def rollout(pi0, T, theta, shift, alpha_scale, w=None, gamma=1.0, reward_kind=L.
     return {'pi_traj': pi_traj, 'pi_last': pi_last, 'reward': reward, 'delta': delta, 'g': g, 'P': P, 'G': G}
 
 
+def train_rollout(mat_pi0, idx, T, theta, shift, alpha_scale, w, gamma, G, ws, bufs, lr_critic=0.0, lr_actor=0.0,
+                  apply=False, reward_kind=L.REWARD_MFG_AC2, seed=0, first_step=0, traj_offset=0, discount_pow=False,
+                  reward_acc=None, precision='mixed'):
+    """One training update per episode: start-state gather (inside the kernel) + fused T-step TD rollout + batch sums
+    [+ parameter update when apply=True (single GPU)].  bufs = dict(pi_traj [B,T+1,d], pi_last [B,d] | None,
+    reward [B,T], delta [B,T], g [B,T])."""
+    _chk_f32(mat_pi0, 'mat_pi0'); _chk_f64(theta, 'theta'); _chk_f64(w, 'w'); _chk_f64(G, 'G')
+    if idx.dtype != torch.int32 or not idx.is_cuda:
+        raise ValueError('idx must be an int32 CUDA tensor')
+    B, d = idx.numel(), mat_pi0.shape[1]
+    flags = (L.TRAIN_APPLY if apply else 0) | (L.ROLLOUT_DISCOUNT_POW if discount_pow else 0)
+    if L.PRECISIONS[precision] == L.PRECISION_F64:
+        flags |= L.ROLLOUT_F64
+    L.check(L.lib().mfg_train_rollout(mat_pi0.data_ptr(), mat_pi0.shape[0], idx.data_ptr(), B, d, int(T), theta.data_ptr(),
+                                      float(shift), float(alpha_scale), w.data_ptr(), float(gamma), int(reward_kind),
+                                      int(seed), int(first_step), int(traj_offset), flags, float(lr_critic),
+                                      float(lr_actor), bufs['pi_traj'].data_ptr(), _ptr(bufs.get('pi_last')),
+                                      bufs['reward'].data_ptr(), bufs['delta'].data_ptr(), bufs['g'].data_ptr(),
+                                      G.data_ptr(), _ptr(reward_acc), ws.data_ptr(), ws.numel() * 8, _stream()),
+            'mfg_train_rollout')
+    return bufs
+
+
 def grad_accumulate(pi, delta, g, reward, G, ws, T=1, stride_b=None, add_reward=False, accumulate=False):
     """Batch sums G (+)= [sum delta phi | sum delta g | sum r | N] over B*T samples; add_reward: delta += reward first
     (in place) -- the IRL step after the reward network has run."""

@@ -159,6 +159,20 @@ int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, 
                 float* reward, double* delta, double* g, float* P_out, double* G, int accumulate,
                 void* workspace, size_t workspace_bytes, mfg_stream_t stream);
 
+/* a9, one training update per episode (update_every = 'rollout'): start-state gather (mfg_ac2.py:466-469: row idx[b] of
+ * the table mat_pi0[num_start,d], read inside the rollout kernel -- no separate gather launch), the fused T-step TD
+ * rollout, the batch sums over all B*T transitions.  flags: MFG_ROLLOUT_F64 / MFG_ROLLOUT_DISCOUNT_POW as for
+ * mfg_rollout, plus MFG_TRAIN_APPLY: also apply w += lr_critic G_w/N, theta += lr_actor G_theta/N and add the mean
+ * reward to *reward_acc (if not NULL) inside the launch that finishes the sums -- a single-GPU update is then 2-3
+ * launches.  Without MFG_TRAIN_APPLY G is complete on return: multi-GPU jobs all-reduce it and call mfg_apply_update.
+ * Outputs as for mfg_rollout (pi_traj, reward, delta, g are required; pi_last may be NULL). */
+#define MFG_TRAIN_APPLY 16
+int mfg_train_rollout(const float* mat_pi0, int64_t num_start, const int32_t* idx, int64_t B, int d, int T, double* theta,
+                      double shift, double alpha_scale, double* w, double gamma, int reward_kind, uint64_t seed,
+                      uint32_t first_step, uint64_t traj_offset, int flags, double lr_critic, double lr_actor,
+                      float* pi_traj, float* pi_last, float* reward, double* delta, double* g, double* G,
+                      double* reward_acc, void* workspace, size_t workspace_bytes, mfg_stream_t stream);
+
 /* f1 (IRL): reward[b] = r_net(state_b, action_b), the reward network of networks.py:46-81 evaluated for B
  * transitions in one launch (ac_irl.py:683 evaluates it with batch 1 per env step).  fp32.  Weight layouts are
  * PyTorch's: conv1_w [k1*k1], conv2_w [f2][k2*k2], fc3_w [n3][d*d*f2] with the input index (pixel*f2 + channel)
