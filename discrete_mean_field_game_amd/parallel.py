@@ -47,7 +47,14 @@ def all_reduce_gradients_(G: torch.Tensor, group=None) -> torch.Tensor:
     """In-place SUM of the fused gradient buffer over all ranks (no-op for a single process).
     The count entry G[F+2] is summed too, so dividing by it afterwards gives the global batch mean."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)
+        if G.is_cuda and dist.get_backend(group) != 'nccl':
+            # gloo (CPU tests, several ranks sharing one GPU): no device collectives on this build, stage the 2 KB
+            # buffer through the host; production runs use RCCL ("nccl") on the device tensor directly
+            h = G.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            G.copy_(h)
+        else:
+            dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)
     return G
 
 

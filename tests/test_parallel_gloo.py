@@ -59,7 +59,10 @@ def _worker(rank, world, port, B, d, q):
         sc, sa = parallel.lr_scales(3, False)
         w_new = w + 0.1 * sc * G[:F].numpy() / float(G[F + 2])
         theta_new = theta + 0.001 * sa * float(G[F]) / float(G[F + 2])
-        q.put((rank, G.numpy().copy(), w_new, theta_new))
+        # start-state indices: every rank draws from a DIFFERENT host stream; rank 0's vector wins and is sharded
+        np.random.seed(1000 + rank)
+        idx = parallel.broadcast_start_indices(np.random.randint(64, size=B))
+        q.put((rank, G.numpy().copy(), w_new, theta_new, idx[sl].copy()))
     finally:
         dist.destroy_process_group()
 
@@ -82,9 +85,11 @@ def test_two_rank_gradient_allreduce_equals_single_process():
     pn = O.transition(P, pi); r = O.calc_reward(P, pi)
     delta, g, G_w, G_theta, rsum = O.batched_td_pg(pi, pn, P, r, w, 8.86349, 0.16, 0.9)
     ref = np.concatenate([G_w, [G_theta, rsum, float(B)]])
-    for rank, Gr, w_new, theta_new in res:
+    for rank, Gr, w_new, theta_new, idx_shard in res:
         assert np.allclose(Gr, ref, rtol=1e-12, atol=1e-15)
         assert Gr[-1] == B
+    np.random.seed(1000)                                         # rank 0's draw, tiled exactly by the two shards
+    assert np.array_equal(np.concatenate([res[0][4], res[1][4]]), np.random.randint(64, size=B))
     # replicated update: both ranks end with bit-identical parameters, no broadcast needed
     assert np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
 
@@ -94,3 +99,5 @@ def test_all_reduce_is_noop_without_process_group():
     assert torch.equal(parallel.all_reduce_gradients_(G.clone()), G)
     s = parallel.current_shard(10)
     assert (s.rank, s.world, s.local_batch, s.traj_offset) == (0, 1, 10, 0)
+    idx = np.arange(5)
+    assert parallel.broadcast_start_indices(idx) is idx
