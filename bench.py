@@ -10,8 +10,10 @@ update_every='rollout') over the rank's trajectory batch, with everything reside
     start-state gather -> fused T-step rollout kernel (Dirichlet action sampling, pi' = P^T pi,
     reward, value, TD error, score) -> batch gradient sums -> [one RCCL all-reduce of the fused
     gradient buffer when N > 1] -> (theta, w) update on device.
-value = (ranks * B * T * K) / max-over-ranks wall time between barriers.  Weak scaling: the per-GPU
-batch is fixed (default 65536, the north-star target point d=21, T=15).
+value = (ranks * B * T * K) / max-over-ranks wall time between barriers.  STRONG scaling by default: the global
+batch (65536, the north-star target point d=21, T=15) is split over the N GPUs; for N > 1 the same line also carries
+the weak-scaling leg (65536 per GPU, `other_scaling`) and BASELINE config 5 (d=256, T=40, 131072 split N ways,
+`c5_strong`); for N == 1 a bounded `configs` array covers C2 / C3 / C4 / the C5 share / the f64 headline.
 
 The same JSON line carries
   roofline     : the HBM-bound given-P kernel (transition + reward over materialised actions; the fused
@@ -40,8 +42,10 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--d', type=int, default=21)
     ap.add_argument('--T', type=int, default=15)
-    ap.add_argument('--batch', type=int, default=65536, help='trajectories per GPU')
-    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--batch', type=int, default=65536,
+                    help='GLOBAL batch, split over the GPUs (strong scaling, default); per-GPU batch with --scaling weak')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='strong')
+    ap.add_argument('--no-configs', action='store_true', help='skip the other BASELINE.json configurations (N == 1)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0, help='budget of the CPU baseline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -163,26 +167,8 @@ def main():
         else:
             dist.init_process_group('gloo', rank=rank, world_size=world)
 
-    d, T = args.d, args.T
-    B = args.batch if args.scaling == 'weak' else args.batch // world
-    F = ops.num_features(d)
     theta0, shift, alpha_scale, gamma = 8.86349, 0.16, 12000.0, 1.0      # mfg_ac2.py:832
     lr_c, lr_a = 0.1, 0.001                                              # mfg_ac2.py:448
-
-    # synthetic workload: 64 Dirichlet(1) start states rounded through '%.3e' text
-    rs = np.random.RandomState(0)
-    mat = rs.dirichlet(np.ones(d), size=64)
-    mat = np.array([[float('%.3e' % v) for v in row] for row in mat], dtype=np.float32)
-    mat_pi0 = torch.as_tensor(mat, device=dev)
-    idx = torch.as_tensor(np.random.RandomState(1234 + rank).randint(64, size=B).astype(np.int32), device=dev)
-    w = torch.as_tensor(np.random.RandomState(1).rand(F), device=dev)    # U[0,1)^F, mfg_ac2.py:176
-    theta = torch.tensor([theta0], dtype=torch.float64, device=dev)
-    G = torch.zeros(F + 3, dtype=torch.float64, device=dev)
-    ws = ops.workspace(B * T, d, dev)
-    bufs = {'pi_traj': torch.empty(B, T + 1, d, device=dev), 'reward': torch.empty(B, T, device=dev),
-            'delta': torch.empty(B, T, dtype=torch.float64, device=dev),
-            'g': torch.empty(B, T, dtype=torch.float64, device=dev)}
-    traj_offset = rank * B
 
     def all_reduce_(t, op=dist.ReduceOp.SUM):
         if args.backend == 'gloo':                                       # debug path: stage through the host
@@ -192,38 +178,62 @@ def main():
         else:
             dist.all_reduce(t, op=op)
 
-    def one_step(k):
-        sc = 1.0 / (k + 1)
-        sa = 1.0 / ((k + 1) * np.log(np.log(k + 20)))                    # mfg_ac2.py:514,522
-        # start-state gather (in-kernel) + fused rollout + batch sums; on one GPU the update rides in the same call
-        ops.train_rollout(mat_pi0, idx, T, theta, shift, alpha_scale, w, gamma, G, ws, bufs, lr_c * sc, lr_a * sa,
-                          apply=not multi, seed=2024, first_step=k * T, traj_offset=traj_offset)
-        if multi:
-            all_reduce_(G)                                               # one RCCL all-reduce per update
-            ops.apply_update(G, d, lr_c * sc, lr_a * sa, w, theta)
-
     def sync():
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        one_step(k)
-    sync()
-    t0 = time.perf_counter()
-    for k in range(args.warmup, args.warmup + args.steps):
-        one_step(k)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if multi:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        all_reduce_(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te[0])
-    theta_end = float(theta[0])
-    if not np.isfinite(theta_end):
-        sys.exit('non-finite theta after the timed region')
-    value = world * B * T * args.steps / elapsed
+    def start_table(d):
+        # synthetic workload: 64 Dirichlet(1) start states rounded through '%.3e' text
+        rs = np.random.RandomState(0)
+        mat = rs.dirichlet(np.ones(d), size=64)
+        mat = np.array([[float('%.3e' % v) for v in row] for row in mat], dtype=np.float32)
+        return torch.as_tensor(mat, device=dev)
+
+    def training_leg(d, T, B, steps, warmup, precision='mixed'):
+        """`steps` timed training rollouts (mfg_ac2.train semantics, one update per rollout) of this rank's B
+        trajectories: start-state gather + fused T-step rollout + batch sums [+ ONE all-reduce when N > 1] + update.
+        Returns (max-over-ranks seconds, theta at the end, the device buffers for reuse)."""
+        F = ops.num_features(d)
+        mat_pi0 = start_table(d)
+        idx = torch.as_tensor(np.random.RandomState(1234 + rank).randint(64, size=B).astype(np.int32), device=dev)
+        w = torch.as_tensor(np.random.RandomState(1).rand(F), device=dev)    # U[0,1)^F, mfg_ac2.py:176
+        theta = torch.tensor([theta0], dtype=torch.float64, device=dev)
+        G = torch.zeros(F + 3, dtype=torch.float64, device=dev)
+        ws = ops.workspace(B * T, d, dev)
+        bufs = {'pi_traj': torch.empty(B, T + 1, d, device=dev), 'reward': torch.empty(B, T, device=dev),
+                'delta': torch.empty(B, T, dtype=torch.float64, device=dev),
+                'g': torch.empty(B, T, dtype=torch.float64, device=dev)}
+        traj_offset = rank * B
+
+        def one_step(k):
+            sc = 1.0 / (k + 1)
+            sa = 1.0 / ((k + 1) * np.log(np.log(k + 20)))                # mfg_ac2.py:514,522
+            # start-state gather (in-kernel) + fused rollout + batch sums; on one GPU the update rides in the same call
+            ops.train_rollout(mat_pi0, idx, T, theta, shift, alpha_scale, w, gamma, G, ws, bufs, lr_c * sc, lr_a * sa,
+                              apply=not multi, seed=2024, first_step=k * T, traj_offset=traj_offset, precision=precision)
+            if multi:
+                all_reduce_(G)                                           # one RCCL all-reduce per update
+                ops.apply_update(G, d, lr_c * sc, lr_a * sa, w, theta)
+
+        for k in range(warmup):
+            one_step(k)
+        sync()
+        t0 = time.perf_counter()
+        for k in range(warmup, warmup + steps):
+            one_step(k)
+        sync()
+        elapsed = time.perf_counter() - t0
+        if multi:
+            te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            all_reduce_(te, op=dist.ReduceOp.MAX)
+            elapsed = float(te[0])
+        theta_end = float(theta[0])
+        if not np.isfinite(theta_end):
+            sys.exit('non-finite theta after the timed region')
+        return elapsed, theta_end, dict(mat_pi0=mat_pi0, idx=idx, w=w, theta=theta, G=G, ws=ws, bufs=bufs,
+                                        traj_offset=traj_offset)
 
     def event_time(fn, n, warm=2):
         for _ in range(warm):
@@ -237,31 +247,60 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / n
 
+    def given_p_leg(d, B, T_mat, st, n_launch=40, warm=20):
+        """HBM-bound given-P kernel (transition + reward) over the materialised actions of T_mat steps of B
+        trajectories; live event timing on the launch stream."""
+        pi0 = ops.gather_start(st['mat_pi0'], st['idx'][:B].contiguous())
+        r = ops.rollout(pi0, T_mat, st['theta'], shift, alpha_scale, seed=7, traj_offset=st['traj_offset'], td=False,
+                        write_P=True)
+        N = B * T_mat
+        P_all = r['P'].view(N, d, d)
+        pi_all = r['pi_traj'][:, :T_mat].contiguous().view(N, d)
+        t_step = event_time(lambda: ops.step_given_P(pi_all, P_all), n=n_launch, warm=warm)
+        bps = 4 * (d * d + 2 * d + 1)
+        return {'transitions': N, 'slab_GB': N * d * d * 4 / 1e9, 'avg_launch_us': t_step * 1e6,
+                'achieved_GBs': N * bps / t_step / 1e9, 'frac': N * bps / t_step / 1e9 / HBM_PEAK_GBS,
+                'env_steps_per_s': N / t_step}
+
+    d, T = args.d, args.T
+    # ---- headline leg.  strong scaling (default): the GLOBAL batch --batch is split over the ranks; weak: --batch per GPU
+    B = args.batch // world if args.scaling == 'strong' else args.batch
+    elapsed, theta_end, st = training_leg(d, T, B, args.steps, args.warmup)
+    value = world * B * T * args.steps / elapsed
+    other = None
+    c5 = None
+    if world > 1:
+        # the other scaling mode, same run (not the headline value)
+        Bo = args.batch if args.scaling == 'strong' else args.batch // world
+        del st
+        eo, _, st = training_leg(d, T, Bo, args.steps, args.warmup)
+        other = {'scaling': 'weak' if args.scaling == 'strong' else 'strong', 'batch_per_gpu': Bo,
+                 'value': world * Bo * T * args.steps / eo, 'ms_per_step': eo / args.steps * 1e3, 'unit': 'env-steps/s'}
+        del st
+        # BASELINE config 5: d=256, T=40, global batch 131072 sharded over the ranks
+        B5 = 131072 // world
+        e5, _, st5 = training_leg(256, 40, B5, 2, 1)
+        c5 = {'workload': 'C5 d=256 T=40 global batch 131072 split over %d GPUs' % world, 'batch_per_gpu': B5,
+              'value': world * B5 * 40 * 2 / e5, 'ms_per_step': e5 / 2 * 1e3, 'unit': 'env-steps/s', 'steps': 2}
+        del st5
+        st = None
+
     out = None
     if rank == 0:
         bytes_per_step = 4 * (d * d + 2 * d + 1)                         # SURVEY.md 8d / BASELINE.md 3
-        pi0 = ops.gather_start(mat_pi0, idx)
         roofline = None
         fused = None
-        if not args.no_roofline:
+        configs = None
+        if not args.no_roofline and world == 1:
             # materialise the actions of one rollout (B*T transitions, > L3 at the default size)
-            N = B * T
-            r = ops.rollout(pi0, T, theta, shift, alpha_scale, seed=7, traj_offset=traj_offset, td=False, write_P=True)
-            P_all = r['P'].view(N, d, d)
-            pi_all = r['pi_traj'][:, :T].contiguous().view(N, d)
-            # 20 untimed launches first: the kernel's first ~20 launches on a fresh slab run up to 1.5x slower (clock /
-            # TLB ramp: 484 -> 337 -> 327 us per launch over the first three batches of 20)
-            n_launch = 40
-            t_step = event_time(lambda: ops.step_given_P(pi_all, P_all), n=n_launch, warm=20)
-            achieved = N * bytes_per_step / t_step / 1e9
+            gp = given_p_leg(d, B, T, st)
             traffic, traffic_src = pmc_traffic('k_step_', d, T, B)
-            roofline = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                        'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+            roofline = {'bound': 'hbm', 'achieved': gp['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': gp['frac'], 'traffic': traffic, 'traffic_source': traffic_src,
                         'kernel': 'k_step_small' if d <= 64 else ('k_step_rows' if d in (128, 256) else 'k_step_large'),
-                        'leg': 'given-P transition+reward over %d transitions (P slab %.2f GB)' % (N, N * d * d * 4 / 1e9),
-                        'algorithmic_bytes_per_launch': N * bytes_per_step, 'avg_launch_us': t_step * 1e6,
-                        'env_steps_per_s': N / t_step}
-            del P_all, pi_all, r
+                        'leg': 'given-P transition+reward over %d transitions (P slab %.2f GB)' % (gp['transitions'], gp['slab_GB']),
+                        'algorithmic_bytes_per_launch': gp['transitions'] * bytes_per_step,
+                        'avg_launch_us': gp['avg_launch_us'], 'env_steps_per_s': gp['env_steps_per_s']}
             # this box's own streaming ceilings (stock torch kernels on a 1.6 GB buffer), for context
             xx = torch.empty(400_000_000, device=dev).uniform_()
             yy = torch.empty_like(xx)
@@ -270,12 +309,17 @@ def main():
             roofline['box_ceiling_GBs'] = {'torch_sum_read': xx.numel() * 4 / t_rd / 1e9,
                                            'torch_copy_read_plus_write': 2 * xx.numel() * 4 / t_cp / 1e9}
             del xx, yy
-            t_f = event_time(lambda: ops.rollout(pi0, T, theta, shift, alpha_scale, w=w, gamma=gamma, seed=7,
-                                                 traj_offset=traj_offset, td=True, G=G, ws=ws, out=bufs), n=10, warm=3)
+            pi0 = ops.gather_start(st['mat_pi0'], st['idx'])
+            t_f = event_time(lambda: ops.rollout(pi0, T, st['theta'], shift, alpha_scale, w=st['w'], gamma=gamma, seed=7,
+                                                 traj_offset=st['traj_offset'], td=True, G=st['G'], ws=st['ws'],
+                                                 out=st['bufs']), n=10, warm=3)
             fused = {'kernel': ('k_core_small' if d <= 64 else 'k_core_large') + '<SAMPLE,TD,MIXED> + k_grad + k_reduce_partials',
                      'bound': 'valu/transcendental+rng (P stays on chip)', 'avg_launch_ms': t_f * 1e3,
                      'env_steps_per_s': B * T / t_f, 'hbm_algorithmic_GBs': B * T * bytes_per_step / t_f / 1e9}
             fused.update(pmc_sq('k_core_', d, T, B))
+            del st, pi0
+            if not args.no_configs:
+                configs = other_configs(training_leg, given_p_leg, d, T, B, args)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(d, args.cpu_seconds)
@@ -285,17 +329,76 @@ def main():
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32 (f64 accumulate)',
             'data': 'synthetic',
             'config': {'workload': 'forward-RL actor-critic training rollouts (mfg_ac2.train, update per rollout): '
-                                   'd=%d topics, T=%d, batch=%d trajectories per GPU' % (d, T, B),
+                                   'd=%d topics, T=%d, global batch %d = %d trajectories per GPU x %d'
+                                   % (d, T, B * world, B, world),
                        'd': d, 'T': T, 'batch_per_gpu': B, 'global_batch': B * world,
                        'theta0': theta0, 'shift': shift, 'alpha_scale': alpha_scale, 'rng': 'philox4x32-10',
                        'parallelism': 'trajectory-sharded x%d, 1 all-reduce/update' % world},
             'theta_end': theta_end,
             'roofline': roofline, 'fused_kernel': fused, 'cpu_baseline': cpu,
         }
+        if other is not None:
+            out['other_scaling'] = other
+        if c5 is not None:
+            out['c5_strong'] = c5
+        if configs is not None:
+            out['configs'] = configs
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def other_configs(training_leg, given_p_leg, d0, T0, B0, args):
+    """BASELINE.json's other configurations on this GPU, bounded (a few seconds each): fused training rollout time and
+    the given-P kernel's HBM rate per shape, AC_IRL.train (config 4) through the drop-in class, and the headline shape
+    in strict f64 precision."""
+    import time as _t
+    import numpy as np
+    import torch
+    out = []
+    for name, d, T, B, steps in (('C2', 21, 15, 4096, 20), ('C3', 128, 40, 16384, 3), ('C5 (1/8 share)', 256, 40, 16384, 2)):
+        try:
+            e, _, st = training_leg(d, T, B, steps, 1)
+            gp = given_p_leg(d, B, T if d <= 64 else 1, st, n_launch=20, warm=10)
+            bps = 4 * (d * d + 2 * d + 1)
+            out.append({'config': name, 'd': d, 'T': T, 'batch': B, 'steps': steps, 'fused_ms_per_rollout': e / steps * 1e3,
+                        'fused_env_steps_per_s': B * T * steps / e,
+                        'fused_frac_of_hbm_line': B * T * steps / e * bps / 1e9 / HBM_PEAK_GBS,
+                        'given_P_GBs': gp['achieved_GBs'], 'given_P_frac': gp['frac'], 'given_P_slab_GB': gp['slab_GB'],
+                        'given_P_avg_launch_us': gp['avg_launch_us']})
+            del st
+        except Exception as exc:  # informational: never fail the headline on it
+            out.append({'config': name, 'error': repr(exc)})
+    # headline shape, strict f64 policy math
+    try:
+        e, _, st = training_leg(d0, T0, B0, 5, 1, precision='f64')
+        out.append({'config': 'headline shape, precision f64', 'd': d0, 'T': T0, 'batch': B0, 'steps': 5,
+                    'fused_ms_per_rollout': e / 5 * 1e3, 'fused_env_steps_per_s': B0 * T0 * 5 / e})
+        del st
+    except Exception as exc:
+        out.append({'config': 'headline f64', 'error': repr(exc)})
+    # C4: max-ent IRL forward solve with the HIP reward network in the loop (ac_irl.py:634-732), d=21, B=4096
+    try:
+        from discrete_mean_field_game_amd.ac_irl import AC_IRL
+        rs = np.random.RandomState(0)
+        mat = rs.dirichlet(np.ones(21), size=64)
+        for mode, episodes in (('step', 30), ('rollout', 60)):
+            np.random.seed(5); torch.manual_seed(5)
+            ac = AC_IRL(theta=8.64, shift=0.0, alpha_scale=1e4, d=21, pi0=mat, demonstrations=[], batch=4096, seed=3,
+                        update_every=mode, verbose=0)
+            ac.train(max_episodes=3, stop_criteria=-1)
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            ac.train(max_episodes=episodes, stop_criteria=-1)
+            torch.cuda.synchronize()
+            dt = _t.perf_counter() - t0
+            out.append({'config': 'C4 AC_IRL.train (reward net in the loop), update per %s' % mode, 'd': 21, 'T': 15,
+                        'batch': 4096, 'episodes': episodes, 'env_steps_per_s': 4096 * 15 * episodes / dt,
+                        'ms_per_episode': dt / episodes * 1e3})
+    except Exception as exc:
+        out.append({'config': 'C4', 'error': repr(exc)})
+    return out
 
 
 if __name__ == '__main__':
