@@ -247,12 +247,14 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / n
 
-    def given_p_leg(d, B, T_mat, st, n_launch=40, warm=20):
+    def given_p_leg(d, B, T_mat, n_launch=40, warm=20):
         """HBM-bound given-P kernel (transition + reward) over the materialised actions of T_mat steps of B
         trajectories; live event timing on the launch stream."""
-        pi0 = ops.gather_start(st['mat_pi0'], st['idx'][:B].contiguous())
-        r = ops.rollout(pi0, T_mat, st['theta'], shift, alpha_scale, seed=7, traj_offset=st['traj_offset'], td=False,
-                        write_P=True)
+        mat_pi0 = start_table(d)
+        idx = torch.as_tensor(np.random.RandomState(99).randint(64, size=B).astype(np.int32), device=dev)
+        pi0 = ops.gather_start(mat_pi0, idx)
+        theta = torch.tensor([theta0], dtype=torch.float64, device=dev)
+        r = ops.rollout(pi0, T_mat, theta, shift, alpha_scale, seed=7, td=False, write_P=True)
         N = B * T_mat
         P_all = r['P'].view(N, d, d)
         pi_all = r['pi_traj'][:, :T_mat].contiguous().view(N, d)
@@ -291,10 +293,13 @@ def main():
         roofline = None
         fused = None
         configs = None
-        if not args.no_roofline and world == 1:
-            # materialise the actions of one rollout (B*T transitions, > L3 at the default size)
-            gp = given_p_leg(d, B, T, st)
-            traffic, traffic_src = pmc_traffic('k_step_', d, T, B)
+        if not args.no_roofline:
+            # the HBM-bound kernel of the path on THIS GPU: materialised actions of one rollout of the global batch
+            # (B*T transitions, a 1.7 GB slab > L3 at the default size), the same leg at every N
+            st = None
+            Br = args.batch if args.scaling == 'strong' else B
+            gp = given_p_leg(d, Br, T)
+            traffic, traffic_src = pmc_traffic('k_step_', d, T, Br)
             roofline = {'bound': 'hbm', 'achieved': gp['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': gp['frac'], 'traffic': traffic, 'traffic_source': traffic_src,
                         'kernel': 'k_step_small' if d <= 64 else ('k_step_rows' if d in (128, 256) else 'k_step_large'),
@@ -309,16 +314,18 @@ def main():
             roofline['box_ceiling_GBs'] = {'torch_sum_read': xx.numel() * 4 / t_rd / 1e9,
                                            'torch_copy_read_plus_write': 2 * xx.numel() * 4 / t_cp / 1e9}
             del xx, yy
-            pi0 = ops.gather_start(st['mat_pi0'], st['idx'])
-            t_f = event_time(lambda: ops.rollout(pi0, T, st['theta'], shift, alpha_scale, w=st['w'], gamma=gamma, seed=7,
-                                                 traj_offset=st['traj_offset'], td=True, G=st['G'], ws=st['ws'],
-                                                 out=st['bufs']), n=10, warm=3)
-            fused = {'kernel': ('k_core_small' if d <= 64 else 'k_core_large') + '<SAMPLE,TD,MIXED> + k_grad + k_reduce_partials',
-                     'bound': 'valu/transcendental+rng (P stays on chip)', 'avg_launch_ms': t_f * 1e3,
-                     'env_steps_per_s': B * T / t_f, 'hbm_algorithmic_GBs': B * T * bytes_per_step / t_f / 1e9}
-            fused.update(pmc_sq('k_core_', d, T, B))
-            del st, pi0
-            if not args.no_configs:
+            if world == 1:                                               # (a training leg on rank 0 alone would hang the others)
+                _, _, st = training_leg(d, T, B, 1, 1)
+                pi0 = ops.gather_start(st['mat_pi0'], st['idx'])
+                t_f = event_time(lambda: ops.rollout(pi0, T, st['theta'], shift, alpha_scale, w=st['w'], gamma=gamma, seed=7,
+                                                     traj_offset=st['traj_offset'], td=True, G=st['G'], ws=st['ws'],
+                                                     out=st['bufs']), n=10, warm=3)
+                fused = {'kernel': ('k_core_small' if d <= 64 else 'k_core_large') + '<SAMPLE,TD,MIXED> + k_grad + k_reduce_partials',
+                         'bound': 'valu/transcendental+rng (P stays on chip)', 'avg_launch_ms': t_f * 1e3,
+                         'env_steps_per_s': B * T / t_f, 'hbm_algorithmic_GBs': B * T * bytes_per_step / t_f / 1e9}
+                fused.update(pmc_sq('k_core_', d, T, B))
+                del st, pi0
+            if world == 1 and not args.no_configs:
                 configs = other_configs(training_leg, given_p_leg, d, T, B, args)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -360,7 +367,7 @@ def other_configs(training_leg, given_p_leg, d0, T0, B0, args):
     for name, d, T, B, steps in (('C2', 21, 15, 4096, 20), ('C3', 128, 40, 16384, 3), ('C5 (1/8 share)', 256, 40, 16384, 2)):
         try:
             e, _, st = training_leg(d, T, B, steps, 1)
-            gp = given_p_leg(d, B, T if d <= 64 else 1, st, n_launch=20, warm=10)
+            gp = given_p_leg(d, B, T if d <= 64 else 1, n_launch=20, warm=10)
             bps = 4 * (d * d + 2 * d + 1)
             out.append({'config': name, 'd': d, 'T': T, 'batch': B, 'steps': steps, 'fused_ms_per_rollout': e / steps * 1e3,
                         'fused_env_steps_per_s': B * T * steps / e,
