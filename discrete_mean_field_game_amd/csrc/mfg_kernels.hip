@@ -428,6 +428,119 @@ __global__ __launch_bounds__(BLOCK, (PER <= 6 ? MFG_STEP_WAVES : 4)) void k_step
 
 #undef MFG_STEP_PREFETCH
 
+// ---------------------------------------------------------------------------------------------
+// a3+a4, compile-time small d (21, 15), WAVE-PRIVATE tiles: each wavefront stages the contiguous slab of its own
+// G = 64/D trajectories (16-byte loads from the enclosing aligned window, the few bytes of the neighbours that come
+// along are never read back), so there is no block-wide barrier at all -- a wave waits only for its OWN prefetch --
+// and the per-trajectory reward sum goes through the wave's LDS region (dead after its column walk) instead of a
+// shuffle tree.  Same arithmetic and summation order as k_core_small's column pass.
+// ---------------------------------------------------------------------------------------------
+template <int KIND, int D>
+__global__ __launch_bounds__(BLOCK, MFG_STEP_WAVES) void k_step_wave(const float* __restrict__ pi, const float* __restrict__ P,
+                                                                      int64_t B, float* __restrict__ pi_next,
+                                                                      float* __restrict__ reward) {
+  constexpr int G = WAVE / D, DD = D * D;
+  constexpr int WF = ((G * DD + 6 + 3) / 4) * 4;        // floats of a wave's LDS window (16-byte multiple, + alignment slack)
+  constexpr int PER = (WF / 4 + WAVE - 1) / WAVE;       // 16-byte loads per lane per tile
+  __shared__ __attribute__((aligned(16))) float sP[WAVES][WF];
+  __shared__ float sQ[WAVES][G * D];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  const int t = lane / D, j = lane - t * D;
+  float* wP = sP[wv];
+  float* wQ = sQ[wv];
+  const int64_t total4 = (B * DD) >> 2;                 // whole 16-byte words of the slab
+  const int64_t ntiles = (B + G - 1) / G;
+  const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  v4f_t pre[PER];
+  float prepi = 0.0f;
+  const v4f_t* P4 = reinterpret_cast<const v4f_t*>(P);
+#define MFG_WAVE_PREFETCH(TT)                                                             \
+  {                                                                                       \
+    const int64_t f0 = (TT) * (int64_t)(G * DD);                                          \
+    const int64_t a4 = f0 >> 2;                                                           \
+    const int png = (int)((B - (TT) * G) < G ? (B - (TT) * G) : G);                       \
+    const int pn4 = (int)(((f0 & 3) + (int64_t)png * DD + 3) >> 2);                       \
+    _Pragma("unroll") for (int u = 0; u < PER; ++u) {                                     \
+      const int k = lane + u * WAVE;                                                      \
+      pre[u] = (v4f_t)(0.0f);                                                             \
+      if (k < pn4) {                                                                      \
+        const int64_t g4 = a4 + k;                                                        \
+        if (g4 < total4) {                                                                \
+          pre[u] = MFG_STREAM_LOAD(P4 + g4);                                              \
+        } else { /* ragged last word of the whole slab */                                 \
+          const int64_t e0 = g4 << 2, tot = B * DD;                                       \
+          if (e0 < tot) pre[u].x = P[e0];                                                 \
+          if (e0 + 1 < tot) pre[u].y = P[e0 + 1];                                         \
+          if (e0 + 2 < tot) pre[u].z = P[e0 + 2];                                         \
+        }                                                                                 \
+      }                                                                                   \
+    }                                                                                     \
+    prepi = (lane < png * D) ? pi[(TT) * (int64_t)(G * D) + lane] : 0.0f;                 \
+  }
+  int64_t tile = (int64_t)blockIdx.x * WAVES + wv;
+  if (tile < ntiles) MFG_WAVE_PREFETCH(tile)
+  for (; tile < ntiles; tile += nwaves) {
+    const int ng = (int)((B - tile * G) < G ? (B - tile * G) : G);
+    const int off = (int)((tile * (int64_t)(G * DD)) & 3);   // position of the slab inside its aligned window
+    v4f_t* d4 = reinterpret_cast<v4f_t*>(wP);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int k = lane + u * WAVE;
+      if (k < WF / 4) d4[k] = pre[u];
+    }
+    if (lane < G * D) wQ[lane] = prepi;
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    if (tile + nwaves < ntiles) MFG_WAVE_PREFETCH(tile + nwaves)
+    const bool valid = (t < G) && (t < ng);
+    const int tc = valid ? t : 0;
+    const float* colp = wP + off + tc * DD + j;
+    const float* qv = wQ + tc * D;
+    double acc = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll MFG_STEP_UNROLL
+    for (int i = 0; i < D; ++i) {
+      const double p = (double)colp[i * D];
+      const double qx = (double)qv[i];
+      const double u = p * qx;
+      acc += u;
+      if (KIND != MFG_REWARD_EXTERNAL) {
+        s1 = fma(u, p, s1);
+        if (KIND == MFG_REWARD_MFG_AC2) s2 = fma(u, u, s2);
+      }
+    }
+    double racc = 0.0;
+    if (KIND == MFG_REWARD_MFG_AC2) racc = fma((double)qv[j], s1, -s2);
+    if (KIND == MFG_REWARD_SYNTHETIC) racc = s1;
+    const int64_t b = tile * G + tc;
+    if (valid) pi_next[b * D + j] = (float)acc;
+    if (KIND != MFG_REWARD_EXTERNAL) {
+      // the wave's tile region is dead now: park the column terms there (8-byte aligned line per trajectory)
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      double* line = reinterpret_cast<double*>(wP) + tc * (D + 1);
+      if (valid) line[j] = racc;
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      if (valid && j == 0) {
+        double r0 = 0.0, r1 = 0.0;
+        int k = 0;
+#pragma unroll 4
+        for (; k + 1 < D; k += 2) {
+          r0 += line[k];
+          r1 += line[k + 1];
+        }
+        if (k < D) r0 += line[k];
+        double r = r0 + r1;
+        if (KIND == MFG_REWARD_SYNTHETIC) r *= -0.5;
+        reward[b] = (float)r;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#undef MFG_WAVE_PREFETCH
+}
+
 // Fallback for a P pointer that is not 16-byte aligned: scalar staging, no prefetch.
 template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_step_small_unaligned(const float* __restrict__ pi, const float* __restrict__ P,
@@ -1403,8 +1516,28 @@ int mfg_step_given_P(const float* pi, const float* P, int64_t B, int d, int rewa
         case 1: hipLaunchKernelGGL((k_step_small_unaligned<1>), dim3(grid), dim3(BLOCK), lds, st, pi, P, B, d, pi_next, reward); break;
         default: hipLaunchKernelGGL((k_step_small_unaligned<2>), dim3(grid), dim3(BLOCK), lds, st, pi, P, B, d, pi_next, reward); break;
       }
-    } else if (d == 21) { STEP_SMALL_D(21, 6) }
-    else if (d == 15) { STEP_SMALL_D(15, 4) }
+    } else if (d == 21 || d == 15) {
+#ifdef MFG_STEP_BLOCK_TILES
+      if (d == 21) { STEP_SMALL_D(21, 6) } else { STEP_SMALL_D(15, 4) }
+#else
+      const int gw = grid_for(B, (WAVE / d) * WAVES, MFG_STEP_WAVES);
+#define STEP_WAVE(K, DD) hipLaunchKernelGGL((k_step_wave<K, DD>), dim3(gw), dim3(BLOCK), 0, st, pi, P, B, pi_next, reward)
+      if (d == 21) {
+        switch (reward_kind) {
+          case 0: STEP_WAVE(0, 21); break;
+          case 1: STEP_WAVE(1, 21); break;
+          default: STEP_WAVE(2, 21); break;
+        }
+      } else {
+        switch (reward_kind) {
+          case 0: STEP_WAVE(0, 15); break;
+          case 1: STEP_WAVE(1, 15); break;
+          default: STEP_WAVE(2, 15); break;
+        }
+      }
+#undef STEP_WAVE
+#endif
+    }
     else if (per <= 4) { STEP_SMALL_D(0, 4) }
     else if (per <= 8) { STEP_SMALL_D(0, 8) }
     else { STEP_SMALL_D(0, 16) }
