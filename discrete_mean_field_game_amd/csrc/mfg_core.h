@@ -37,7 +37,15 @@ struct CoreArgs {
   double* g;           // [B,T] or NULL
   float* P_out;        // [B,T,d,d] or NULL
   const float4* htab;  // h(z) cubic table (mixed precision TD), see mfg_device.h
+#ifdef MFG_TIMING
+  unsigned long long* dbg;  // timing variant only (tools/phase_timing.py): s_memtime stamps of block 0, wave 0
+#endif
 };
+#ifdef MFG_TIMING
+#define MFG_STAMP(k) if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && s < 4) a.dbg[s * 16 + (k)] = __builtin_amdgcn_s_memtime();
+#else
+#define MFG_STAMP(k)
+#endif
 
 int set_error(int code, const char* msg);  // records mfg_last_error() (defined in mfg_kernels.hip)
 
@@ -405,6 +413,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
       }
     }
     for (int s = 0; s < T; ++s) {
+      MFG_STAMP(0)
       tile_sync();
       float Fi = 0.0f;
       if (valid) {
@@ -430,6 +439,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
           for (int k = tid; k < nb * d; k += BLOCK) pal[k] = a.pi_alpha[b0 * d + k];
       }
       tile_sync();
+      MFG_STAMP(1)
       float* trow = tile + (tlc * d + i) * dp;
       const float* pv = pis + tlc * d;
       const float* pav = (!SAMPLE && a.pi_alpha) ? pal + tlc * d : pv;
@@ -492,6 +502,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
             racc += reward_term(a.reward_kind, pid, (double)pv[j], (double)p);
           }
         }
+        MFG_STAMP(2)
         if (SAMPLE) {
           // normalise the row.  strict: P_ij = fl32(y_ij / S_i); mixed: P_ij = y_ij * fl32(1 / S_i) (one fp32 multiply per
           // element, within 1.5 ulp of the strict value; rows still sum to 1 within a few 1e-7)
@@ -511,6 +522,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
         if (TD) gacc = fma(FAST ? digamma_pos_mixed(A) : digamma_pos(A), D_, gacc);
 #endif
       }
+      MFG_STAMP(3)
       tile_sync();
       float pi_n;
       double rcol = 0.0;
@@ -568,6 +580,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
         pi_n = a.pi_next_in ? pnv[i] : 0.0f;
         rcol = pid * racc;
       }
+      MFG_STAMP(4)
       // Per-trajectory sums of the lane terms (reward, score, value): every lane parks its terms in an LDS line, lane 0
       // of the trajectory adds up reward and value, lane 1 the score -- two LDS round trips per step instead of the six
       // dependent cross-lane exchanges (ds_bpermute) of a shuffle tree per quantity, in a fixed order.
@@ -603,7 +616,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
           r0 = a.reward_in ? (double)a.reward_in[b * T + s] : 0.0;
         } else {
           int k = 0;
-#pragma unroll 4
+#pragma unroll
           for (; k + 1 < d; k += 2) {
             r0 += redq[k];
             r1 += redq[k + 1];
@@ -615,7 +628,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
         if (a.reward_out) a.reward_out[b * T + s] = (float)r;
         if (want_v) {
           int k = 0;
-#pragma unroll 4
+#pragma unroll
           for (; k + 1 < d; k += 2) {
             v0 += redq[2 * d + k];
             v1 += redq[2 * d + k + 1];
@@ -632,7 +645,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
       if (TD && valid && i == gl && a.g) {
         double g0 = 0.0, g1 = 0.0;
         int k = 0;
-#pragma unroll 4
+#pragma unroll
         for (; k + 1 < d; k += 2) {
           g0 += redq[d + k];
           g1 += redq[d + k + 1];
@@ -642,6 +655,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
       }
       if (valid && a.pi_traj) a.pi_traj[(b * (int64_t)(T + 1) + s + 1) * d + i] = pi_n;
       pi_i = pi_n;
+      MFG_STAMP(5)
     }
     if (valid && a.pi_next_out) a.pi_next_out[b * d + i] = pi_i;
   }

@@ -13,17 +13,20 @@ namespace mfg {
 // a static tile split.
 template <bool SAMPLE, bool TD, bool FAST, int D>
 static void go(const CoreArgs& a, int num_cus, size_t lds, hipStream_t st) {
-  static std::atomic<size_t> cached_lds{~(size_t)0};
-  static std::atomic<int> cached_bpc{1};
-  if (cached_lds.load() != lds) {
+  // occupancy of this instantiation at this LDS size, cached per device
+  static std::atomic<size_t> cached_lds[64];
+  static std::atomic<int> cached_bpc[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (cached_lds[dev].load() != lds + 1) {  // (+1: zero-initialised slots never match)
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_small<SAMPLE, TD, FAST, D>, BLOCK, lds) != hipSuccess || n < 1)
       n = 1;
-    cached_bpc.store(n);
-    cached_lds.store(lds);
+    cached_bpc[dev].store(n);
+    cached_lds[dev].store(lds + 1);
   }
   const int G = WAVE / a.d, TB = WAVES * G;
-  const int grid = core_grid(a.B, TB, cached_bpc.load() * MFG_CORE_OVERSUBSCRIBE, num_cus);
+  const int grid = core_grid(a.B, TB, cached_bpc[dev].load() * MFG_CORE_OVERSUBSCRIBE, num_cus);
   hipLaunchKernelGGL((k_core_small<SAMPLE, TD, FAST, D>), dim3(grid), dim3(BLOCK), lds, st, a);
 }
 

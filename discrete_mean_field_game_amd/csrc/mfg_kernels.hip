@@ -13,7 +13,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "../../include/mfg_hip.h"
@@ -48,15 +50,18 @@ static int check_launch(const char* what) {
 
 static inline hipStream_t S(mfg_stream_t s) { return (hipStream_t)s; }
 
+// CU count of the CURRENT device (cached per device: one context may drive several GPUs from one process)
 static int num_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int c = cus[dev].load(std::memory_order_relaxed);
+  if (!c) {
     hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) cus = p.multiProcessorCount;
-    if (cus <= 0) cus = 256;
+    c = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    cus[dev].store(c, std::memory_order_relaxed);
   }
-  return cus;
+  return c;
 }
 
 
@@ -1389,6 +1394,12 @@ static const float4* htab_ptr() {
 
 static int launch_core(const CoreArgs& a_in, bool sample, bool td, int precision, hipStream_t st) {
   CoreArgs a = a_in;
+#ifdef MFG_TIMING
+  {
+    const char* e = getenv("MFG_TIMING_BUF");
+    a.dbg = e ? (unsigned long long*)strtoull(e, nullptr, 16) : nullptr;
+  }
+#endif
   if (td && precision == MFG_PRECISION_MIXED) {
     a.htab = htab_ptr();
     if (!a.htab) return fail(MFG_ELAUNCH, "%s", "h(z) table initialisation failed");

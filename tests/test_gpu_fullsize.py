@@ -70,7 +70,11 @@ def test_fullsize_rollout_properties(dev, d, B, T):
     N = B * T
     pn, rr = o.step_given_P(traj[:, :T].contiguous().view(N, d), P.view(N, d, d))
     assert torch.equal(pn.view(B, T, d), traj[:, 1:])
-    assert float(((rr.view(B, T) - r).abs() / r.abs().clamp_min(1e-3)).max()) < 2e-6
+    if d in (21, 15):
+        # the packed compile-time-d kernels share the column-pass arithmetic and summation order: rewards bit for bit
+        assert torch.equal(rr.view(B, T), r)
+    else:
+        assert float(((rr.view(B, T) - r).abs() / r.abs().clamp_min(1e-3)).max()) < 2e-6
     # checksum of checksums: the batch gradient equals an fp64 recomputation from the per-sample outputs
     x = traj[:, :T].double().reshape(N, d)
     dl = delta.reshape(N)

@@ -10,7 +10,7 @@ import csv, json, sys
 
 fetch_csv, write_csv, tag, shape = sys.argv[1:5]
 d, T, B = (int(x) for x in shape.split(','))
-WIDE = ('k_step_small', 'k_step_large', 'k_step_rows')
+WIDE = ('k_step_small', 'k_step_wave', 'k_step_large', 'k_step_rows')
 
 
 def per_kernel(path, counter):
