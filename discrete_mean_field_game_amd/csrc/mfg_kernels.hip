@@ -1174,6 +1174,89 @@ __global__ __launch_bounds__(BLOCK) void k_grad_mfma(GradArgs a, int tpw) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Critic values of a whole rollout on the fp64 matrix cores (d a multiple of 16, 64 <= d <= 512): the second GEMM-shaped
+// piece of the path.  V_n = x_n^T U x_n + b.x_n + c for the N = B (T+1) states a rollout left in pi_traj, i.e. the
+// diagonal of X U X^T: a wave owns 16 states (A operand: X[16 x 4] slices from its LDS copy of the rows), sweeps the
+// column tiles of the upper triangle U (B operand straight from the L2-resident weight vector, row k of U is contiguous in
+// c), and folds each finished 16 x 16 tile Y = X U into  v_n += sum_c (Y_nc + b_c) x_nc.  The 16 lanes that hold one state
+// are one DPP row, so the final sum is four DPP steps.  Inside the wave-per-trajectory rollout kernel the same values
+// cost a latency-bound triangular loop per state (10 % of the d = 128 training rollout); here they are ~2 nt (nt + 1)
+// matrix instructions per 16 states.  Followed by k_td_delta (delta = r + gamma V' - V).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_value_mfma(const float* __restrict__ pi, int64_t stride_b, int64_t N, int TP1, int d,
+                                                      const double* __restrict__ w, double* __restrict__ V) {
+  extern __shared__ __attribute__((aligned(16))) float smx[];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  const int li = lane & 15, lk = lane >> 4;
+  const int nt = d >> 4, pitch = d + 4;  // +4 floats: the 16 state rows of an A operand fall on distinct banks
+  const int Q = d * (d + 1) / 2;
+  float* xs = smx + (size_t)wv * 16 * pitch;
+  const double invT = 1.0 / (double)TP1;
+  const int64_t ngroups = (N + 15) / 16;
+  for (int64_t grp = (int64_t)blockIdx.x * WAVES + wv; grp < ngroups; grp += (int64_t)gridDim.x * WAVES) {
+    const int64_t n0 = grp * 16;
+    __builtin_amdgcn_wave_barrier();
+    // stage the 16 state rows (fp32, float4 copies: d is a multiple of 16 and rows are 16-byte aligned when stride_b % 4 == 0)
+    for (int e = lane; e < 16 * (d >> 2); e += WAVE) {
+      const int q = e / (d >> 2), c4 = e - q * (d >> 2);
+      const int64_t n = n0 + q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N) {
+        const int64_t b = (int64_t)(((double)n + 0.5) * invT);
+        v = *reinterpret_cast<const float4*>(pi + b * stride_b + (n - b * TP1) * (int64_t)d + 4 * c4);
+      }
+      *reinterpret_cast<float4*>(xs + q * pitch + 4 * c4) = v;
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    double vs[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int jt = 0; jt < nt; ++jt) {
+      const int c = (jt << 4) + li;  // this lane's column of the tile
+      v4d_t acc = (v4d_t)(0.0);
+      const int ksteps = (jt + 1) << 2;  // rows 0 .. 16 jt + 15 of U, four at a time
+#pragma unroll 4
+      for (int ks = 0; ks < ksteps; ++ks) {
+        const int k = (ks << 2) + lk;
+        const double av = (double)xs[li * pitch + k];                                  // A[i = li][k]
+        const double bv = (k <= c) ? w[(int64_t)k * d - ((int64_t)k * (k - 1)) / 2 + (c - k)] : 0.0;  // B[k][j = li] = U[k][c]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+      const double bc = w[Q + c];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) vs[v] = fma(acc[v] + bc, (double)xs[(4 * v + lk) * pitch + c], vs[v]);  // D[i = 4v + lk][j = li]
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      double t = vs[v];
+      t += dpp_mov_f64<0xB1, 0xF>(t);
+      t += dpp_mov_f64<0x4E, 0xF>(t);
+      t += dpp_mov_f64<0x141, 0xF>(t);
+      t += dpp_mov_f64<0x140, 0xF>(t);
+      const int64_t n = n0 + 4 * v + lk;
+      if (li == 0 && n < N) V[n] = t + w[Q + d];
+    }
+  }
+}
+
+// delta[b, s] = r[b, s] + gd(s) V[b, s+1] - V[b, s],  gd = gamma (mfg_ac2.py:505) or the running gamma^s (ac_irl.py:691);
+// reward == NULL: the IRL form without the reward (added by the gradient kernel once the network has run).
+__global__ void k_td_delta(const double* __restrict__ V, const float* __restrict__ reward, int64_t B, int T, double gamma,
+                           int discount_pow, double* __restrict__ delta) {
+  const int64_t n_tot = B * T;
+  for (int64_t n = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; n < n_tot; n += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = n / T;
+    const int s = (int)(n - b * T);
+    double gd = gamma;
+    if (discount_pow) {
+      gd = 1.0;
+      for (int q = 0; q < s; ++q) gd *= gamma;  // the running product of the in-kernel form, same rounding
+    }
+    const double r = reward ? (double)reward[n] : 0.0;
+    delta[n] = r + gd * V[b * (T + 1) + s + 1] - V[b * (T + 1) + s];
+  }
+}
+
 // Sum nsb partial rows in a fixed order: block = 16 slices (waves) x 64 outputs (lanes, coalesced);
 // slice s adds rows s, s+16, ... ; the 16 slice sums are combined in slice order through LDS.
 constexpr int RP_SLICES = 16;
@@ -1242,6 +1325,11 @@ struct ApplyArgs {
   double *w, *theta, *reward_acc;
 };
 
+// Large-d rollouts evaluate the critic values of all states in one matrix-core pass after the rollout (k_value_mfma): room
+// for V[B (T+1)] <= 2 N doubles behind the partial rows of the gradient sums.
+static bool value_batch_ok(int d) { return d > WAVE && d % 16 == 0 && d <= MFG_MAX_D; }
+static size_t value_buffer_bytes(int64_t N, int d) { return value_batch_ok(d) ? (size_t)(2 * N) * 8 : 0; }
+
 static void grad_geometry(int64_t N, int d, int* chunk, int64_t* nsb, int* nob) {
   const int64_t FO = mfg_num_features(d) + 3;
   int ch = 8192 / d;
@@ -1267,7 +1355,7 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
   int chunk, nob;
   int64_t nsb;
   grad_geometry(N, d, &chunk, &nsb, &nob);
-  const size_t need = (size_t)(nsb * FO * 8) + MFG_WS_CONTROL_BYTES;
+  const size_t need = (size_t)(nsb * FO * 8) + MFG_WS_CONTROL_BYTES;  // (the value buffer, if any, lies behind)
   if (ws_bytes < need) return fail(MFG_EWORKSPACE, "%s: need %lld bytes, have %lld", "workspace", (long long)need,
                                    (long long)ws_bytes);
   // the parameter update, when asked for, rides in the kernel that finishes the sums (fixed-order; needs accumulate == 0
@@ -1454,7 +1542,7 @@ size_t mfg_workspace_bytes(int64_t N, int d) {
   int chunk, nob;
   int64_t nsb;
   grad_geometry(N, d, &chunk, &nsb, &nob);
-  return (size_t)(nsb * (mfg_num_features(d) + 3) * 8) + MFG_WS_CONTROL_BYTES;
+  return (size_t)(nsb * (mfg_num_features(d) + 3) * 8) + MFG_WS_CONTROL_BYTES + value_buffer_bytes(N, d);
 }
 
 #define CHECK_BD()                                        \
@@ -1734,6 +1822,32 @@ int mfg_apply_update(const double* G, int d, double lr_critic, double lr_actor, 
   return check_launch("apply_update");
 }
 
+// After a TD rollout that skipped the in-kernel values (large d): V of all B (T+1) states, then delta.
+static int launch_values_and_delta(const float* pi_traj, int64_t B, int T, int d, const double* w, const float* reward,
+                                   double gamma, int discount_pow, double* delta, void* ws, size_t ws_bytes, hipStream_t st) {
+  const int64_t N = B * T, NV = B * (int64_t)(T + 1);
+  int chunk, nob;
+  int64_t nsb;
+  grad_geometry(N, d, &chunk, &nsb, &nob);
+  const size_t off = (size_t)(nsb * (mfg_num_features(d) + 3) * 8) + MFG_WS_CONTROL_BYTES;
+  double* V = reinterpret_cast<double*>((char*)ws + off);
+  const size_t lds = (size_t)WAVES * 16 * (d + 4) * 4;
+  int64_t groups = (NV + 15) / 16;
+  int64_t blocks = (groups + WAVES - 1) / WAVES;
+  const int64_t cap = (int64_t)num_cus() * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(k_value_mfma, dim3((unsigned)blocks), dim3(BLOCK), lds, st, pi_traj, (int64_t)(T + 1) * d, NV, T + 1, d, w, V);
+  hipLaunchKernelGGL(k_td_delta, dim3(grid_for(N, 256, 8)), dim3(256), 0, st, (const double*)V, reward, B, T, gamma, discount_pow,
+                     delta);
+  (void)ws_bytes;
+  return check_launch("values");
+}
+// whether a TD rollout can defer its values to k_value_mfma
+static bool defer_values(int d, int64_t B, int T, const float* pi_traj, const void* ws, size_t ws_bytes) {
+  if (!value_batch_ok(d) || !pi_traj || !ws || (((uintptr_t)pi_traj & 15) != 0)) return false;
+  return ws_bytes >= mfg_workspace_bytes(B * T, d);
+}
+
 int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, double shift, double alpha_scale,
                 const double* w, double gamma, int reward_kind, uint64_t seed, uint32_t first_step, uint64_t traj_offset,
                 int flags, float* pi_traj, float* pi_last, float* reward, double* delta, double* g, float* P_out,
@@ -1770,8 +1884,15 @@ int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, 
   a.g = g;
   a.P_out = (flags & MFG_ROLLOUT_WRITE_P) ? P_out : nullptr;
   const int precision = (flags & MFG_ROLLOUT_F64) ? MFG_PRECISION_F64 : MFG_PRECISION_MIXED;
+  const bool deferred = td && defer_values(d, B, T, pi_traj, workspace, workspace_bytes);
+  if (deferred) a.w = nullptr;  // the kernel then leaves delta alone; values + delta follow on the matrix cores
   int rc = launch_core(a, true, td, precision, S(stream));
-  if (rc != MFG_OK || !td || !G) return rc;
+  if (rc != MFG_OK || !td) return rc;
+  if (deferred) {
+    rc = launch_values_and_delta(pi_traj, B, T, d, w, reward, gamma, a.discount_pow, delta, workspace, workspace_bytes, S(stream));
+    if (rc != MFG_OK) return rc;
+  }
+  if (!G) return rc;
   REQUIRE(workspace, "workspace is null");
   return launch_grad(pi_traj, (int64_t)(T + 1) * d, delta, g, reward, B * T, T, d, G, accumulate, workspace,
                      workspace_bytes, S(stream));
@@ -1809,8 +1930,14 @@ int mfg_train_rollout(const float* mat_pi0, int64_t num_start, const int32_t* id
   a.delta = delta;
   a.g = g;
   const int precision = (flags & MFG_ROLLOUT_F64) ? MFG_PRECISION_F64 : MFG_PRECISION_MIXED;
+  const bool deferred = defer_values(d, B, T, pi_traj, workspace, workspace_bytes);
+  if (deferred) a.w = nullptr;
   int rc = launch_core(a, true, true, precision, S(stream));
   if (rc != MFG_OK) return rc;
+  if (deferred) {
+    rc = launch_values_and_delta(pi_traj, B, T, d, w, reward, gamma, a.discount_pow, delta, workspace, workspace_bytes, S(stream));
+    if (rc != MFG_OK) return rc;
+  }
   const ApplyArgs ap{lr_critic, lr_actor, w, theta, reward_acc};
   const bool want_apply = (flags & MFG_TRAIN_APPLY) != 0;
   bool applied = false;
