@@ -288,3 +288,30 @@ def test_config_C4_irl_train_with_reward_net_in_the_loop(dev, mode):
     # fp32 reward kernel vs fp64 restatement: rewards agree to ~1e-6 absolute, so the updates agree to ~1e-9
     assert abs(float(np.ravel(ac.theta)[0]) - theta) < 5e-8
     assert np.max(np.abs(ac.w[:, 0] - w)) < 5e-8
+
+
+@pytest.mark.parametrize('d,B,T', [(80, 7, 3), (128, 5, 6), (144, 33, 2), (256, 3, 5), (512, 2, 2)])
+def test_matrix_core_values_equal_in_kernel_values(dev, d, B, T):
+    """Large-d TD rollouts evaluate V of all B (T+1) states on the fp64 matrix cores after the rollout (k_value_mfma) when
+    a workspace is passed; without one (the IRL form, reward_kind EXTERNAL) the rollout kernel evaluates the same values
+    itself.  Both must give the same TD errors (re-associated fp64 sums: 1e-12), for both discount forms and ragged
+    state counts (B (T+1) not a multiple of the 16-state tile), and match the oracle."""
+    from discrete_mean_field_game_amd import _lib as L
+    o = ops()
+    pi0 = start_states(B, d, dev, seed=4)
+    theta = torch.tensor([THETA], dtype=torch.float64, device=dev)
+    w = torch.as_tensor(np.random.RandomState(2).rand(o.num_features(d)), device=dev)
+    for dpow in (False, True):
+        a = o.rollout(pi0, T, theta, SHIFT, SCALE, w=w, gamma=0.9, seed=3, td=True, discount_pow=dpow)           # deferred
+        b = o.rollout(pi0, T, theta, SHIFT, SCALE, w=w, gamma=0.9, seed=3, td=True, discount_pow=dpow,
+                      reward_kind=L.REWARD_EXTERNAL)                                                               # in-kernel
+        torch.cuda.synchronize()
+        assert torch.equal(a['pi_traj'], b['pi_traj']) and torch.equal(a['g'], b['g'])
+        want = b['delta'] + a['reward'].double()
+        assert float((a['delta'] - want).abs().max()) <= 1e-12 * float(want.abs().max())
+    # oracle values of the stored states
+    x = a['pi_traj'].cpu().numpy().astype(np.float64)
+    V = O().calc_value(x.reshape(-1, d), w.cpu().numpy()).reshape(B, T + 1)
+    disc = 0.9 ** np.arange(T)
+    want = a['reward'].cpu().numpy().astype(np.float64) + disc[None, :] * V[:, 1:] - V[:, :-1]
+    assert np.max(np.abs(a['delta'].cpu().numpy() - want)) <= 1e-11 * np.max(np.abs(V))
