@@ -679,3 +679,58 @@ def test_ac_irl_generate_trajectories_numpy_rng_retraces_reference(dev):
     # mixed-precision score on fp32-rounded (pi, P): late in a trajectory g is a 1e-5-sized sum of cancelling O(1e-2) terms,
     # so the bound is relative to the leading terms, not to g itself
     assert np.allclose(g, z['gradient'], rtol=1e-5, atol=2e-8)
+
+
+@pytest.mark.parametrize('d,B,T', [(21, 1000, 15), (15, 77, 15), (47, 30, 4), (128, 40, 5)])
+@pytest.mark.parametrize('apply', [True, False])
+def test_train_rollout_equals_gather_rollout_update_sequence(dev, d, B, T, apply):
+    """mfg_train_rollout (start-state gather inside the rollout kernel, update inside the kernel that finishes the sums) gives
+    bit for bit what the separate calls give: mfg_gather_start -> mfg_rollout(TD, G) -> mfg_apply_update."""
+    from discrete_mean_field_game_amd import ops
+    rs = np.random.RandomState(d)
+    mat = torch.as_tensor(rs.dirichlet(np.ones(d), size=9).astype(np.float32), device=dev)
+    idx = torch.as_tensor(rs.randint(9, size=B).astype(np.int32), device=dev)
+    F = ops.num_features(d)
+    w0 = rs.rand(F)
+    outs = []
+    for fused in (True, False):
+        theta = torch.tensor([8.86349], dtype=torch.float64, device=dev)
+        w = torch.as_tensor(w0.copy(), device=dev)
+        G = torch.zeros(F + 3, dtype=torch.float64, device=dev)
+        ws = ops.workspace(B * T, d, dev)
+        racc = torch.zeros(1, dtype=torch.float64, device=dev)
+        bufs = {'pi_traj': torch.empty(B, T + 1, d, device=dev), 'pi_last': torch.empty(B, d, device=dev),
+                'reward': torch.empty(B, T, device=dev), 'delta': torch.empty(B, T, dtype=torch.float64, device=dev),
+                'g': torch.empty(B, T, dtype=torch.float64, device=dev)}
+        if fused:
+            ops.train_rollout(mat, idx, T, theta, 0.16, 12000.0, w, 0.9, G, ws, bufs, 0.1, 0.001, apply=apply, seed=5,
+                              first_step=3, traj_offset=11, reward_acc=racc)
+            if not apply:
+                ops.apply_update(G, d, 0.1, 0.001, w, theta, racc)
+        else:
+            pi0 = ops.gather_start(mat, idx)
+            ops.rollout(pi0, T, theta, 0.16, 12000.0, w=w, gamma=0.9, seed=5, first_step=3, traj_offset=11, td=True, G=G,
+                        ws=ws, out=bufs)
+            ops.apply_update(G, d, 0.1, 0.001, w, theta, racc)
+        torch.cuda.synchronize()
+        outs.append((theta.clone(), w.clone(), G.clone(), racc.clone(), bufs['pi_traj'].clone(), bufs['delta'].clone(),
+                     bufs['g'].clone(), bufs['reward'].clone(), bufs['pi_last'].clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert float(outs[0][0]) != 8.86349 and float(outs[0][2][F + 2]) == B * T
+
+
+@pytest.mark.parametrize('d,B', [(21, 1), (21, 2), (21, 3), (21, 4), (21, 100), (15, 1), (15, 5), (15, 1001)])
+def test_given_P_wave_kernel_ragged_tiles(dev, d, B):
+    """k_step_wave (wave-private tiles, 16-byte loads of the enclosing aligned window) at batch sizes that leave ragged
+    last tiles and last 16-byte words, against the oracle; the reward-less call returns the same states."""
+    from discrete_mean_field_game_amd import ops
+    rs = np.random.RandomState(B)
+    pi = rs.dirichlet(np.ones(d), size=B).astype(np.float32)
+    P = rs.dirichlet(np.ones(d), size=(B, d)).astype(np.float32)
+    pn, r = ops.step_given_P(torch.as_tensor(pi, device=dev), torch.as_tensor(P, device=dev))
+    assert np.array_equal(pn.cpu().numpy(), O().transition(P.astype(np.float64), pi.astype(np.float64)).astype(np.float32))
+    ref = O().calc_reward(P.astype(np.float64), pi.astype(np.float64))
+    assert np.max(np.abs(r.cpu().numpy() - ref) / np.maximum(np.abs(ref), 1e-6)) < 1e-6
+    pn2, none = ops.step_given_P(torch.as_tensor(pi, device=dev), torch.as_tensor(P, device=dev), want_reward=False)
+    assert none is None and torch.equal(pn2, pn)
