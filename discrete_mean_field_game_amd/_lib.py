@@ -61,6 +61,7 @@ SIGNATURES = {
                            _p, _p, _p, _p, _p, _p, _p, _i32, _p, _sz, _p]),
     'mfg_jsd': (_i32, [_p, _p, _i64, _i32, _p, _p]),
     'mfg_grad_accumulate': (_i32, [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _i32, _p, _sz, _p]),
+    'mfg_grad_apply': (_i32, [_p, _i64, _p, _p, _p, _i64, _i32, _i32, _i32, _p, _f64, _f64, _p, _p, _p, _p, _sz, _p]),
     'mfg_train_episode': (_i32, [_p, _p, _i64, _i32, _i32, _p, _f64, _f64, _p, _f64, _i32, _u64, _u32, _u64, _i32, _f64, _f64,
                                  _p, _p, _p, _p, _p, _p, _sz, _p]),
     'mfg_train_rollout': (_i32, [_p, _i64, _p, _i64, _i32, _i32, _p, _f64, _f64, _p, _f64, _i32, _u64, _u32, _u64, _i32, _f64,

@@ -199,14 +199,19 @@ class AC_IRL(actor_critic):
                 states = o['pi_traj'][:, :T].reshape(Bl * T, d)
                 self._reward_sample_offset = shard.traj_offset * T
                 r = rfn(states, o['P'].view(Bl * T, d, d))
-                ops.grad_accumulate(o['pi_traj'], o['delta'].view(-1), o['g'].view(-1), r, G, ws_ep, T=T, add_reward=True)
-                all_reduce_gradients_(G, self.group)
-                ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta, total_reward)
+                if shard.world == 1:
+                    ops.grad_apply(o['pi_traj'], o['delta'].view(-1), o['g'].view(-1), r, G, ws_ep, lr_critic * sc,
+                                   lr_actor * sa, self._w, self._theta, total_reward, T=T, add_reward=True)
+                else:
+                    ops.grad_accumulate(o['pi_traj'], o['delta'].view(-1), o['g'].view(-1), r, G, ws_ep, T=T, add_reward=True)
+                    all_reduce_gradients_(G, self.group)
+                    ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta, total_reward)
                 total_reward = total_reward * T
                 self._theta_is_array = True
                 pi = o['pi_last']
             for step in range(0 if fused_episode else T):
                 acc = (self.update_every == 'rollout' and step > 0)
+                step_applied = False
                 if self.rng == 'philox':
                     # ONE launch samples P, takes the transition and evaluates everything of the TD step that does not
                     # need the reward (score g, gamma V(pi') - V(pi)); P is materialised for the reward network, whose
@@ -222,7 +227,13 @@ class AC_IRL(actor_critic):
                         self._write_all(pi, P, step + 1)
                     self._reward_sample_offset = shard.traj_offset
                     r = rfn(pi, P)
-                    ops.grad_accumulate(pi, dg[0], dg[1], r, G, ws, add_reward=True, accumulate=acc)
+                    if self.update_every == 'step' and shard.world == 1:
+                        # sums + update in one launch (the step is core -> reward net -> this)
+                        ops.grad_apply(pi, dg[0], dg[1], r, G, ws, lr_critic * sc, lr_actor * sa, self._w, self._theta,
+                                       total_reward, add_reward=True)
+                        step_applied = True
+                    else:
+                        ops.grad_accumulate(pi, dg[0], dg[1], r, G, ws, add_reward=True, accumulate=acc)
                 else:
                     P = self._sample(pi, shard.traj_offset, snapshot=False)
                     pi_next, _ = ops.step_given_P(pi, P, want_reward=False)
@@ -233,8 +244,9 @@ class AC_IRL(actor_critic):
                     ops.td_pg_accumulate(pi, pi_next, P, r, self._w, self._theta, self.shift, discount, G=G, ws=ws,
                                          precision=self.precision, out=dg, accumulate=acc)
                 if self.update_every == 'step':
-                    all_reduce_gradients_(G, self.group)
-                    ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta, total_reward)
+                    if not step_applied:
+                        all_reduce_gradients_(G, self.group)
+                        ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta, total_reward)
                     self._theta_is_array = True
                     if self.trace is not None:
                         self.trace.append(float(self._theta.cpu()[0]))

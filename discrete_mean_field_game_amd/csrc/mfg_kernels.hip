@@ -1506,7 +1506,7 @@ static int launch_core(const CoreArgs& a_in, bool sample, bool td, int precision
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 9; }
+int mfg_abi_version(void) { return 10; }
 
 int mfg_init(void) {
   if (!htab_ptr()) return fail(MFG_ELAUNCH, "%s", "mfg_init: no HIP device / table initialisation failed");
@@ -1961,6 +1961,26 @@ int mfg_grad_accumulate(const float* pi, int64_t stride_b, double* delta, const 
   REQUIRE(!add_reward || reward, "add_reward without reward");
   return launch_grad(pi, stride_b, delta, g, reward, B * T, T, d, G, accumulate, workspace, workspace_bytes, S(stream),
                      nullptr, nullptr, add_reward != 0);
+}
+
+int mfg_grad_apply(const float* pi, int64_t stride_b, double* delta, const double* g, const float* reward, int64_t B, int T,
+                   int d, int add_reward, double* G, double lr_critic, double lr_actor, double* w, double* theta,
+                   double* reward_acc, void* workspace, size_t workspace_bytes, mfg_stream_t stream) {
+  CHECK_BD();
+  REQUIRE(T >= 1 && stride_b >= (int64_t)T * d, "bad T / stride_b");
+  REQUIRE(pi && delta && G && workspace && w && theta, "null pointer");
+  REQUIRE(!add_reward || reward, "add_reward without reward");
+  const ApplyArgs ap{lr_critic, lr_actor, w, theta, reward_acc};
+  bool applied = false;
+  int rc = launch_grad(pi, stride_b, delta, g, reward, B * T, T, d, G, 0, workspace, workspace_bytes, S(stream), &ap, &applied,
+                       add_reward != 0);
+  if (rc != MFG_OK) return rc;
+  if (!applied) {
+    const int64_t F = mfg_num_features(d);
+    hipLaunchKernelGGL(k_apply_update, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, S(stream), G, F, lr_critic, lr_actor,
+                       w, theta, reward_acc);
+  }
+  return check_launch("grad_apply");
 }
 
 int mfg_train_episode(float* pi_io, float* pi_scratch, int64_t B, int d, int T, double* theta, double shift,

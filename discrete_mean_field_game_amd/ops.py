@@ -243,6 +243,20 @@ def grad_accumulate(pi, delta, g, reward, G, ws, T=1, stride_b=None, add_reward=
     return G
 
 
+def grad_apply(pi, delta, g, reward, G, ws, lr_critic, lr_actor, w, theta, reward_acc=None, T=1, stride_b=None,
+               add_reward=False):
+    """grad_accumulate + apply_update in one call (single GPU): the update rides in the kernel that finishes the sums."""
+    d = pi.shape[-1]
+    B = delta.numel() // T
+    if stride_b is None:
+        stride_b = (T + 1) * d if (pi.dim() == 3 and pi.shape[1] == T + 1) else T * d
+    L.check(L.lib().mfg_grad_apply(pi.data_ptr(), int(stride_b), delta.data_ptr(), _ptr(g), _ptr(reward), B, int(T), d,
+                                   int(bool(add_reward)), G.data_ptr(), float(lr_critic), float(lr_actor), w.data_ptr(),
+                                   theta.data_ptr(), _ptr(reward_acc), ws.data_ptr(), ws.numel() * 8, _stream()),
+            'mfg_grad_apply')
+    return G
+
+
 def train_episode(pi, T, theta, shift, alpha_scale, w, gamma, lr_critic, lr_actor, G, ws, bufs, reward_kind=L.REWARD_MFG_AC2,
                   seed=0, first_step=0, traj_offset=0, reward_acc=None, precision='mixed'):
     """T env steps with the reference's per-step parameter updates, issued natively (single GPU).  `pi` [B,d] is

@@ -202,6 +202,13 @@ int mfg_grad_accumulate(const float* pi, int64_t stride_b, double* delta, const 
                         int T, int d, int add_reward, double* G, int accumulate, void* workspace, size_t workspace_bytes,
                         mfg_stream_t stream);
 
+/* mfg_grad_accumulate (accumulate = 0) followed by mfg_apply_update, with the update applied inside the kernel that
+ * finishes the sums (single GPU; mfg_ac2.py:511-522 / ac_irl.py:697-708 for the batch): the IRL step
+ * rollout(EXTERNAL) -> reward net -> this call is three launches. */
+int mfg_grad_apply(const float* pi, int64_t stride_b, double* delta, const double* g, const float* reward, int64_t B, int T,
+                   int d, int add_reward, double* G, double lr_critic, double lr_actor, double* w, double* theta,
+                   double* reward_acc, void* workspace, size_t workspace_bytes, mfg_stream_t stream);
+
 /* a9, native inner loop of train() with the reference's per-step updates (mfg_ac2.py:478-525) on ONE GPU: for
  * s < T: sample P ~ policy(pi), pi' = P^T pi, r, delta = r + gamma V(pi') - V(pi), g (a1-a7, one fused launch);
  * batch sums over the B trajectories (a6/a8); w += lr_critic G_w/B, theta += lr_actor G_theta/B,
