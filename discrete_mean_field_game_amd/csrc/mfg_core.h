@@ -681,7 +681,8 @@ inline size_t core_small_lds(int d, bool want_v, bool sample) {
 #ifndef MFG_CORE_LARGE_WAVES
 #define MFG_CORE_LARGE_WAVES(R) (((R) <= 2 || (R) == 4) ? 3 : 2)
 #endif
-template <int R, bool SAMPLE, bool TD, bool FAST>
+// FULL: d == 64 R (every lane owns R live columns, d even): the validity masks of the quads fold away (d = 128, 256, ...).
+template <int R, bool SAMPLE, bool TD, bool FAST, bool FULL>
 __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(CoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int d = a.d, T = a.T;
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
 #pragma unroll
       for (int m = 0; m < R; ++m) {
         const int c = lane + m * WAVE;
-        okc[m] = c < d;
+        okc[m] = FULL || c < d;
         pad[m] = SAMPLE ? pc[m] : (c < d ? pav[c] : 0.0f);
         acc[m] = 0.0;
         s1[m] = 0.0;
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
         // per iteration and quads {(i, m), (i, m+1), (i+1, m), (i+1, m+1)} (odd R: last column {(i, m), (i+1, m)})
         constexpr int NR = (R % 4 == 0) ? 1 : 2;
         for (int i = 0; i < d; i += NR) {
-          const bool row1 = NR == 2 && i + 1 < d;
+          const bool row1 = NR == 2 && (FULL || i + 1 < d);
           const int i1 = row1 ? i + 1 : i;
           const float pr[2] = {pis[i], pis[i1]};
           float fr[2] = {0.0f, 0.0f};
@@ -777,11 +778,15 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
               sample_elems_g<4, TD, FAST, sep>(a, theta, ts, pj, ej, pa, fi, el, ok, step, traj, yy, al, ad, gt);
 #pragma unroll
               for (int e = 0; e < 4; ++e) y[0][m + e] = yy[e];
-              ysum[0] += ((TT)yy[0] + (TT)yy[1]) + ((TT)yy[2] + (TT)yy[3]);
+              // (m == 0: assign -- "0 + x" is not foldable without fast-math and costs an instruction per sum)
+              const TT y4 = ((TT)yy[0] + (TT)yy[1]) + ((TT)yy[2] + (TT)yy[3]);
+              ysum[0] = m == 0 ? y4 : ysum[0] + y4;
               if (TD) {
-                asum[0] += (al[0] + al[1]) + (al[2] + al[3]);
-                dsum[0] += (ad[0] + ad[1]) + (ad[2] + ad[3]);
-                gsum += (gt[0] + gt[1]) + (gt[2] + gt[3]);
+                const TT a4 = (al[0] + al[1]) + (al[2] + al[3]), d4 = (ad[0] + ad[1]) + (ad[2] + ad[3]);
+                const TT g4 = (gt[0] + gt[1]) + (gt[2] + gt[3]);
+                asum[0] = m == 0 ? a4 : asum[0] + a4;
+                dsum[0] = m == 0 ? d4 : dsum[0] + d4;
+                gsum = m == 0 ? g4 : gsum + g4;
               }
             }
           } else {
@@ -804,14 +809,16 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
                 y[0][m1] = yy[1];
                 y[NR - 1][m] = yy[2];
                 y[NR - 1][m1] = yy[3];
-                ysum[0] += (TT)yy[0] + (TT)yy[1];
-                ysum[1] += (TT)yy[2] + (TT)yy[3];
+                const TT ya = (TT)yy[0] + (TT)yy[1], yb = (TT)yy[2] + (TT)yy[3];
+                ysum[0] = m == 0 ? ya : ysum[0] + ya;
+                ysum[1] = m == 0 ? yb : ysum[1] + yb;
                 if (TD) {
-                  asum[0] += al[0] + al[1];
-                  asum[1] += al[2] + al[3];
-                  dsum[0] += ad[0] + ad[1];
-                  dsum[1] += ad[2] + ad[3];
-                  gsum += (gt[0] + gt[1]) + (gt[2] + gt[3]);
+                  const TT g4 = (gt[0] + gt[1]) + (gt[2] + gt[3]);
+                  asum[0] = m == 0 ? al[0] + al[1] : asum[0] + (al[0] + al[1]);
+                  asum[1] = m == 0 ? al[2] + al[3] : asum[1] + (al[2] + al[3]);
+                  dsum[0] = m == 0 ? ad[0] + ad[1] : dsum[0] + (ad[0] + ad[1]);
+                  dsum[1] = m == 0 ? ad[2] + ad[3] : dsum[1] + (ad[2] + ad[3]);
+                  gsum = m == 0 ? g4 : gsum + g4;
                 }
               } else {
                 // odd R: the lane's last column; its two rows share the Box-Muller pair
@@ -1044,10 +1051,13 @@ inline int launch_core_large_impl(const CoreArgs& a, bool sample, bool td, int n
   const int R = (d + WAVE - 1) / WAVE;
   const size_t lds = (size_t)WAVES * 4 * d * 4 + (size_t)WAVES * 3 * d * 8;
   const int grid = core_grid(a.B, WAVES, 8 * MFG_CORE_OVERSUBSCRIBE, num_cus);
-#define MFG_CORE_LARGE_MODE(RR)                                                                              \
-  if (sample && td) hipLaunchKernelGGL((k_core_large<RR, true, true, FAST>), dim3(grid), dim3(BLOCK), lds, st, a);        \
-  else if (sample) hipLaunchKernelGGL((k_core_large<RR, true, false, FAST>), dim3(grid), dim3(BLOCK), lds, st, a);        \
-  else hipLaunchKernelGGL((k_core_large<RR, false, true, FAST>), dim3(grid), dim3(BLOCK), lds, st, a);
+#define MFG_CORE_LARGE_GO(RR, SS, TT, FF) \
+  hipLaunchKernelGGL((k_core_large<RR, SS, TT, FAST, FF>), dim3(grid), dim3(BLOCK), lds, st, a)
+#define MFG_CORE_LARGE_MODE(RR)                                          \
+  if (sample && td) { if (full) MFG_CORE_LARGE_GO(RR, true, true, true); else MFG_CORE_LARGE_GO(RR, true, true, false); }   \
+  else if (sample) { if (full) MFG_CORE_LARGE_GO(RR, true, false, true); else MFG_CORE_LARGE_GO(RR, true, false, false); }  \
+  else MFG_CORE_LARGE_GO(RR, false, true, false);
+  const bool full = (d == R * WAVE);
   switch (R) {
     case 2: MFG_CORE_LARGE_MODE(2) break;
     case 3: MFG_CORE_LARGE_MODE(3) break;
@@ -1058,6 +1068,7 @@ inline int launch_core_large_impl(const CoreArgs& a, bool sample, bool td, int n
     case 8: MFG_CORE_LARGE_MODE(8) break;
     default: return MFG_EUNSUPPORTED;
   }
+#undef MFG_CORE_LARGE_GO
 #undef MFG_CORE_LARGE_MODE
   return MFG_OK;
 }

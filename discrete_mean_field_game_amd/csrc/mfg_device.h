@@ -531,6 +531,16 @@ __device__ __forceinline__ float dpp_mov_f32(float v) {
                                   : __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xF, false);
   return __int_as_float(r);
 }
+// The two cross-row steps are written as ONE instruction each: v_add_f32_dpp with row_bcast and a row mask, destination tied to
+// the second source, so that the rows outside the mask simply keep their value (the compiler expands the update_dpp form
+// into zero-initialised move + DPP move + add: 3 instructions per sum per step, a quarter of the d = 128 kernel's row-sum
+// cost).  The s_nop covers the VALU-write -> DPP-read hazard, which the compiler cannot see through inline assembly.
+__device__ __forceinline__ void dpp_add_row_bcast15(float& v) {
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+}
+__device__ __forceinline__ void dpp_add_row_bcast31(float& v) {
+  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+}
 template <int NS>
 __device__ __forceinline__ void wave_sums_f32_dpp(float* x) {
 #define MFG_SUMF_STEP(CTRL, MASK)                                          \
@@ -543,9 +553,11 @@ __device__ __forceinline__ void wave_sums_f32_dpp(float* x) {
   MFG_SUMF_STEP(0x4E, 0xF)
   MFG_SUMF_STEP(0x141, 0xF)
   MFG_SUMF_STEP(0x140, 0xF)
-  MFG_SUMF_STEP(0x142, 0xA)
-  MFG_SUMF_STEP(0x143, 0xC)
 #undef MFG_SUMF_STEP
+#pragma unroll
+  for (int q = 0; q < NS; ++q) dpp_add_row_bcast15(x[q]);
+#pragma unroll
+  for (int q = 0; q < NS; ++q) dpp_add_row_bcast31(x[q]);
 #pragma unroll
   for (int q = 0; q < NS; ++q) x[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[q]), 63));
 }
