@@ -539,14 +539,10 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
           const double p = (double)tcol[k * dp];
           const double u = p * q64[k];
           acc += u;
-#ifdef MFG_ABL_COLREW
-          if (false) {
-#else
-          if (a.reward_kind != MFG_REWARD_EXTERNAL) {
+#ifndef MFG_ABL_COLREW
+          s1 = fma(u, p, s1);  // both reward sums unconditionally; the kind selects what is used below
+          s2 = fma(u, u, s2);
 #endif
-            s1 = fma(u, p, s1);
-            if (a.reward_kind == MFG_REWARD_MFG_AC2) s2 = fma(u, u, s2);
-          }
         }
         if (a.reward_kind == MFG_REWARD_MFG_AC2) rcol = fma(pid, s1, -s2);
         if (a.reward_kind == MFG_REWARD_SYNTHETIC) rcol = s1;
@@ -914,10 +910,8 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
                 if (Po) Po[(int64_t)ir * d + lane + m * WAVE] = p32;
                 const double u = p * pii;
                 acc[m] += u;
-                if (a.reward_kind != MFG_REWARD_EXTERNAL) {
-                  s1[m] = fma(u, p, s1[m]);
-                  if (a.reward_kind == MFG_REWARD_MFG_AC2) s2 = fma(u, u, s2);
-                }
+                s1[m] = fma(u, p, s1[m]);  // both reward sums unconditionally (2 FMAs): a run-time kind test per element
+                s2 = fma(u, u, s2);        // compiles to selects around them (4 v_cndmask per element)
               }
             }
           }

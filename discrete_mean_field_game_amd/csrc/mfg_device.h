@@ -531,15 +531,37 @@ __device__ __forceinline__ float dpp_mov_f32(float v) {
                                   : __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xF, false);
   return __int_as_float(r);
 }
-// The two cross-row steps are written as ONE instruction each: v_add_f32_dpp with row_bcast and a row mask, destination tied to
-// the second source, so that the rows outside the mask simply keep their value (the compiler expands the update_dpp form
-// into zero-initialised move + DPP move + add: 3 instructions per sum per step, a quarter of the d = 128 kernel's row-sum
-// cost).  The s_nop covers the VALU-write -> DPP-read hazard, which the compiler cannot see through inline assembly.
-__device__ __forceinline__ void dpp_add_row_bcast15(float& v) {
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
-}
-__device__ __forceinline__ void dpp_add_row_bcast31(float& v) {
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+// The two cross-row steps are written as ONE instruction per sum: v_add_f32_dpp with row_bcast and a row mask, destination
+// tied to the second source, so that the rows outside the mask simply keep their value (the compiler expands the
+// update_dpp form into zero-initialised move + DPP move + add: 3 instructions per sum per step, a quarter of the d = 128
+// kernel's row-sum cost).  The s_nop covers the VALU-write -> DPP-read hazard, which the compiler cannot see through
+// inline assembly.
+// One asm statement per step for all NS sums: the NS independent chains cover each other's hazard distance, so ONE
+// s_nop per step suffices (NS >= 3: none needed at all, kept for safety).
+template <int NS>
+__device__ __forceinline__ void dpp_add_row_bcast(float* x, bool second) {
+  static_assert(NS == 1 || NS == 2 || NS == 3 || NS == 6, "row-sum group sizes used by the kernels");
+#define MFG_BC(OP, MASK)                                                                                              \
+  if constexpr (NS == 1) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " OP " row_mask:" MASK " bank_mask:0xf" : "+v"(x[0])); \
+  else if constexpr (NS == 2) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " OP " row_mask:" MASK " bank_mask:0xf\n\t"      \
+                                           "v_add_f32_dpp %1, %1, %1 " OP " row_mask:" MASK " bank_mask:0xf" : "+v"(x[0]), "+v"(x[1])); \
+  else if constexpr (NS == 3) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " OP " row_mask:" MASK " bank_mask:0xf\n\t"      \
+                                           "v_add_f32_dpp %1, %1, %1 " OP " row_mask:" MASK " bank_mask:0xf\n\t"                  \
+                                           "v_add_f32_dpp %2, %2, %2 " OP " row_mask:" MASK " bank_mask:0xf"                       \
+                                           : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));                                                 \
+  else asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " OP " row_mask:" MASK " bank_mask:0xf\n\t"                             \
+                    "v_add_f32_dpp %1, %1, %1 " OP " row_mask:" MASK " bank_mask:0xf\n\t"                                         \
+                    "v_add_f32_dpp %2, %2, %2 " OP " row_mask:" MASK " bank_mask:0xf\n\t"                                         \
+                    "v_add_f32_dpp %3, %3, %3 " OP " row_mask:" MASK " bank_mask:0xf\n\t"                                         \
+                    "v_add_f32_dpp %4, %4, %4 " OP " row_mask:" MASK " bank_mask:0xf\n\t"                                         \
+                    "v_add_f32_dpp %5, %5, %5 " OP " row_mask:" MASK " bank_mask:0xf"                                              \
+                    : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]));
+  if (!second) {
+    MFG_BC("row_bcast:15", "0xa")
+  } else {
+    MFG_BC("row_bcast:31", "0xc")
+  }
+#undef MFG_BC
 }
 template <int NS>
 __device__ __forceinline__ void wave_sums_f32_dpp(float* x) {
@@ -554,10 +576,8 @@ __device__ __forceinline__ void wave_sums_f32_dpp(float* x) {
   MFG_SUMF_STEP(0x141, 0xF)
   MFG_SUMF_STEP(0x140, 0xF)
 #undef MFG_SUMF_STEP
-#pragma unroll
-  for (int q = 0; q < NS; ++q) dpp_add_row_bcast15(x[q]);
-#pragma unroll
-  for (int q = 0; q < NS; ++q) dpp_add_row_bcast31(x[q]);
+  dpp_add_row_bcast<NS>(x, false);
+  dpp_add_row_bcast<NS>(x, true);
 #pragma unroll
   for (int q = 0; q < NS; ++q) x[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[q]), 63));
 }
