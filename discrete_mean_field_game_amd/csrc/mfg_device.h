@@ -57,12 +57,8 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 
 // ---------------------------------------------------------------------------
 // Gamma(shape a, scale 1), Marsaglia & Tsang (2000) with the U^(1/a) boost for a < 1.  fp32.
-// Matrix elements are sampled in PAIRS (j, j+1) of one row: one Philox block gives the two Box-Muller
-// normals (cos / sin of the same radius) and the two acceptance uniforms, which halves the RNG cost
-// and gives the compiler two independent dependency chains to interleave (the kernels are latency
-// bound).  Counters: pair block = (elem of the first element, block 0); a rejected element retries on
-// its own counter (its elem, block 1, 2, ...); boost uniforms (shape < 1 only) come from block 0xFFFF of
-// the pair counter.  Acceptance is > 99 % at the shapes of the reference policy, so retries are rare.
+// Matrix elements are sampled in QUADS (see "Quad sampler" below): one Philox block gives two Box-Muller pairs
+// (cos / sin of the same radius) and four 12-bit acceptance integers.
 // ---------------------------------------------------------------------------
 struct GammaState {
   float a, dd, c;
@@ -75,6 +71,14 @@ __device__ __forceinline__ void gamma_setup(GammaState& g, float a) {
   const float a1 = g.small ? a + 1.0f : a;
   g.dd = a1 - (1.0f / 3.0f);
   g.c = __builtin_amdgcn_rsqf(9.0f * g.dd);
+}
+// Hot-path variant of the quad sampler: (d, c) for the shape as it is; shapes < 1 are flagged and re-set-up with the
+// boosted shape a + 1 in the cold continuation (gamma_fix), so the hot path carries no select for them.
+__device__ __forceinline__ void gamma_setup_hot(GammaState& g, float a) {
+  g.a = a;
+  g.small = a < 1.0f;
+  g.dd = a - (1.0f / 3.0f);
+  g.c = __builtin_amdgcn_rsqf(9.0f * g.dd);  // garbage for a < 1/3: such elements never use the hot-path result
 }
 
 // Marsaglia-Tsang acceptance for normal x and uniform u; v = (1 + c x)^3.
@@ -101,42 +105,6 @@ __device__ __forceinline__ bool mt_accept(const GammaState& g, float x, float u,
 
 __device__ __forceinline__ float box_muller_radius(uint32_t r) {
   return __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u01(r)));  // sqrt(-2 ln u)
-}
-
-// Rare path: element `elem` was rejected on the pair block; retry on its own counter.
-__device__ __forceinline__ float gamma_retry(const GammaState& g, uint64_t seed, uint32_t elem, uint32_t step, uint64_t traj) {
-  float v = 1.0f;
-  for (uint32_t block = 1; block < 64; ++block) {
-    const u32x4 r = philox_elem(seed, elem, step, traj, block);
-    const float x = box_muller_radius(r.x) * __builtin_amdgcn_cosf(u01(r.y));
-    if (mt_accept(g, x, u01(r.z), v)) return v;
-  }
-  return 1.0f;  // never reached in practice
-}
-
-// Gamma variates for elements elem0 and elem1 (the second one only if has1); the pair block is keyed by elem0.
-__device__ __forceinline__ void gamma_pair_strided(const GammaState& g0, const GammaState& g1, bool has1, uint64_t seed,
-                                                   uint32_t elem0, uint32_t elem1, uint32_t step, uint64_t traj, float& y0,
-                                                   float& y1) {
-  const u32x4 r = philox_elem(seed, elem0, step, traj, 0);
-  const float rad = box_muller_radius(r.x);
-  const float ang = u01(r.y);
-  float v0, v1;
-  const bool ok0 = mt_accept(g0, rad * __builtin_amdgcn_cosf(ang), u01(r.z), v0);
-  const bool ok1 = mt_accept(g1, rad * __builtin_amdgcn_sinf(ang), u01(r.w), v1);
-  if (!ok0) v0 = gamma_retry(g0, seed, elem0, step, traj);
-  if (has1 && !ok1) v1 = gamma_retry(g1, seed, elem1, step, traj);
-  y0 = g0.dd * v0;
-  y1 = g1.dd * v1;
-  if (g0.small || (has1 && g1.small)) {
-    const u32x4 rb = philox_elem(seed, elem0, step, traj, 0xFFFFu);
-    if (g0.small) y0 *= __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01(rb.x)) * __builtin_amdgcn_rcpf(g0.a));
-    if (g1.small) y1 *= __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01(rb.y)) * __builtin_amdgcn_rcpf(g1.a));
-  }
-}
-__device__ __forceinline__ void gamma_pair(const GammaState& g0, const GammaState& g1, bool has1, uint64_t seed,
-                                           uint32_t elem0, uint32_t step, uint64_t traj, float& y0, float& y1) {
-  gamma_pair_strided(g0, g1, has1, seed, elem0, elem0 + 1u, step, traj, y0, y1);
 }
 
 // ---------------------------------------------------------------------------
@@ -201,26 +169,7 @@ __device__ __forceinline__ float gamma_exact_path(const GammaState& g, float x, 
   return 1.0f;  // never reached in practice
 }
 
-// Gamma(shape) variate from the normal x and the 12 leading bits kf of its acceptance uniform.
-__device__ __forceinline__ float gamma_from_normal(const GammaState& g, float x, float kf, uint64_t seed, uint32_t elem,
-                                                   uint32_t step, uint64_t traj) {
-  const float t = g.c * x;
-  const float t2 = t * t;
-  const float x2 = x * x;
-  float v = 1.0f + t * (3.0f + t * (3.0f + t));
-  const float thr = fmaf(-x2, fmaf(t2, 0.19f, 1e-6f), 1.0f);
-  const bool sure = (t2 <= 0.25f) && (kf + 1.0f <= thr * 4096.0f);
-  if (!sure) v = gamma_exact_path(g, x, kf, seed, elem, step, traj);
-  float y = g.dd * v;
-  if (g.small) {
-    const u32x4 rb = philox_elem(seed, elem, step, traj, 0xFFFFu);
-    y *= __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01(rb.x)) * __builtin_amdgcn_rcpf(g.a));
-    if (y == 0.0f) y = ZERO_GAMMA_REPLACEMENT;  // underflow of the boost (mfg_ac2.py:244); y > 0 otherwise
-  }
-  return y;
-}
-
-// Branch-free half of gamma_from_normal for the interleaved quad loops: v = (1 + c x)^3 and whether the 12 leading
+// Branch-free hot half of the quad sampler: v = (1 + c x)^3 and whether the 12 leading
 // acceptance bits already decide the draw.
 __device__ __forceinline__ float gamma_try(const GammaState& g, float x, float kf, bool& sure) {
 #ifdef MFG_ABL_TRY
@@ -238,24 +187,18 @@ __device__ __forceinline__ float gamma_try(const GammaState& g, float x, float k
 // Cold half: exact continuation and the shape < 1 boost; returns the variate.
 __device__ __forceinline__ float gamma_fix(const GammaState& g, float x, float kf, bool sure, float v, uint64_t seed,
                                            uint32_t elem, uint32_t step, uint64_t traj) {
-  if (!sure) v = gamma_exact_path(g, x, kf, seed, elem, step, traj);
-  float y = g.dd * v;
   if (g.small) {
+    // shape < 1: Gamma(a) = Gamma(a + 1) U^(1/a); the boosted draw runs the exact test from the start
+    GammaState gb;
+    gamma_setup(gb, g.a);
+    v = gamma_exact_path(gb, x, kf, seed, elem, step, traj);
     const u32x4 rb = philox_elem(seed, elem, step, traj, 0xFFFFu);
-    y *= __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01(rb.x)) * __builtin_amdgcn_rcpf(g.a));
-    if (y == 0.0f) y = ZERO_GAMMA_REPLACEMENT;
+    float y = gb.dd * v * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01(rb.x)) * __builtin_amdgcn_rcpf(g.a));
+    if (y == 0.0f) y = ZERO_GAMMA_REPLACEMENT;  // underflow of the boost (mfg_ac2.py:244)
+    return y;
   }
-  return y;
-}
-
-// Two elements of one Box-Muller pair h of the quad (the second one only if has1).
-__device__ __forceinline__ void gamma_pair_q(const GammaState& g0, const GammaState& g1, bool has1, const QuadRand& q, int h,
-                                             uint64_t seed, uint32_t elem0, uint32_t elem1, uint32_t step, uint64_t traj,
-                                             float& y0, float& y1) {
-  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(q.radu[h]));
-  y0 = gamma_from_normal(g0, rad * __builtin_amdgcn_cosf(q.ang[h]), q.kf[2 * h], seed, elem0, step, traj);
-  y1 = 1.0f;
-  if (has1) y1 = gamma_from_normal(g1, rad * __builtin_amdgcn_sinf(q.ang[h]), q.kf[2 * h + 1], seed, elem1, step, traj);
+  if (!sure) v = gamma_exact_path(g, x, kf, seed, elem, step, traj);
+  return g.dd * v;
 }
 
 // ---------------------------------------------------------------------------
@@ -414,25 +357,6 @@ __device__ __forceinline__ void theta_times_x(const ThetaSplit& t, float pj, flo
   x = (pj - pi) - t.sh;
   zh = t.th * x;
   zl = fmaf(t.th, x, -zh) + fmaf(t.tl, x, -t.c0);
-}
-
-__device__ __forceinline__ float digamma_pos_fast(float x) {
-  float corr = 0.0f;
-  if (x < 8.0f) {
-    float q = x, qp = 1.0f;
-#pragma unroll
-    for (int k = 1; k < 8; ++k) {
-      const float xk = x + (float)k;
-      qp = fmaf(qp, xk, q);
-      q = q * xk;
-    }
-    corr = qp * __builtin_amdgcn_rcpf(q);
-    x += 8.0f;
-  }
-  const float inv = __builtin_amdgcn_rcpf(x);
-  const float inv2 = inv * inv;
-  const float s = inv2 * (1.0f / 12.0f - inv2 * (1.0f / 120.0f - inv2 * (1.0f / 252.0f)));
-  return fast_ln(x) - 0.5f * inv - s - corr;
 }
 
 // ---------------------------------------------------------------------------
