@@ -325,8 +325,8 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
   const double theta = *a.theta;
   const ThetaSplit ts = theta_split(theta, a.shift);
   const float inv_d = 1.0f / (float)d;
-  // mixed sampling kernels: separable e^z = E_j F_i (mfg_device.h).  The factors leave the fp32 range beyond
-  // |theta| (1 + |shift|) ~ 85 and the outputs then turn NaN -- loudly; precision 'f64' has no such limit.
+  // mixed sampling kernels: separable e^z = E_j F_i (mfg_device.h).  The factors leave the fp32 range when
+  // |theta| (max_j pi_j + |shift|) exceeds ~88 and the outputs then turn NaN -- loudly; precision 'f64' has no such limit.
   constexpr bool sep = SAMPLE && FAST;
   if (want_v) {
     if (CIRC) {

@@ -660,3 +660,31 @@ def test_grad_accumulate_all_kernels(dev, d, B, T, add_reward):
     # accumulate = True adds onto G
     o_.grad_accumulate(traj, de.clone(), g, r, G, ws, T=T, accumulate=True)
     assert float((G[:Q] - 2 * ref[:Q]).abs().max()) <= 1e-12 * max(scale, 1e-300)
+
+
+def test_mixed_sampler_range_of_the_separable_exponential(dev):
+    """Mixed precision forms e^{theta (pi_j - pi_i - shift)} as E_j F_i (fp32 factors).  Inside its documented range,
+    |theta| (1 + |shift|) <~ 85, the sampler is still exact (KS on Beta marginals at theta = 40, where E_j spans
+    1 .. 2e17); beyond it the factors leave the fp32 range and the output must turn non-finite -- loudly -- while
+    precision 'f64' has no such limit."""
+    from scipy import stats
+    d, B = 6, 20000
+    pi1 = np.array([0.05, 0.3, 0.1, 0.35, 0.15, 0.05], dtype=np.float32)
+    pi = np.repeat(pi1[None], B, 0)
+    theta, shift, scale = 40.0, 0.1, 50.0
+    P = ops().sample_dirichlet(t32(pi, dev), t64([theta], dev), shift, scale, seed=11, precision='mixed').cpu().numpy().astype(np.float64)
+    assert np.all(np.isfinite(P)) and np.allclose(P.sum(-1), 1.0, atol=1e-5)
+    al = O().calc_alpha(pi1.astype(np.float64), theta, shift) * scale
+    for (i, j) in [(0, 3), (3, 0), (1, 3), (2, 2)]:
+        a, b = al[i, j], al[i].sum() - al[i, j]
+        if a < 1e-3:
+            continue                                              # numerically a point mass at 0: nothing to test
+        ks = stats.kstest(P[:, i, j], stats.beta(a, b).cdf)
+        assert ks.pvalue > 1e-4, (i, j, a, b, ks)
+    # theta * max(pi) = 97 > ln(fp32 max) = 88.7: E_0 overflows
+    big = t64([100.0], dev)
+    peaked = np.repeat(np.array([[0.97, 0.006, 0.006, 0.006, 0.006, 0.006]], dtype=np.float32), 64, 0)
+    Pm = ops().sample_dirichlet(t32(peaked, dev), big, shift, scale, seed=11, precision='mixed')
+    assert not bool(torch.isfinite(Pm).all())                     # out of range: NaN, not a silently wrong sample
+    Pf = ops().sample_dirichlet(t32(peaked, dev), big, shift, scale, seed=11, precision='f64')
+    assert bool(torch.isfinite(Pf).all()) and bool((Pf.sum(-1) - 1).abs().max() < 1e-5)
