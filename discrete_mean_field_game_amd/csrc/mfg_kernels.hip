@@ -440,7 +440,50 @@ __global__ __launch_bounds__(BLOCK, (PER <= 6 ? MFG_STEP_WAVES : 4)) void k_step
 // and the per-trajectory reward sum goes through the wave's LDS region (dead after its column walk) instead of a
 // shuffle tree.  Same arithmetic and summation order as k_core_small's column pass.
 // ---------------------------------------------------------------------------------------------
-template <int KIND, int D>
+// Prefetch of tile TT (the G trajectories' slab, as 16-byte words of its enclosing aligned window) into pre[] / prepi.
+// MFG_WAVE_PREFETCH: B is a multiple of lcm(G, 4) (the launcher splits off the remainder), so every tile is full and
+// the slab is a whole number of 16-byte words: every word of a window lies inside it, the first PER-1 loads are
+// unconditional and issue back to back; the last one clamps its lane's word index to the window.  (With per-load lane
+// tests, partial register writes or a second code path for partial tiles the compiler serialised the loads with
+// s_waitcnt vmcnt(0), or waited for the prefetch right after issuing it in order to copy the whole pre[] tuple through
+// a phi -- 2x on the low-occupancy batched kernel.)
+#define MFG_WAVE_PREFETCH(TT)                                                             \
+  {                                                                                       \
+    const int64_t f0 = (TT) * (int64_t)(G * DD);                                          \
+    const int pn4 = (int)(((f0 & 3) + (int64_t)(G * DD) + 3) >> 2);                       \
+    const v4f_t* src = P4 + (f0 >> 2);                                                    \
+    _Pragma("unroll") for (int u = 0; u < PER; ++u) {                                     \
+      /* every load unconditional (no phi over pre[]): lanes past the window re-read its last word */ \
+      const int k = lane + u * WAVE;                                                      \
+      pre[u] = MFG_STREAM_LOAD(src + (((u + 1) * WAVE <= ((G * DD) >> 2)) ? k : (k < pn4 ? k : pn4 - 1))); \
+    }                                                                                     \
+    prepi = pi[(TT) * (int64_t)(G * D) + (lane < G * D ? lane : G * D - 1)];              \
+  }
+// MFG_WAVE_PREFETCH_RAG: any B (the tail launch): word addresses clamped to the slab, the 1..3 floats after its last
+// whole word are patched into LDS by MFG_WAVE_TAIL.
+#define MFG_WAVE_PREFETCH_RAG(TT)                                                             \
+  {                                                                                       \
+    const int64_t f0 = (TT) * (int64_t)(G * DD);                                          \
+    const int64_t a4 = f0 >> 2;                                                           \
+    const int png = (int)((B - (TT) * G) < G ? (B - (TT) * G) : G);                       \
+    const int pn4 = (int)(((f0 & 3) + (int64_t)png * DD + 3) >> 2);                       \
+    _Pragma("unroll") for (int u = 0; u < PER; ++u) {                                     \
+      const int k = lane + u * WAVE;                                                      \
+      pre[u] = (v4f_t)(0.0f);                                                             \
+      /* whole words only, address clamped to the slab: no partial register writes, so the PER loads issue back to  \
+         back; the 1..3 floats after the last whole word are patched into LDS by MFG_WAVE_TAIL */                    \
+      if (k < pn4) pre[u] = MFG_STREAM_LOAD(P4 + ((a4 + k) < total4 ? (a4 + k) : total4 - 1));                    \
+    }                                                                                     \
+    prepi = (lane < png * D) ? pi[(TT) * (int64_t)(G * D) + lane] : 0.0f;                 \
+  }
+// The 1..3 floats after the slab's last whole 16-byte word (B d^2 not a multiple of 4) belong to the LAST tile only: its
+// wave copies them into its LDS window after the vector staging (wave-uniform test, off the hot path).
+#define MFG_WAVE_TAIL(TT)                                                                  \
+  if ((TT) == ntiles - 1 && ((B * DD) & 3)) {                                              \
+    const int64_t w0 = total4 << 2;                                                        \
+    if (lane < (int)((B * DD) & 3)) wP[(int)(w0 - ((((TT) * (int64_t)(G * DD)) >> 2) << 2)) + lane] = P[w0 + lane]; \
+  }
+template <int KIND, int D, bool RAG>
 __global__ __launch_bounds__(BLOCK, MFG_STEP_WAVES) void k_step_wave(const float* __restrict__ pi, const float* __restrict__ P,
                                                                       int64_t B, float* __restrict__ pi_next,
                                                                       float* __restrict__ reward) {
@@ -449,7 +492,8 @@ __global__ __launch_bounds__(BLOCK, MFG_STEP_WAVES) void k_step_wave(const float
   constexpr int PER = (WF / 4 + WAVE - 1) / WAVE;       // 16-byte loads per lane per tile
   __shared__ __attribute__((aligned(16))) float sP[WAVES][WF];
   __shared__ float sQ[WAVES][G * D];
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE);  // wave-uniform by construction: keeps the tile bookkeeping scalar
   const int t = lane / D, j = lane - t * D;
   float* wP = sP[wv];
   float* wQ = sQ[wv];
@@ -459,31 +503,10 @@ __global__ __launch_bounds__(BLOCK, MFG_STEP_WAVES) void k_step_wave(const float
   v4f_t pre[PER];
   float prepi = 0.0f;
   const v4f_t* P4 = reinterpret_cast<const v4f_t*>(P);
-#define MFG_WAVE_PREFETCH(TT)                                                             \
-  {                                                                                       \
-    const int64_t f0 = (TT) * (int64_t)(G * DD);                                          \
-    const int64_t a4 = f0 >> 2;                                                           \
-    const int png = (int)((B - (TT) * G) < G ? (B - (TT) * G) : G);                       \
-    const int pn4 = (int)(((f0 & 3) + (int64_t)png * DD + 3) >> 2);                       \
-    _Pragma("unroll") for (int u = 0; u < PER; ++u) {                                     \
-      const int k = lane + u * WAVE;                                                      \
-      pre[u] = (v4f_t)(0.0f);                                                             \
-      if (k < pn4) {                                                                      \
-        const int64_t g4 = a4 + k;                                                        \
-        if (g4 < total4) {                                                                \
-          pre[u] = MFG_STREAM_LOAD(P4 + g4);                                              \
-        } else { /* ragged last word of the whole slab */                                 \
-          const int64_t e0 = g4 << 2, tot = B * DD;                                       \
-          if (e0 < tot) pre[u].x = P[e0];                                                 \
-          if (e0 + 1 < tot) pre[u].y = P[e0 + 1];                                         \
-          if (e0 + 2 < tot) pre[u].z = P[e0 + 2];                                         \
-        }                                                                                 \
-      }                                                                                   \
-    }                                                                                     \
-    prepi = (lane < png * D) ? pi[(TT) * (int64_t)(G * D) + lane] : 0.0f;                 \
-  }
   int64_t tile = (int64_t)blockIdx.x * WAVES + wv;
-  if (tile < ntiles) MFG_WAVE_PREFETCH(tile)
+  if (tile < ntiles) {
+    if (RAG) MFG_WAVE_PREFETCH_RAG(tile) else MFG_WAVE_PREFETCH(tile)
+  }
   for (; tile < ntiles; tile += nwaves) {
     const int ng = (int)((B - tile * G) < G ? (B - tile * G) : G);
     const int off = (int)((tile * (int64_t)(G * DD)) & 3);   // position of the slab inside its aligned window
@@ -494,9 +517,12 @@ __global__ __launch_bounds__(BLOCK, MFG_STEP_WAVES) void k_step_wave(const float
       if (k < WF / 4) d4[k] = pre[u];
     }
     if (lane < G * D) wQ[lane] = prepi;
+    if (RAG) MFG_WAVE_TAIL(tile)
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    if (tile + nwaves < ntiles) MFG_WAVE_PREFETCH(tile + nwaves)
+    if (tile + nwaves < ntiles) {
+      if (RAG) MFG_WAVE_PREFETCH_RAG(tile + nwaves) else MFG_WAVE_PREFETCH(tile + nwaves)
+    }
     const bool valid = (t < G) && (t < ng);
     const int tc = valid ? t : 0;
     const float* colp = wP + off + tc * DD + j;
@@ -543,7 +569,155 @@ __global__ __launch_bounds__(BLOCK, MFG_STEP_WAVES) void k_step_wave(const float
       __builtin_amdgcn_wave_barrier();
     }
   }
-#undef MFG_WAVE_PREFETCH
+}
+
+// ---------------------------------------------------------------------------------------------
+// a3+a4, d = 21 / 15, LARGE batches: k_step_wave with the OUTPUT side rebuilt.  tools/micro/step_lab.hip (round 2) showed
+// that the walk costs 4 % and the 4.5 % of bytes that are written cost 25 %: the same kernel without its stores streams at
+// 6.95 TB/s, with them at 5.5, and with the stores aimed at an L2-resident scratch again at 7.05 -- it is the trickle of
+// small writes reaching HBM in between the reads, not the store instructions.  So here a wave
+//   * takes KB CONSECUTIVE tiles (KB*G trajectories), parks their pi' / rewards in its own LDS stash and writes them out
+//     once per super tile as one contiguous burst of 16-byte stores (KB = 32 at d = 21: 8 KB of pi' per wave),
+//   * issues those stores at device scope (sc1: written through the L2 right away instead of trickling out of it line by
+//     line whenever the cache replaces one),
+//   * and the grid is sized to 8 waves per CU with an equal number of super tiles per wave (the batch costs 42 KB of LDS
+//     per block; more resident waves measured slower with the batched stores, fewer starve the read stream).
+// Same arithmetic, same summation order, bit-identical outputs.  Measured on the 983 040-transition slab: 5.5 -> 6.4 TB/s.
+// A ragged last super tile falls back to per-tile stores.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store16_device_scope(v4f_t* p, v4f_t v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+template <int KIND, int D, int KB>
+__global__ __launch_bounds__(BLOCK, 2) void k_step_wave_batched(const float* __restrict__ pi, const float* __restrict__ P,
+                                                                 int64_t B, float* __restrict__ pi_next,
+                                                                 float* __restrict__ reward) {
+  constexpr int G = WAVE / D, DD = D * D;
+  constexpr int WF = ((G * DD + 6 + 3) / 4) * 4;
+  constexpr int PER = (WF / 4 + WAVE - 1) / WAVE;
+  constexpr int NO = KB * G * D, NR = KB * G;          // floats of pi' / rewards per super tile
+  constexpr bool REW = KIND != MFG_REWARD_EXTERNAL;
+  static_assert(NO % 4 == 0 && NR % 4 == 0, "a super tile's outputs must be whole 16-byte words");
+  __shared__ __attribute__((aligned(16))) float sP[WAVES][WF];
+  __shared__ float sQ[WAVES][G * D];
+  __shared__ __attribute__((aligned(16))) float sO[WAVES][NO];
+  __shared__ __attribute__((aligned(16))) float sR[WAVES][NR];
+  __shared__ double sL[WAVES][G * (D + 1)];  // per-trajectory line of the column terms of the reward
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE);  // wave-uniform by construction: keeps the tile bookkeeping scalar
+  const int t = lane / D, j = lane - t * D;
+  const bool valid = t < G;  // every tile is full (B is a multiple of G)
+  const int tc = valid ? t : 0;
+  float* wP = sP[wv];
+  float* wQ = sQ[wv];
+  float* wO = sO[wv];
+  float* wR = sR[wv];
+  double* line = sL[wv] + tc * (D + 1);
+  const int64_t ntiles = (B + G - 1) / G;
+  const int64_t nsuper = (ntiles + KB - 1) / KB;
+  const int64_t nwaves = (int64_t)gridDim.x * WAVES;
+  v4f_t pre[PER];
+  float prepi = 0.0f;
+  const v4f_t* P4 = reinterpret_cast<const v4f_t*>(P);
+  int64_t sup = (int64_t)blockIdx.x * WAVES + wv;
+  if (sup * KB < ntiles) MFG_WAVE_PREFETCH(sup * KB)
+  for (; sup < nsuper; sup += nwaves) {
+    const bool full = (sup + 1) * (int64_t)(KB * G) <= B;  // every trajectory of the super tile exists: batched stores
+    int oo = lane, ro = 0;  // running stash offsets of the tile (no per-tile multiply)
+    int kk = 0;
+#pragma unroll 1
+    for (; kk < KB; ++kk, oo += G * D, ro += G) {
+      const int64_t tile = sup * KB + kk;
+      if (tile >= ntiles) break;  // wave-uniform (last super tile only)
+      const int off = (int)((tile * (int64_t)(G * DD)) & 3);
+      v4f_t* d4 = reinterpret_cast<v4f_t*>(wP);
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int k = lane + u * WAVE;
+        if (k < WF / 4) d4[k] = pre[u];
+      }
+      if (lane < G * D) wQ[lane] = prepi;
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      {
+        const int64_t nxt = (kk + 1 < KB && tile + 1 < ntiles) ? tile + 1 : (sup + nwaves) * KB;
+        if (nxt < ntiles) MFG_WAVE_PREFETCH(nxt)
+      }
+      const float* colp = wP + off + tc * DD + j;
+      const float* qv = wQ + tc * D;
+      double acc = 0.0, s1 = 0.0, s2 = 0.0;
+      // The reward of the PREVIOUS tile is summed here, one line entry per row of this tile's walk, by every lane of
+      // the trajectory (broadcast reads; the VALU is idle anyway): the per-tile serial phase of k_step_wave -- two wave
+      // barriers and 21 dependent adds on one lane -- disappears into the walk.  Same order: even terms, odd terms.
+      double r0 = 0.0, r1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const double p = (double)colp[i * D];
+        const double qx = (double)qv[i];
+        const double u = p * qx;
+        acc += u;
+        if (REW) {
+          s1 = fma(u, p, s1);
+          if (KIND == MFG_REWARD_MFG_AC2) s2 = fma(u, u, s2);
+          if (i & 1) r1 += line[i];
+          else r0 += line[i];
+        }
+      }
+      double racc = 0.0;
+      if (KIND == MFG_REWARD_MFG_AC2) racc = fma((double)qv[j], s1, -s2);
+      if (KIND == MFG_REWARD_SYNTHETIC) racc = s1;
+      const int64_t b = tile * G + tc;
+      if (full) {
+        if (valid) wO[oo] = (float)acc;
+      } else if (valid) {
+        pi_next[b * D + j] = (float)acc;
+      }
+      if (REW) {
+        if (kk > 0 && valid) {  // the previous tile's reward (stash: every lane of the trajectory writes the same value,
+          double r = r0 + r1;   // so the sums above stay in the walk instead of sinking into a one-lane branch)
+          if (KIND == MFG_REWARD_SYNTHETIC) r *= -0.5;
+          if (full) wR[ro - G + tc] = (float)r;
+          else if (j == 0) reward[b - G] = (float)r;
+        }
+        __builtin_amdgcn_wave_barrier();  // every lane has read the line (LDS operations of a wave execute in order)
+        if (valid) line[j] = racc;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (REW && kk > 0) {
+      // the super tile's last reward: the one serial sum left
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      if (valid && j == 0) {
+        double r0 = 0.0, r1 = 0.0;
+        int k = 0;
+#pragma unroll 4
+        for (; k + 1 < D; k += 2) {
+          r0 += line[k];
+          r1 += line[k + 1];
+        }
+        if (k < D) r0 += line[k];
+        double r = r0 + r1;
+        if (KIND == MFG_REWARD_SYNTHETIC) r *= -0.5;
+        if (full) wR[ro - G + tc] = (float)r;
+        else reward[(sup * KB + kk - 1) * G + tc] = (float)r;
+      }
+    }
+    if (full) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      v4f_t* o4 = reinterpret_cast<v4f_t*>(pi_next + sup * (int64_t)NO);
+      const v4f_t* s4 = reinterpret_cast<const v4f_t*>(wO);
+      for (int k = lane; k < NO / 4; k += WAVE) store16_device_scope(o4 + k, s4[k]);
+      if (REW) {
+        v4f_t* r4 = reinterpret_cast<v4f_t*>(reward + sup * (int64_t)NR);
+        const v4f_t* sr4 = reinterpret_cast<const v4f_t*>(wR);
+        for (int k = lane; k < NR / 4; k += WAVE) store16_device_scope(r4 + k, sr4[k]);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
 }
 
 // Fallback for a P pointer that is not 16-byte aligned: scalar staging, no prefetch.
@@ -1583,6 +1757,18 @@ int mfg_philox_raw(uint64_t seed, uint32_t first_ctr, uint32_t c1, uint32_t c2, 
   return check_launch("philox_raw");
 }
 
+// developer knob (tools/step_probe.py): MFG_STEP_BATCH = 0 | 8 | 16 | 32 forces the tiles per super tile of the d = 21 / 15
+// given-P kernel (0 = per-tile stores); unset / anything else = chosen from the batch size
+static int step_batch_override() {
+  static const int v = [] {
+    const char* e = getenv("MFG_STEP_BATCH");
+    if (!e || !*e) return -1;
+    const int k = atoi(e);
+    return (k == 0 || k == 8 || k == 16 || k == 32) ? k : -1;
+  }();
+  return v;
+}
+
 int mfg_step_given_P(const float* pi, const float* P, int64_t B, int d, int reward_kind, float* pi_next, float* reward,
                      mfg_stream_t stream) {
   CHECK_BD();
@@ -1619,21 +1805,69 @@ int mfg_step_given_P(const float* pi, const float* P, int64_t B, int d, int rewa
 #ifdef MFG_STEP_BLOCK_TILES
       if (d == 21) { STEP_SMALL_D(21, 6) } else { STEP_SMALL_D(15, 4) }
 #else
-      const int gw = grid_for(B, (WAVE / d) * WAVES, MFG_STEP_WAVES);
-#define STEP_WAVE(K, DD) hipLaunchKernelGGL((k_step_wave<K, DD>), dim3(gw), dim3(BLOCK), 0, st, pi, P, B, pi_next, reward)
-      if (d == 21) {
-        switch (reward_kind) {
-          case 0: STEP_WAVE(0, 21); break;
-          case 1: STEP_WAVE(1, 21); break;
-          default: STEP_WAVE(2, 21); break;
+      // The main launch covers B4 = B - B mod lcm(G, 4) trajectories (full tiles only and a whole number of 16-byte words
+      // of P, so its prefetch needs no partial-tile / end-of-slab handling); the remaining < 12 trajectories go through
+      // the ragged-capable instantiation.
+      const int G = WAVE / d;
+      const int64_t unit = (G % 4 == 0) ? G : (G % 2 == 0 ? 2 * G : 4 * G);
+      const int64_t B4 = B - B % unit;
+#define STEP_WAVE(K, DD, RAG, GRID, PI, PP, NB, PN, RW) \
+  hipLaunchKernelGGL((k_step_wave<K, DD, RAG>), dim3(GRID), dim3(BLOCK), 0, st, PI, PP, NB, PN, RW)
+#define STEP_WAVE_K(DD, RAG, GRID, PI, PP, NB, PN, RW)                    \
+  switch (reward_kind) {                                                   \
+    case 0: STEP_WAVE(0, DD, RAG, GRID, PI, PP, NB, PN, RW); break;        \
+    case 1: STEP_WAVE(1, DD, RAG, GRID, PI, PP, NB, PN, RW); break;        \
+    default: STEP_WAVE(2, DD, RAG, GRID, PI, PP, NB, PN, RW); break;       \
+  }
+      if (B4 > 0) {
+        // Large batches: consecutive-tile super tiles with batched device-scope stores (k_step_wave_batched), as soon as
+        // every one of the 8 waves per CU gets >= 2 super tiles; KB = tiles per super tile, the largest that qualifies.
+        const int64_t ntiles = (B4 + G - 1) / G;
+        const int64_t nw_target = (int64_t)num_cus() * 2 * WAVES;
+        int kb = 0;
+        for (int cand : {32, 16, 8}) {  // >= 2 super tiles per wave, and the last round >= 90 % full
+          const int64_t ns = (ntiles + cand - 1) / cand, rr = (ns + nw_target - 1) / nw_target;
+          if (!kb && rr >= 2 && 10 * ns >= 9 * rr * nw_target) kb = cand;
         }
-      } else {
-        switch (reward_kind) {
-          case 0: STEP_WAVE(0, 15); break;
-          case 1: STEP_WAVE(1, 15); break;
-          default: STEP_WAVE(2, 15); break;
+        const int forced = step_batch_override();  // developer knob: MFG_STEP_BATCH = 0 (never) | 8 | 16 | 32
+        if (forced >= 0) kb = forced;
+        const bool out16 = (((uintptr_t)pi_next & 15) == 0) && (((uintptr_t)reward & 15) == 0);
+        if (kb && out16) {
+          const int64_t nsuper = (ntiles + kb - 1) / kb;
+          const int64_t rounds = (nsuper + nw_target - 1) / nw_target;
+          const int64_t nwv = (nsuper + rounds - 1) / rounds;
+          const int gb = (int)((nwv + WAVES - 1) / WAVES);
+#define STEP_WAVE_B(K, DD, KB) \
+  hipLaunchKernelGGL((k_step_wave_batched<K, DD, KB>), dim3(gb), dim3(BLOCK), 0, st, pi, P, B4, pi_next, reward)
+#define STEP_WAVE_BK(DD, KB)                    \
+  switch (reward_kind) {                        \
+    case 0: STEP_WAVE_B(0, DD, KB); break;      \
+    case 1: STEP_WAVE_B(1, DD, KB); break;      \
+    default: STEP_WAVE_B(2, DD, KB); break;     \
+  }
+          if (d == 21) {
+            if (kb == 32) { STEP_WAVE_BK(21, 32) } else if (kb == 16) { STEP_WAVE_BK(21, 16) } else { STEP_WAVE_BK(21, 8) }
+          } else {
+            if (kb == 32) { STEP_WAVE_BK(15, 32) } else if (kb == 16) { STEP_WAVE_BK(15, 16) } else { STEP_WAVE_BK(15, 8) }
+          }
+#undef STEP_WAVE_BK
+#undef STEP_WAVE_B
+        } else {
+          const int gw = grid_for(B4, G * WAVES, MFG_STEP_WAVES);
+          if (d == 21) { STEP_WAVE_K(21, false, gw, pi, P, B4, pi_next, reward) }
+          else { STEP_WAVE_K(15, false, gw, pi, P, B4, pi_next, reward) }
         }
       }
+      if (B > B4) {
+        const float* pi_t = pi + B4 * d;
+        const float* P_t = P + B4 * d * d;   // 16-byte aligned: B4 is a multiple of 4
+        float* pn_t = pi_next + B4 * d;
+        float* rw_t = reward ? reward + B4 : nullptr;
+        const int64_t Bt = B - B4;
+        if (d == 21) { STEP_WAVE_K(21, true, 1, pi_t, P_t, Bt, pn_t, rw_t) }
+        else { STEP_WAVE_K(15, true, 1, pi_t, P_t, Bt, pn_t, rw_t) }
+      }
+#undef STEP_WAVE_K
 #undef STEP_WAVE
 #endif
     }

@@ -315,3 +315,34 @@ def test_matrix_core_values_equal_in_kernel_values(dev, d, B, T):
     disc = 0.9 ** np.arange(T)
     want = a['reward'].cpu().numpy().astype(np.float64) + disc[None, :] * V[:, 1:] - V[:, :-1]
     assert np.max(np.abs(a['delta'].cpu().numpy() - want)) <= 1e-11 * np.max(np.abs(V))
+
+
+@pytest.mark.parametrize('d,B', [(21, 96000 + 7), (21, 192000 + 5), (21, 384000 + 50), (21, 983040), (15, 128000 + 1), (15, 512000 + 3)])
+def test_given_P_batched_store_kernel_equals_per_tile_kernel(dev, d, B):
+    """Large batches take k_step_wave_batched (KB consecutive tiles per wave, outputs parked in LDS and written as one
+    device-scope burst per super tile, the reward line summed inside the next tile's walk; KB = 8 / 16 / 32 by batch size on
+    a 256-CU device; the last B mod 12 trajectories go through the ragged-capable per-tile kernel).  It must reproduce, bit
+    for bit, what the per-tile kernel gives on the same trajectories (calls on chunks small enough to stay on k_step_wave),
+    for both reward kinds and the reward-less call, including the ragged last super tile; a slice is checked against the
+    oracle."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(B)
+    pi = torch.rand(B, d, device=dev, generator=g)
+    pi = (pi / pi.sum(1, keepdim=True)).contiguous()
+    P = torch.rand(B, d, d, device=dev, generator=g)
+    P /= P.sum(-1, keepdim=True)
+    chunk = 40000   # < 3 super tiles per wave for every KB: per-tile kernel
+    for kind in (0, 1):
+        pn, r = ops().step_given_P(pi, P, reward_kind=kind)
+        for s in range(0, B, chunk):
+            e = min(B, s + chunk)
+            pn_c, r_c = ops().step_given_P(pi[s:e], P[s:e], reward_kind=kind)
+            assert torch.equal(pn[s:e], pn_c) and torch.equal(r[s:e], r_c), (kind, s)
+    pn2, none = ops().step_given_P(pi, P, want_reward=False)
+    assert none is None and torch.equal(pn2, pn)
+    sl = slice(B - 300, B)   # the ragged tail + the last full super tiles
+    Pn, pin = P[sl].cpu().numpy().astype(np.float64), pi[sl].cpu().numpy().astype(np.float64)
+    assert np.array_equal(pn[sl].cpu().numpy(), O().transition(Pn, pin).astype(np.float32))
+    r0 = ops().step_given_P(pi, P, reward_kind=0)[1][sl].cpu().numpy()
+    ref = O().calc_reward(Pn, pin)
+    assert np.max(np.abs(r0 - ref) / np.maximum(np.abs(ref), 1e-6)) < 1e-6
