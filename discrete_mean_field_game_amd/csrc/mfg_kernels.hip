@@ -585,8 +585,17 @@ __global__ __launch_bounds__(BLOCK, MFG_STEP_WAVES) void k_step_wave(const float
 // Same arithmetic, same summation order, bit-identical outputs.  Measured on the 983 040-transition slab: 5.5 -> 6.4 TB/s.
 // A ragged last super tile falls back to per-tile stores.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store16_device_scope(v4f_t* p, v4f_t v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+// Device-scope (sc1) stores through the raw-buffer intrinsics (a plain C++ store cannot carry a scope; inline asm would
+// hide the store from the compiler's hazard / waitcnt bookkeeping).  The base must be wave-uniform.
+typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t out_rsrc(void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x27000);  // raw buffer, 32-bit dword format (gfx9 family)
+}
+__device__ __forceinline__ void store16_device_scope(__amdgpu_buffer_rsrc_t r, int byte_off, v4f_t v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, v), r, byte_off, 0, 16 /* sc1 */);
+}
+__device__ __forceinline__ void store4_device_scope(__amdgpu_buffer_rsrc_t r, int byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, byte_off, 0, 16 /* sc1 */);
 }
 template <int KIND, int D, int KB>
 __global__ __launch_bounds__(BLOCK, 2) void k_step_wave_batched(const float* __restrict__ pi, const float* __restrict__ P,
@@ -706,13 +715,13 @@ __global__ __launch_bounds__(BLOCK, 2) void k_step_wave_batched(const float* __r
     if (full) {
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
-      v4f_t* o4 = reinterpret_cast<v4f_t*>(pi_next + sup * (int64_t)NO);
+      const __amdgpu_buffer_rsrc_t ob = out_rsrc(pi_next + sup * (int64_t)NO);
       const v4f_t* s4 = reinterpret_cast<const v4f_t*>(wO);
-      for (int k = lane; k < NO / 4; k += WAVE) store16_device_scope(o4 + k, s4[k]);
+      for (int k = lane; k < NO / 4; k += WAVE) store16_device_scope(ob, k * 16, s4[k]);
       if (REW) {
-        v4f_t* r4 = reinterpret_cast<v4f_t*>(reward + sup * (int64_t)NR);
+        const __amdgpu_buffer_rsrc_t rb = out_rsrc(reward + sup * (int64_t)NR);
         const v4f_t* sr4 = reinterpret_cast<const v4f_t*>(wR);
-        for (int k = lane; k < NR / 4; k += WAVE) store16_device_scope(r4 + k, sr4[k]);
+        for (int k = lane; k < NR / 4; k += WAVE) store16_device_scope(rb, k * 16, sr4[k]);
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
@@ -775,43 +784,88 @@ __global__ __launch_bounds__(BLOCK) void k_step_small_unaligned(const float* __r
 // groups that hold the same columns of different rows are combined with xor-shuffles at the end.
 // ---------------------------------------------------------------------------------------------
 #ifndef MFG_ROWS_UNROLL
-#define MFG_ROWS_UNROLL 8
+#define MFG_ROWS_UNROLL 8   // row groups (1 KiB wave loads) per chunk; two chunks are in flight / in use per wave
 #endif
+#ifndef MFG_ROWS_BPC
+#define MFG_ROWS_BPC 2      // resident blocks per CU the grid is sized for (8 waves per CU)
+#endif
+// Round 2: a CONTINUOUS load stream per wave.  The first version loaded pi, staged it, and only then started the row
+// loads of a trajectory -- two serial memory latencies per trajectory during which the wave streamed nothing (12 % of
+// the time at d = 128, fitted from the d = 128 / 256 rates) -- and ran 32 waves per CU.  Now the rows are consumed in
+// chunks of U row groups from two register buffers (ping-pong): while one chunk is multiplied the next one is in flight,
+// and the chunk after a trajectory's last is the FIRST chunk of the wave's next trajectory, issued before the reduction /
+// stores of the current one; the next trajectory's state is prefetched into registers at the start of the current one.
+// 8 waves per CU (more resident waves measured slower: d = 256 6.5 TB/s at 32 waves/CU, 6.9-7.0 at 8), outputs stored at
+// device scope (sc1).  Per-lane summation order is unchanged (rows in increasing order) => bit-identical results.
 template <int KIND, int LPR>
-__global__ __launch_bounds__(BLOCK) void k_step_rows(const float* __restrict__ pi, const float* __restrict__ P, int64_t B,
-                                                     float* __restrict__ pi_next, float* __restrict__ reward) {
+__global__ __launch_bounds__(BLOCK, 2) void k_step_rows(const float* __restrict__ pi, const float* __restrict__ P, int64_t B,
+                                                        float* __restrict__ pi_next, float* __restrict__ reward) {
   constexpr int d = 4 * LPR, RPW = WAVE / LPR;
+  constexpr int U = MFG_ROWS_UNROLL;
+  constexpr int CPT = d / RPW / U;   // chunks per trajectory
+  constexpr int NQ = d / WAVE;       // state entries per lane
+  static_assert(CPT >= 2 && CPT % 2 == 0, "ping-pong needs an even number of chunks per trajectory");
   __shared__ double2 qs[WAVES][d];  // (pi_i, pi_i^2) fp64 per wave
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE);
   const int sub = lane / LPR, c4 = lane - sub * LPR;
   double2* q = qs[wv];
   const int64_t nw = (int64_t)gridDim.x * WAVES;
-  for (int64_t b = (int64_t)blockIdx.x * WAVES + wv; b < B; b += nw) {
+  int64_t b = (int64_t)blockIdx.x * WAVES + wv;
+  if (b >= B) return;
+  v4f_t va[U], vb[U];
+  float pnx[NQ];
+  // chunk c of trajectory bb -> register buffer BUF (U wave-wide 1 KiB loads)
+#define MFG_ROWS_ISSUE(BUF, bb, c)                                                                          \
+  {                                                                                                         \
+    const v4f_t* src = reinterpret_cast<const v4f_t*>(P + (bb) * (int64_t)d * d) + (c) * (U * WAVE) + lane; \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) BUF[u] = MFG_STREAM_LOAD(src + u * WAVE);                 \
+  }
+#define MFG_ROWS_COMPUTE(BUF, c)                                    \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                   \
+    const double2 qq = q[((c) * U + u) * RPW + sub];                \
+    const float pv[4] = {BUF[u].x, BUF[u].y, BUF[u].z, BUF[u].w};   \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) {                 \
+      const double p = (double)pv[k];                               \
+      acc[k] = fma(p, qq.x, acc[k]);                                \
+      if (KIND != MFG_REWARD_EXTERNAL) {                            \
+        const double pp = p * p;                                    \
+        s1[k] = fma(qq.x, pp, s1[k]);                               \
+        if (KIND == MFG_REWARD_MFG_AC2) s2 = fma(qq.y, pp, s2);     \
+      }                                                             \
+    }                                                               \
+  }
+  // prologue: state of the first trajectory, its first chunk
+#pragma unroll
+  for (int m = 0; m < NQ; ++m) pnx[m] = pi[b * d + lane + m * WAVE];
+  MFG_ROWS_ISSUE(va, b, 0)
+  for (; b < B; b += nw) {
+    const int64_t bn = b + nw;
     __builtin_amdgcn_wave_barrier();
-    for (int c = lane; c < d; c += WAVE) {
-      const double v = (double)pi[b * d + c];
-      q[c] = make_double2(v, v * v);
+#pragma unroll
+    for (int m = 0; m < NQ; ++m) {
+      const double v = (double)pnx[m];
+      q[lane + m * WAVE] = make_double2(v, v * v);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    double acc[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0}, s2 = 0.0;
-    const v4f_t* Pb = reinterpret_cast<const v4f_t*>(P + b * (int64_t)d * d) + c4;
-#pragma unroll MFG_ROWS_UNROLL
-    for (int i0 = 0; i0 < d; i0 += RPW) {
-      const int row = i0 + sub;
-      const v4f_t v = MFG_STREAM_LOAD(Pb + row * LPR);
-      const double2 qq = q[row];
-      const float pv[4] = {v.x, v.y, v.z, v.w};
+    if (bn < B) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const double p = (double)pv[k];
-        acc[k] = fma(p, qq.x, acc[k]);
-        if (KIND != MFG_REWARD_EXTERNAL) {
-          const double pp = p * p;
-          s1[k] = fma(qq.x, pp, s1[k]);
-          if (KIND == MFG_REWARD_MFG_AC2) s2 = fma(qq.y, pp, s2);
-        }
+      for (int m = 0; m < NQ; ++m) pnx[m] = pi[bn * d + lane + m * WAVE];
+    }
+    double acc[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0}, s2 = 0.0;
+#pragma unroll 1
+    for (int c = 0; c < CPT; c += 2) {
+      MFG_ROWS_ISSUE(vb, b, c + 1)
+      MFG_ROWS_COMPUTE(va, c)
+      {
+        // always issued (no phi over the register buffer): the chunk after the wave's very last one re-reads chunk 0
+        const bool more = c + 2 < CPT;
+        const int64_t nb = more ? b : (bn < B ? bn : b);
+        const int nc = more ? c + 2 : 0;
+        MFG_ROWS_ISSUE(va, nb, nc)
       }
+      MFG_ROWS_COMPUTE(vb, c + 1)
     }
 #pragma unroll
     for (int off = LPR; off < WAVE; off <<= 1) {
@@ -822,12 +876,8 @@ __global__ __launch_bounds__(BLOCK) void k_step_rows(const float* __restrict__ p
       }
     }
     if (sub == 0) {
-      float4 o;
-      o.x = (float)acc[0];
-      o.y = (float)acc[1];
-      o.z = (float)acc[2];
-      o.w = (float)acc[3];
-      reinterpret_cast<float4*>(pi_next + b * d)[c4] = o;
+      const v4f_t ov = {(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
+      store16_device_scope(out_rsrc(pi_next + b * d), c4 * 16, ov);
     }
     if (KIND != MFG_REWARD_EXTERNAL) {
       double racc = 0.0;
@@ -838,9 +888,11 @@ __global__ __launch_bounds__(BLOCK) void k_step_rows(const float* __restrict__ p
       if (KIND == MFG_REWARD_MFG_AC2) racc -= s2;
       racc = wave_sum(racc);
       if (KIND == MFG_REWARD_SYNTHETIC) racc *= -0.5;
-      if (lane == 0) reward[b] = (float)racc;
+      if (lane == 0) store4_device_scope(out_rsrc(reward + b), 0, (float)racc);
     }
   }
+#undef MFG_ROWS_ISSUE
+#undef MFG_ROWS_COMPUTE
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1878,7 +1930,7 @@ int mfg_step_given_P(const float* pi, const float* P, int64_t B, int d, int rewa
 #undef STEP_SMALL
   } else {
     const size_t lds = (size_t)WAVES * d * 4;
-    const int grid = grid_for(B, WAVES, 8);
+    const int grid = grid_for(B, WAVES, (d == 128 || d == 256) ? MFG_ROWS_BPC : 8);
     const bool a16 = (((uintptr_t)P & 15) == 0) && (((uintptr_t)pi_next & 15) == 0);
     int vec = 1;
     if (a16 && d % 4 == 0) vec = 4;
