@@ -302,7 +302,7 @@ def main():
             traffic, traffic_src = pmc_traffic('k_step_', d, T, Br)
             roofline = {'bound': 'hbm', 'achieved': gp['achieved_GBs'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': gp['frac'], 'traffic': traffic, 'traffic_source': traffic_src,
-                        'kernel': ('k_step_wave' if d in (21, 15) else 'k_step_small') if d <= 64 else ('k_step_rows' if d in (128, 256) else 'k_step_large'),
+                        'kernel': (('k_step_wave_batched' if gp['transitions'] >= 100000 else 'k_step_wave') if d in (21, 15) else 'k_step_small') if d <= 64 else ('k_step_rows' if d in (128, 256) else 'k_step_large'),
                         'leg': 'given-P transition+reward over %d transitions (P slab %.2f GB)' % (gp['transitions'], gp['slab_GB']),
                         'algorithmic_bytes_per_launch': gp['transitions'] * bytes_per_step,
                         'avg_launch_us': gp['avg_launch_us'], 'env_steps_per_s': gp['env_steps_per_s']}
