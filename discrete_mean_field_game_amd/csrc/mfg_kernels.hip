@@ -789,6 +789,18 @@ __global__ __launch_bounds__(BLOCK) void k_step_small_unaligned(const float* __r
 #ifndef MFG_ROWS_BPC
 #define MFG_ROWS_BPC 2      // resident blocks per CU the grid is sized for (8 waves per CU)
 #endif
+#ifndef MFG_ROWS_KT
+#define MFG_ROWS_KT 8       // consecutive trajectories per wave whose outputs are written as one burst (large batches)
+#endif
+#ifndef MFG_ROWS_ABL_NOREW   // timing ablations (tools/variant.sh): drop the reward sums / the output stores
+#define MFG_ROWS_ABL_NOREW 0
+#endif
+#ifndef MFG_ROWS_ABL_NOSTORE
+#define MFG_ROWS_ABL_NOSTORE 0
+#endif
+#ifndef MFG_ROWS_ABL_NOMATH
+#define MFG_ROWS_ABL_NOMATH 0
+#endif
 // Round 2: a CONTINUOUS load stream per wave.  The first version loaded pi, staged it, and only then started the row
 // loads of a trajectory -- two serial memory latencies per trajectory during which the wave streamed nothing (12 % of
 // the time at d = 128, fitted from the d = 128 / 256 rates) -- and ran 32 waves per CU.  Now the rows are consumed in
@@ -797,7 +809,10 @@ __global__ __launch_bounds__(BLOCK) void k_step_small_unaligned(const float* __r
 // stores of the current one; the next trajectory's state is prefetched into registers at the start of the current one.
 // 8 waves per CU (more resident waves measured slower: d = 256 6.5 TB/s at 32 waves/CU, 6.9-7.0 at 8), outputs stored at
 // device scope (sc1).  Per-lane summation order is unchanged (rows in increasing order) => bit-identical results.
-template <int KIND, int LPR>
+// KT > 1: a wave takes KT CONSECUTIVE trajectories (a super tile), parks their pi' / rewards in its LDS stash and writes
+// them as one contiguous burst (the d = 21 finding: it is the trickle of small writes between the reads that costs
+// bandwidth -- the 0.8 % of bytes written here cost 6 % at d = 128).  KT = 1 (small batches): direct stores.
+template <int KIND, int LPR, int KT>
 __global__ __launch_bounds__(BLOCK, 2) void k_step_rows(const float* __restrict__ pi, const float* __restrict__ P, int64_t B,
                                                         float* __restrict__ pi_next, float* __restrict__ reward) {
   constexpr int d = 4 * LPR, RPW = WAVE / LPR;
@@ -805,14 +820,20 @@ __global__ __launch_bounds__(BLOCK, 2) void k_step_rows(const float* __restrict_
   constexpr int CPT = d / RPW / U;   // chunks per trajectory
   constexpr int NQ = d / WAVE;       // state entries per lane
   static_assert(CPT >= 2 && CPT % 2 == 0, "ping-pong needs an even number of chunks per trajectory");
+  static_assert(KT == 1 || KT % 4 == 0, "a super tile's rewards must be whole 16-byte words");
   __shared__ double2 qs[WAVES][d];  // (pi_i, pi_i^2) fp64 per wave
+  __shared__ __attribute__((aligned(16))) float sO[WAVES][KT > 1 ? KT * d : 4];
+  __shared__ __attribute__((aligned(16))) float sR[WAVES][KT > 1 ? KT : 4];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE);
   const int sub = lane / LPR, c4 = lane - sub * LPR;
   double2* q = qs[wv];
+  float* wO = sO[wv];
+  float* wR = sR[wv];
   const int64_t nw = (int64_t)gridDim.x * WAVES;
-  int64_t b = (int64_t)blockIdx.x * WAVES + wv;
-  if (b >= B) return;
+  const int64_t nsup = (B + KT - 1) / KT;
+  int64_t sup = (int64_t)blockIdx.x * WAVES + wv;
+  if (sup >= nsup) return;
   v4f_t va[U], vb[U];
   float pnx[NQ];
   // chunk c of trajectory bb -> register buffer BUF (U wave-wide 1 KiB loads)
@@ -823,12 +844,16 @@ __global__ __launch_bounds__(BLOCK, 2) void k_step_rows(const float* __restrict_
   }
 #define MFG_ROWS_COMPUTE(BUF, c)                                    \
   _Pragma("unroll") for (int u = 0; u < U; ++u) {                   \
+    if (MFG_ROWS_ABL_NOMATH) {                                      \
+      acc[0] += (double)(BUF[u].x + BUF[u].y + BUF[u].z + BUF[u].w); \
+      continue;                                                     \
+    }                                                               \
     const double2 qq = q[((c) * U + u) * RPW + sub];                \
     const float pv[4] = {BUF[u].x, BUF[u].y, BUF[u].z, BUF[u].w};   \
     _Pragma("unroll") for (int k = 0; k < 4; ++k) {                 \
       const double p = (double)pv[k];                               \
       acc[k] = fma(p, qq.x, acc[k]);                                \
-      if (KIND != MFG_REWARD_EXTERNAL) {                            \
+      if (KIND != MFG_REWARD_EXTERNAL && !MFG_ROWS_ABL_NOREW) {     \
         const double pp = p * p;                                    \
         s1[k] = fma(qq.x, pp, s1[k]);                               \
         if (KIND == MFG_REWARD_MFG_AC2) s2 = fma(qq.y, pp, s2);     \
@@ -836,59 +861,85 @@ __global__ __launch_bounds__(BLOCK, 2) void k_step_rows(const float* __restrict_
     }                                                               \
   }
   // prologue: state of the first trajectory, its first chunk
+  {
+    const int64_t b0 = sup * KT;
 #pragma unroll
-  for (int m = 0; m < NQ; ++m) pnx[m] = pi[b * d + lane + m * WAVE];
-  MFG_ROWS_ISSUE(va, b, 0)
-  for (; b < B; b += nw) {
-    const int64_t bn = b + nw;
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int m = 0; m < NQ; ++m) {
-      const double v = (double)pnx[m];
-      q[lane + m * WAVE] = make_double2(v, v * v);
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    if (bn < B) {
-#pragma unroll
-      for (int m = 0; m < NQ; ++m) pnx[m] = pi[bn * d + lane + m * WAVE];
-    }
-    double acc[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0}, s2 = 0.0;
+    for (int m = 0; m < NQ; ++m) pnx[m] = pi[b0 * d + lane + m * WAVE];
+    MFG_ROWS_ISSUE(va, b0, 0)
+  }
+  for (; sup < nsup; sup += nw) {
+    const bool full = KT > 1 && (sup + 1) * KT <= B;  // every trajectory of the super tile exists: batched stores
 #pragma unroll 1
-    for (int c = 0; c < CPT; c += 2) {
-      MFG_ROWS_ISSUE(vb, b, c + 1)
-      MFG_ROWS_COMPUTE(va, c)
-      {
-        // always issued (no phi over the register buffer): the chunk after the wave's very last one re-reads chunk 0
-        const bool more = c + 2 < CPT;
-        const int64_t nb = more ? b : (bn < B ? bn : b);
-        const int nc = more ? c + 2 : 0;
-        MFG_ROWS_ISSUE(va, nb, nc)
-      }
-      MFG_ROWS_COMPUTE(vb, c + 1)
-    }
+    for (int kk = 0; kk < KT; ++kk) {
+      const int64_t b = sup * KT + kk;
+      if (b >= B) break;  // wave-uniform (last super tile only)
+      // the wave's next trajectory (B = none: the very last chunk issue re-reads this trajectory's chunk 0)
+      const int64_t bn = (kk + 1 < KT && b + 1 < B) ? b + 1 : ((sup + nw) * KT < B ? (sup + nw) * KT : B);
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int off = LPR; off < WAVE; off <<= 1) {
+      for (int m = 0; m < NQ; ++m) {
+        const double v = (double)pnx[m];
+        q[lane + m * WAVE] = make_double2(v, v * v);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      if (bn < B) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        acc[k] += __shfl_xor(acc[k], off, WAVE);
-        if (KIND != MFG_REWARD_EXTERNAL) s1[k] += __shfl_xor(s1[k], off, WAVE);
+        for (int m = 0; m < NQ; ++m) pnx[m] = pi[bn * d + lane + m * WAVE];
+      }
+      double acc[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0}, s2 = 0.0;
+#pragma unroll 1
+      for (int c = 0; c < CPT; c += 2) {
+        MFG_ROWS_ISSUE(vb, b, c + 1)
+        MFG_ROWS_COMPUTE(va, c)
+        {
+          // always issued (no phi over the register buffer): the chunk after the wave's very last one re-reads chunk 0
+          const bool more = c + 2 < CPT;
+          const int64_t nb = more ? b : (bn < B ? bn : b);
+          const int nc = more ? c + 2 : 0;
+          MFG_ROWS_ISSUE(va, nb, nc)
+        }
+        MFG_ROWS_COMPUTE(vb, c + 1)
+      }
+#pragma unroll
+      for (int off = LPR; off < WAVE; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          acc[k] += __shfl_xor(acc[k], off, WAVE);
+          if (KIND != MFG_REWARD_EXTERNAL) s1[k] += __shfl_xor(s1[k], off, WAVE);
+        }
+      }
+      if (sub == 0 && (!MFG_ROWS_ABL_NOSTORE || acc[0] == 123.456)) {
+        const v4f_t ov = {(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
+        if (full) reinterpret_cast<v4f_t*>(wO + kk * d)[c4] = ov;
+        else store16_device_scope(out_rsrc(pi_next + b * d), c4 * 16, ov);
+      }
+      if (KIND != MFG_REWARD_EXTERNAL) {
+        double racc = 0.0;
+        if (sub == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) racc += (KIND == MFG_REWARD_MFG_AC2) ? q[4 * c4 + k].x * s1[k] : s1[k];
+        }
+        if (KIND == MFG_REWARD_MFG_AC2) racc -= s2;
+        racc = wave_sum(racc);
+        if (KIND == MFG_REWARD_SYNTHETIC) racc *= -0.5;
+        if (lane == 0 && (!MFG_ROWS_ABL_NOSTORE || racc == 123.456)) {
+          if (full) wR[kk] = (float)racc;
+          else store4_device_scope(out_rsrc(reward + b), 0, (float)racc);
+        }
       }
     }
-    if (sub == 0) {
-      const v4f_t ov = {(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
-      store16_device_scope(out_rsrc(pi_next + b * d), c4 * 16, ov);
-    }
-    if (KIND != MFG_REWARD_EXTERNAL) {
-      double racc = 0.0;
-      if (sub == 0) {
+    if (full) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      const __amdgpu_buffer_rsrc_t ob = out_rsrc(pi_next + sup * (int64_t)(KT * d));
+      const v4f_t* s4 = reinterpret_cast<const v4f_t*>(wO);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) racc += (KIND == MFG_REWARD_MFG_AC2) ? q[4 * c4 + k].x * s1[k] : s1[k];
-      }
-      if (KIND == MFG_REWARD_MFG_AC2) racc -= s2;
-      racc = wave_sum(racc);
-      if (KIND == MFG_REWARD_SYNTHETIC) racc *= -0.5;
-      if (lane == 0) store4_device_scope(out_rsrc(reward + b), 0, (float)racc);
+      for (int k = lane; k < KT * d / 4; k += WAVE) store16_device_scope(ob, k * 16, s4[k]);
+      if (KIND != MFG_REWARD_EXTERNAL && lane < KT / 4)
+        store16_device_scope(out_rsrc(reward + sup * (int64_t)KT), lane * 16, reinterpret_cast<const v4f_t*>(wR)[lane]);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
     }
   }
 #undef MFG_ROWS_ISSUE
@@ -1937,18 +1988,25 @@ int mfg_step_given_P(const float* pi, const float* P, int64_t B, int d, int rewa
     else if (a16 && d % 2 == 0) vec = 2;
     // keep at most 2 chunks per lane on the vector paths, fall back to narrower vectors otherwise
     int R = (d + WAVE * vec - 1) / (WAVE * vec);
-#define STEP_ROWS(L)                                                                                                    \
-  switch (reward_kind) {                                                                                                \
-    case 0: hipLaunchKernelGGL((k_step_rows<0, L>), dim3(grid), dim3(BLOCK), 0, st, pi, P, B, pi_next, reward); break;  \
-    case 1: hipLaunchKernelGGL((k_step_rows<1, L>), dim3(grid), dim3(BLOCK), 0, st, pi, P, B, pi_next, reward); break;  \
-    default: hipLaunchKernelGGL((k_step_rows<2, L>), dim3(grid), dim3(BLOCK), 0, st, pi, P, B, pi_next, reward); break; \
+#define STEP_ROWS(L, KT, GRID)                                                                                                \
+  switch (reward_kind) {                                                                                                       \
+    case 0: hipLaunchKernelGGL((k_step_rows<0, L, KT>), dim3(GRID), dim3(BLOCK), 0, st, pi, P, B, pi_next, reward); break;     \
+    case 1: hipLaunchKernelGGL((k_step_rows<1, L, KT>), dim3(GRID), dim3(BLOCK), 0, st, pi, P, B, pi_next, reward); break;     \
+    default: hipLaunchKernelGGL((k_step_rows<2, L, KT>), dim3(GRID), dim3(BLOCK), 0, st, pi, P, B, pi_next, reward); break;    \
   }
-    if (a16 && d == 128) {
-      STEP_ROWS(32)
-      return check_launch("step_given_P");
-    }
-    if (a16 && d == 256) {
-      STEP_ROWS(64)
+    if (a16 && (d == 128 || d == 256)) {
+      // super tiles of MFG_ROWS_KT consecutive trajectories (batched output bursts) once every resident wave gets one
+      const bool out16 = (((uintptr_t)pi_next & 15) == 0) && (((uintptr_t)reward & 15) == 0);
+      const int64_t nw_target = (int64_t)num_cus() * MFG_ROWS_BPC * WAVES;
+      const int kt = (out16 && (B + MFG_ROWS_KT - 1) / MFG_ROWS_KT >= nw_target) ? MFG_ROWS_KT : 1;
+      const int64_t nsup = (B + kt - 1) / kt;
+      const int64_t rounds = (nsup + nw_target - 1) / nw_target;
+      const int gr = (int)(((nsup + rounds - 1) / rounds + WAVES - 1) / WAVES);
+      if (d == 128) {
+        if (kt > 1) { STEP_ROWS(32, MFG_ROWS_KT, gr) } else { STEP_ROWS(32, 1, gr) }
+      } else {
+        if (kt > 1) { STEP_ROWS(64, MFG_ROWS_KT, gr) } else { STEP_ROWS(64, 1, gr) }
+      }
       return check_launch("step_given_P");
     }
 #undef STEP_ROWS
