@@ -1461,19 +1461,39 @@ __global__ __launch_bounds__(BLOCK) void k_grad_mfma(GradArgs a, int tpw) {
 // cost a latency-bound triangular loop per state (10 % of the d = 128 training rollout); here they are ~2 nt (nt + 1)
 // matrix instructions per 16 states.  Followed by k_td_delta (delta = r + gamma V' - V).
 // ---------------------------------------------------------------------------------------------
+// Round 2b: the B operand comes from LDS.  Before, every lane fetched its U element from the L2-resident weight vector
+// with 64-bit index arithmetic and a select in front of every matrix instruction (~15 VALU + 1 dependent L2 load per
+// MFMA, the whole of U re-read by every wave for its 16 states): 3-6x the matrix-core time.  Now the block's four waves
+// (64 states) share each 64-row x 16-column piece of U: it is fetched once per block (zero-filled below the diagonal),
+// double-buffered in LDS -- the loads of piece n+1 are issued before the matrix instructions of piece n and committed
+// after them -- and a matrix instruction costs two LDS reads and a convert.
+constexpr int VM_CH = 64;  // rows of U per staged piece
 __global__ __launch_bounds__(BLOCK) void k_value_mfma(const float* __restrict__ pi, int64_t stride_b, int64_t N, int TP1, int d,
                                                       const double* __restrict__ w, double* __restrict__ V) {
   extern __shared__ __attribute__((aligned(16))) float smx[];
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE);
   const int li = lane & 15, lk = lane >> 4;
   const int nt = d >> 4, pitch = d + 4;  // +4 floats: the 16 state rows of an A operand fall on distinct banks
   const int Q = d * (d + 1) / 2;
   float* xs = smx + (size_t)wv * 16 * pitch;
+  double* Bs = reinterpret_cast<double*>(smx + (size_t)WAVES * 16 * pitch);  // [2][VM_CH][16]
   const double invT = 1.0 / (double)TP1;
   const int64_t ngroups = (N + 15) / 16;
-  for (int64_t grp = (int64_t)blockIdx.x * WAVES + wv; grp < ngroups; grp += (int64_t)gridDim.x * WAVES) {
-    const int64_t n0 = grp * 16;
-    __builtin_amdgcn_wave_barrier();
+  const int64_t npass = (ngroups + WAVES - 1) / WAVES;
+  // staging role of this thread: column sc of the tile, rows sr, sr + 16, sr + 32, sr + 48 of the piece
+  const int sc = tid & 15, sr = tid >> 4;
+  double stg[4];
+#define MFG_VM_LOAD(jt_, ch_)                                                              \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
+    const int k = VM_CH * (ch_) + sr + 16 * q, c = 16 * (jt_) + sc;                        \
+    stg[q] = (k <= c) ? w[k * d - (k * (k - 1)) / 2 + (c - k)] : 0.0;                      \
+  }
+#define MFG_VM_COMMIT(buf_)                                                                \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) Bs[((buf_) * VM_CH + sr + 16 * q) * 16 + sc] = stg[q];
+  for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+    const int64_t n0 = (pass * WAVES + wv) * 16;
+    __syncthreads();  // the previous pass is done with Bs
     // stage the 16 state rows (fp32, float4 copies: d is a multiple of 16 and rows are 16-byte aligned when stride_b % 4 == 0)
     for (int e = lane; e < 16 * (d >> 2); e += WAVE) {
       const int q = e / (d >> 2), c4 = e - q * (d >> 2);
@@ -1485,19 +1505,31 @@ __global__ __launch_bounds__(BLOCK) void k_value_mfma(const float* __restrict__ 
       }
       *reinterpret_cast<float4*>(xs + q * pitch + 4 * c4) = v;
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
+    MFG_VM_LOAD(0, 0)
+    MFG_VM_COMMIT(0)
+    __syncthreads();
+    int buf = 0;
     double vs[4] = {0.0, 0.0, 0.0, 0.0};
     for (int jt = 0; jt < nt; ++jt) {
       const int c = (jt << 4) + li;  // this lane's column of the tile
       v4d_t acc = (v4d_t)(0.0);
-      const int ksteps = (jt + 1) << 2;  // rows 0 .. 16 jt + 15 of U, four at a time
+      const int nch = (16 * (jt + 1) + VM_CH - 1) / VM_CH;
+      for (int ch = 0; ch < nch; ++ch) {
+        // the next piece of the sweep: issue its loads now, commit them after this piece's matrix instructions
+        const bool last_ch = ch + 1 == nch;
+        const bool has_next = !last_ch || jt + 1 < nt;
+        const int njt = last_ch ? jt + 1 : jt, nc = last_ch ? 0 : ch + 1;
+        if (has_next) MFG_VM_LOAD(njt, nc)
+        int ksteps = 4 * (jt + 1) - (VM_CH / 4) * ch;  // rows 0 .. 16 jt + 15 of U, four at a time
+        if (ksteps > VM_CH / 4) ksteps = VM_CH / 4;
+        const float* xa = xs + li * pitch + VM_CH * ch + lk;
+        const double* bb = Bs + (buf * VM_CH + lk) * 16 + li;
 #pragma unroll 4
-      for (int ks = 0; ks < ksteps; ++ks) {
-        const int k = (ks << 2) + lk;
-        const double av = (double)xs[li * pitch + k];                                  // A[i = li][k]
-        const double bv = (k <= c) ? w[(int64_t)k * d - ((int64_t)k * (k - 1)) / 2 + (c - k)] : 0.0;  // B[k][j = li] = U[k][c]
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        for (int ks = 0; ks < ksteps; ++ks)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)xa[4 * ks], bb[64 * ks], acc, 0, 0, 0);  // A[i = li][k], B[k][j = li]
+        if (has_next) MFG_VM_COMMIT(buf ^ 1)
+        __syncthreads();
+        buf ^= 1;
       }
       const double bc = w[Q + c];
 #pragma unroll
@@ -1514,6 +1546,8 @@ __global__ __launch_bounds__(BLOCK) void k_value_mfma(const float* __restrict__ 
       if (li == 0 && n < N) V[n] = t + w[Q + d];
     }
   }
+#undef MFG_VM_LOAD
+#undef MFG_VM_COMMIT
 }
 
 // delta[b, s] = r[b, s] + gd(s) V[b, s+1] - V[b, s],  gd = gamma (mfg_ac2.py:505) or the running gamma^s (ac_irl.py:691);
@@ -2175,7 +2209,7 @@ static int launch_values_and_delta(const float* pi_traj, int64_t B, int T, int d
   grad_geometry(N, d, &chunk, &nsb, &nob);
   const size_t off = (size_t)(nsb * (mfg_num_features(d) + 3) * 8) + MFG_WS_CONTROL_BYTES;
   double* V = reinterpret_cast<double*>((char*)ws + off);
-  const size_t lds = (size_t)WAVES * 16 * (d + 4) * 4;
+  const size_t lds = (size_t)WAVES * 16 * (d + 4) * 4 + (size_t)2 * VM_CH * 16 * 8;  // state rows + two pieces of U
   int64_t groups = (NV + 15) / 16;
   int64_t blocks = (groups + WAVES - 1) / WAVES;
   const int64_t cap = (int64_t)num_cus() * 8;
