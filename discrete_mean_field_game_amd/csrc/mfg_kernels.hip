@@ -1314,6 +1314,10 @@ typedef double v4d_t __attribute__((ext_vector_type(4)));
 constexpr int GM_KC = 32;    // samples staged per chunk
 constexpr int GM_TPW = 8;    // max tiles per wave
 
+// NPF > 0 (float4 staging, NPF = d / 32 sixteen-byte loads per thread and chunk): the NEXT chunk's rows and deltas are
+// fetched into registers before this chunk's matrix instructions and committed to LDS after them, so the staging
+// latency (every sample chunk is staged by all blockIdx.y slices) hides behind the MFMAs.  NPF == 0: unpipelined.
+template <int NPF>
 __global__ __launch_bounds__(BLOCK) void k_grad_mfma(GradArgs a, int tpw) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int d = a.d, nt = d >> 4, pitch = d + 16;  // pitch = 16 mod 32: the four k-rows of an operand hit distinct banks
@@ -1349,13 +1353,55 @@ __global__ __launch_bounds__(BLOCK) void k_grad_mfma(GradArgs a, int tpw) {
   double lin[4] = {0.0, 0.0, 0.0, 0.0}, s_d = 0.0, s_dg = 0.0, s_r = 0.0, s_n = 0.0;
   const int li = lane & 15, lk = lane >> 4;
   const double invT = 1.0 / (double)a.T;
+  // register prefetch of a chunk (NPF > 0): thread -> (row q0 + rpp u, float4 column c4), no divisions per element
+  const int dq = d >> 2, rpp = BLOCK / (dq > 0 ? dq : 1);
+  const int q0 = tid / dq, c4 = tid - q0 * dq;
+  float4 pf[NPF > 0 ? NPF : 1];
+  double pf_de = 0.0, pf_dg = 0.0, pf_rr = 0.0;
+  bool pf_on = false;
+#define MFG_GM_FETCH(n0_)                                                                              \
+  {                                                                                                    \
+    const int cn_ = (int)((a.N - (n0_)) < GM_KC ? (a.N - (n0_)) : GM_KC);                              \
+    _Pragma("unroll") for (int u = 0; u < NPF; ++u) {                                                  \
+      const int q = q0 + u * rpp;                                                                      \
+      pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
+      if (q < cn_) {                                                                                   \
+        const int64_t n = (n0_) + q;                                                                   \
+        const int64_t b = (int64_t)(((double)n + 0.5) * invT);                                         \
+        pf[u] = *reinterpret_cast<const float4*>(a.pi + b * a.stride_b + (n - b * a.T) * d + 4 * c4);  \
+      }                                                                                                \
+    }                                                                                                  \
+    pf_de = 0.0; pf_dg = 0.0; pf_rr = 0.0; pf_on = false;                                              \
+    if (tid < cn_) {                                                                                   \
+      const int64_t n = (n0_) + tid;                                                                   \
+      pf_de = a.delta[n];                                                                              \
+      pf_rr = a.reward ? (double)a.reward[n] : 0.0;                                                    \
+      if (a.g) pf_dg = a.g[n];                                                                         \
+      pf_on = true;                                                                                    \
+    }                                                                                                  \
+  }
+  if (NPF > 0 && (int64_t)blockIdx.x * GM_KC < a.N) MFG_GM_FETCH((int64_t)blockIdx.x * GM_KC)
   for (int64_t n0 = (int64_t)blockIdx.x * GM_KC; n0 < a.N; n0 += (int64_t)gridDim.x * GM_KC) {
     const int cn = (int)((a.N - n0) < GM_KC ? (a.N - n0) : GM_KC);
     __syncthreads();
+    if (NPF > 0) {
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) *reinterpret_cast<float4*>(sp + (q0 + u * rpp) * pitch + 4 * c4) = pf[u];
+      if (tid < GM_KC) {
+        if (side && pf_on) {
+          s_d += pf_de;
+          if (a.g) s_dg = fma(pf_de, pf_dg, s_dg);
+          s_r += pf_rr;
+          s_n += 1.0;
+        }
+        dl[tid] = pf_de;
+      }
+      __syncthreads();
+      const int64_t nn = n0 + (int64_t)gridDim.x * GM_KC;
+      if (nn < a.N) MFG_GM_FETCH(nn)
+    } else {
     if (a.chunk) {
       // rows are 16-byte aligned and BLOCK is a multiple of d/4: thread -> (row, float4 column) without divisions
-      const int dq = d >> 2, rpp = BLOCK / dq;
-      const int q0 = tid / dq, c4 = tid - q0 * dq;
       for (int q = q0; q < GM_KC; q += rpp) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < cn) {
@@ -1393,6 +1439,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_mfma(GradArgs a, int tpw) {
       dl[tid] = de;
     }
     __syncthreads();
+    }
 #pragma unroll
     for (int ks = 0; ks < GM_KC / 4; ++ks) {
       const int k = ks * 4 + lk;
@@ -1419,6 +1466,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_mfma(GradArgs a, int tpw) {
       }
     }
   }
+#undef MFG_GM_FETCH
   // D[i][j] of a tile: lane holds rows i = 4 v + lane / 16, v = 0..3, column j = lane % 16
   double* out = a.partial + (int64_t)blockIdx.x * FO;
 #pragma unroll
@@ -1741,7 +1789,14 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
     const int tpw = (ntiles + ny * WAVES - 1) / (ny * WAVES);
     a.chunk = (BLOCK % (d / 4) == 0 && (((uintptr_t)pi & 15) == 0) && (stride_b % 4 == 0)) ? 1 : 0;  // float4 staging
     const size_t lds_m = (size_t)GM_KC * 8 + (size_t)4 * BLOCK * 8 + (size_t)GM_KC * (d + 16) * 4;
-    hipLaunchKernelGGL(k_grad_mfma, dim3((unsigned)nsb, (unsigned)ny), dim3(BLOCK), lds_m, st, a, tpw);
+    const int npf = a.chunk ? d / 32 : 0;
+    switch (npf) {
+      case 2: hipLaunchKernelGGL((k_grad_mfma<2>), dim3((unsigned)nsb, (unsigned)ny), dim3(BLOCK), lds_m, st, a, tpw); break;
+      case 4: hipLaunchKernelGGL((k_grad_mfma<4>), dim3((unsigned)nsb, (unsigned)ny), dim3(BLOCK), lds_m, st, a, tpw); break;
+      case 8: hipLaunchKernelGGL((k_grad_mfma<8>), dim3((unsigned)nsb, (unsigned)ny), dim3(BLOCK), lds_m, st, a, tpw); break;
+      case 16: hipLaunchKernelGGL((k_grad_mfma<16>), dim3((unsigned)nsb, (unsigned)ny), dim3(BLOCK), lds_m, st, a, tpw); break;
+      default: hipLaunchKernelGGL((k_grad_mfma<0>), dim3((unsigned)nsb, (unsigned)ny), dim3(BLOCK), lds_m, st, a, tpw); break;
+    }
     hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
                        (const double*)a.partial, nsb, FO, accumulate, G, rap);
     if (applied && rap.on) *applied = true;
