@@ -346,3 +346,32 @@ def test_given_P_batched_store_kernel_equals_per_tile_kernel(dev, d, B):
     r0 = ops().step_given_P(pi, P, reward_kind=0)[1][sl].cpu().numpy()
     ref = O().calc_reward(Pn, pin)
     assert np.max(np.abs(r0 - ref) / np.maximum(np.abs(ref), 1e-6)) < 1e-6
+
+
+@pytest.mark.parametrize('d,B', [(128, 16384 + 3), (128, 40000), (256, 16384 + 1)])
+def test_given_P_row_kernel_super_tiles_equal_per_trajectory_stores(dev, d, B):
+    """d = 128 / 256 batches of >= 16 384 trajectories take the super-tile form of k_step_rows (8 consecutive trajectories
+    per wave, outputs stashed in LDS and written as one device-scope burst; ragged last super tile: direct stores).  It
+    must reproduce bit for bit what the per-trajectory-store form gives (calls on chunks below the threshold), for both
+    reward kinds and the reward-less call; a slice is checked against the oracle."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(B + d)
+    pi = torch.rand(B, d, device=dev, generator=g)
+    pi = (pi / pi.sum(1, keepdim=True)).contiguous()
+    P = torch.rand(B, d, d, device=dev, generator=g)
+    P /= P.sum(-1, keepdim=True)
+    chunk = 4096
+    for kind in (0, 1):
+        pn, r = ops().step_given_P(pi, P, reward_kind=kind)
+        for s in range(0, B, chunk):
+            e = min(B, s + chunk)
+            pn_c, r_c = ops().step_given_P(pi[s:e], P[s:e], reward_kind=kind)
+            assert torch.equal(pn[s:e], pn_c) and torch.equal(r[s:e], r_c), (kind, s)
+    pn2, none = ops().step_given_P(pi, P, want_reward=False)
+    assert none is None and torch.equal(pn2, pn)
+    sl = slice(B - 20, B)
+    Pn, pin = P[sl].cpu().numpy().astype(np.float64), pi[sl].cpu().numpy().astype(np.float64)
+    assert np.array_equal(pn[sl].cpu().numpy(), O().transition(Pn, pin).astype(np.float32))
+    r0 = ops().step_given_P(pi, P, reward_kind=0)[1][sl].cpu().numpy()
+    ref = O().calc_reward(Pn, pin)
+    assert np.max(np.abs(r0 - ref) / np.maximum(np.abs(ref), 1e-6)) < 1e-6
