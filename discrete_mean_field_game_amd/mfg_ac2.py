@@ -442,7 +442,11 @@ class actor_critic:
                     self.train_log(np.ravel(self.theta), file_theta, '%.5e')
                     self.train_log(pi_host, file_pi, '%.3e')
                     self.train_log(np.array([reward_avg]), file_reward, '%.3e')
+                    self._train_log_extra()
         self._last_pi = pi
+
+    def _train_log_extra(self):
+        """Hook for the variants' additional per-report log lines (mfg_synthetic.py:522 logs w)."""
 
     def _write_all(self, pi, P, num_steps):
         with open('temp.csv', 'ab') as f:

@@ -35,6 +35,26 @@ class actor_critic(_base):
                 rows.append(list(map(float, f.readline().strip().split(' ')))[0:self.d])
         self.mat_pi0 = np.array(rows, dtype=np.float64)
 
+    def train(self, num_episodes=4000, gamma=1, constant=0, lr_critic=0.1, lr_actor=0.001, consecutive=100,
+              file_theta='results_syn/theta.csv', file_pi='results_syn/pi.csv', file_reward='results_syn/reward.csv',
+              file_w='results_syn/w.csv', write_file=0, write_all=0, **kw):
+        """mfg_synthetic.py:426-522: the mfg_ac2 loop with the synthetic reward, the `results_syn/` log defaults, the start
+        states re-read from cwd/train_normalized when that directory exists (:438-440), and one more log line per
+        report: w (`file_w`, '%.5e', :522)."""
+        if os.path.isdir(os.getcwd() + '/train_normalized'):
+            self.init_pi0(path_to_dir=os.getcwd() + '/train_normalized')
+        self._file_w = file_w
+        try:
+            return super().train(num_episodes=num_episodes, gamma=gamma, constant=constant, lr_critic=lr_critic,
+                                 lr_actor=lr_actor, consecutive=consecutive, file_theta=file_theta, file_pi=file_pi,
+                                 file_reward=file_reward, write_file=write_file, write_all=write_all, **kw)
+        finally:
+            self._file_w = None
+
+    def _train_log_extra(self):
+        if getattr(self, '_file_w', None):
+            self.train_log(np.ravel(self.w), self._file_w, '%.5e')
+
     def calc_reward_vector(self, P):
         """v_i = -1/2 ||P_i||^2 (mfg_synthetic.py:726-738) via the backward kernel on a 1-step sequence."""
         Pd = self._P_dev(P)                               # [B,d,d]

@@ -331,6 +331,29 @@ def test_mfg_synthetic_class_surface(dev):
     assert np.isfinite(float(np.ravel(ac.theta)[0]))
 
 
+def test_mfg_synthetic_train_logs_w(dev, tmp_path):
+    """mfg_synthetic.train (mfg_synthetic.py:426-522): `results_syn/` defaults, the extra `file_w` keyword and one w line
+    ('%.5e', comma separated, like train_log :419-423) per report next to theta / pi / reward."""
+    import inspect
+    from discrete_mean_field_game_amd.mfg_synthetic import actor_critic as SAC
+    sig = inspect.signature(SAC.train).parameters
+    assert sig['file_w'].default == 'results_syn/w.csv' and sig['file_theta'].default == 'results_syn/theta.csv'
+    z = np.load(os.path.join(G, 'reward_mfg_synthetic.npz'))
+    np.random.seed(1)
+    ac = SAC(theta=2.6, shift=0.0, alpha_scale=10000, d=21, pi0=z['pi'], verbose=0)
+    files = {k: str(tmp_path / (k + '.csv')) for k in ('theta', 'pi', 'reward', 'w')}
+    ac.train(num_episodes=4, constant=1, consecutive=2, write_file=1, file_theta=files['theta'], file_pi=files['pi'],
+             file_reward=files['reward'], file_w=files['w'])
+    lines = {k: open(v).read().splitlines() for k, v in files.items()}
+    assert [len(v) for v in lines.values()] == [2, 2, 2, 2]              # reports at episodes 0 and 2 (0-indexed, :513)
+    last = lines['w'][-1].split(',')
+    assert len(last) == 21 * 22 // 2 + 21 + 1
+    assert all(len(x.split('e')[0]) == len('%.5e' % 1.0) - 4 or x.startswith('-') for x in last)
+    # the run made two more updates after the last report; the logged w is a genuinely earlier state of the same vector
+    assert not np.allclose(np.array(last, dtype=np.float64), np.ravel(ac.w), rtol=0, atol=0)
+    assert np.allclose(np.array(last, dtype=np.float64), np.ravel(ac.w), rtol=0.5, atol=0.5)
+
+
 def test_irl_importance_weights_calc_z(dev):
     """AC_IRL.calc_z / calc_pdf_action (ac_irl.py:270-379) against the oracle's log-space restatement."""
     from discrete_mean_field_game_amd import ac_irl
