@@ -82,6 +82,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise MfgError('HIP extension not built: %s is missing (run __graft_entry__.build() / make -C %s)'
                            % (LIB_PATH, CSRC))
+        # PyTorch-ROCm brings its own libamdhip64; whichever copy is loaded FIRST owns the process.  Loading this library
+        # before torch binds it to /opt/rocm's runtime, torch then loads a second one, and kernels / symbols registered
+        # with one runtime are unknown to the other ("h(z) table initialisation failed").  So torch goes first.
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)
