@@ -114,7 +114,10 @@ int mfg_philox_raw(uint64_t seed, uint32_t first_ctr, uint32_t c1, uint32_t c2, 
                    uint32_t* out, mfg_stream_t stream);
 
 /* a3+a4: pi_next = P^T pi, reward[b] (fp32) per reward_kind     (mfg_ac2.py:497-499).
- * reward may be NULL (transition only, ac_irl.py:679). */
+ * reward may be NULL (transition only, ac_irl.py:679).  The HBM-bound kernel of the path: P is read once
+ * (16-byte streaming loads when P is 16-byte aligned); with 16-byte aligned pi_next / reward, large batches
+ * (d = 21, 15: >= ~10^5 transitions; d = 128, 256: >= 16 384) write their outputs as batched device-scope
+ * bursts.  Results do not depend on which form runs.  pi_next must not alias pi. */
 int mfg_step_given_P(const float* pi, const float* P, int64_t B, int d, int reward_kind, float* pi_next,
                      float* reward, mfg_stream_t stream);
 
