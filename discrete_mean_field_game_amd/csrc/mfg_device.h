@@ -285,12 +285,23 @@ __device__ __forceinline__ void softplus_sigmoid_e(float e, float& sp, float& sg
   sp = e + 0.3f;
   return;
 #endif
+#ifdef MFG_LOG1P_POLY  // the first form: degree-6 polynomial below 1/4, ln(1 + e) above, one select (6 more instructions)
   const float u = 1.0f + e;
   sg = e * __builtin_amdgcn_rcpf(u);
   float lp = log1p_small(e), ln = fast_ln(u);
   asm("" : "+v"(lp), "+v"(ln));  // both sides evaluated: the select is a v_cndmask, not an exec-masked if/else that would
                                  // cut the basic block (the sampling loop interleaves four elements' chains)
   sp = (e < 0.25f) ? lp : ln;
+#else
+  // log1p(e) = ln(u) + (e - (u - 1)) / u with u = fl32(1 + e): the hardware log of the ROUNDED sum plus the first-order
+  // correction for what the rounding dropped (u - 1 is exact, so the numerator is the exact rounding error of 1 + e).
+  // Branch-free over the whole range -- for e < 2^-24 it returns e -- and it shares the reciprocal with the sigmoid:
+  // max relative error 1.95e-7 over e in [2^-24, 4] (tools/micro/log1p_check.hip), 8 instructions against 14.
+  const float u = 1.0f + e;
+  const float r = __builtin_amdgcn_rcpf(u);
+  sg = e * r;
+  sp = fmaf(e - (u - 1.0f), r, fast_ln(u));
+#endif
 }
 
 // fp64 helpers of the mixed-precision per-row epilogue (one call per matrix ROW per step, but IEEE fp64 division / log
