@@ -79,7 +79,7 @@ __device__ __forceinline__ void policy_setup(PolicyElem<FAST>& e, const CoreArgs
     theta_times_x(ts, pj, pi, x, zh, zl);
     softplus_sigmoid_fast(zh, zl, e.al_f, sg);
     e.ad_f = x * sg;
-    if (TD) e.psi_ad = x * htab_eval(a.htab, ts.th * x);  // fp32 product is ample for a table lookup (|dh/dz| < 1)
+    if (TD) e.psi_ad = x * htab_eval(a.htab, x, ts.thn);  // fp32 product is ample for a table lookup (|dh/dz| < 1)
     if (SAMPLE) gamma_setup_hot(e.gs, e.al_f * (float)a.alpha_scale);
   } else {
     const double x = (double)pj - (double)pi - a.shift;
@@ -98,7 +98,7 @@ __device__ __forceinline__ void policy_setup_sep(PolicyElem<true>& e, const Core
   float sg;
   softplus_sigmoid_e(Ej * Fi, e.al_f, sg);
   e.ad_f = x * sg;
-  if (TD) e.psi_ad = x * htab_eval(a.htab, ts.th * x);
+  if (TD) e.psi_ad = x * htab_eval(a.htab, x, ts.thn);
   if (SAMPLE) gamma_setup_hot(e.gs, e.al_f * (float)a.alpha_scale);
 }
 

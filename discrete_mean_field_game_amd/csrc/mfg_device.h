@@ -240,17 +240,14 @@ __device__ __forceinline__ void softplus_sigmoid(double z, double& sp, double& s
 // v_rcp_f32, ~1 ulp), fp64 only for the sums.  Measured effect on the score g: ~1e-6 relative.
 // ---------------------------------------------------------------------------
 // alpha = log1p(e^z), sigmoid(z) for z = zh + zl (zl = low-order part of theta*x, so that e carries fp32
-// relative error instead of |z| * 2^-24).  log1p: 2 atanh(e/(2+e)) series below e = 1/4 (no reliance on
-// the hardware log near 1), log(1+e) above.
+// relative error instead of |z| * 2^-24).  log1p as in softplus_sigmoid_e.
 __device__ __forceinline__ void softplus_sigmoid_fast(float zh, float zl, float& sp, float& sg) {
   float e = fast_exp(zh);
   e = fmaf(e, zl, e);
   const float u = 1.0f + e;
-  sg = e * __builtin_amdgcn_rcpf(u);
-  const float s = e * __builtin_amdgcn_rcpf(2.0f + e);
-  const float s2 = s * s;
-  const float ser = 2.0f * s * fmaf(s2, fmaf(s2, fmaf(s2, fmaf(s2, 1.0f / 9.0f, 1.0f / 7.0f), 0.2f), 1.0f / 3.0f), 1.0f);
-  sp = (e < 0.25f) ? ser : fast_ln(u);
+  const float r = __builtin_amdgcn_rcpf(u);
+  sg = e * r;
+  sp = fmaf(e - (u - 1.0f), r, fast_ln(u));  // log1p through the rounded sum + rounding-error correction (softplus_sigmoid_e)
 }
 
 // Round 2: the exponential is SEPARABLE, e^{theta (pi_j - pi_i - shift)} = E_j F_i with E_j = e^{theta pi_j},
@@ -355,6 +352,7 @@ __device__ __forceinline__ float fast_rcp_f32_of_f64(double x) {
 // product and of the constants carried in zl.
 struct ThetaSplit {
   float th, tl, sh, c0;  // theta = th + tl, shift = sh + sl, c0 = th * sl
+  float thn;             // th * (h-table intervals per unit of z): the table index is one fma of x
 };
 __device__ __forceinline__ ThetaSplit theta_split(double theta, double shift) {
   ThetaSplit t;
@@ -362,6 +360,7 @@ __device__ __forceinline__ ThetaSplit theta_split(double theta, double shift) {
   t.tl = (float)(theta - (double)t.th);
   t.sh = (float)shift;
   t.c0 = t.th * (float)(shift - (double)t.sh);
+  t.thn = t.th * 16.0f;  // HTAB_PER_UNIT (a power of two: exact)
   return t;
 }
 __device__ __forceinline__ void theta_times_x(const ThetaSplit& t, float pj, float pi, float& x, float& zh, float& zl) {
@@ -384,11 +383,13 @@ constexpr float HTAB_ZMAX = 88.0f;                         // fp32 range of e^z 
 constexpr int HTAB_PER_UNIT = 16;                          // intervals per unit of z
 constexpr int HTAB_N = (88 + 24) * HTAB_PER_UNIT;          // 1 792 intervals over [-24, 88)
 
-__device__ __forceinline__ float htab_eval(const float4* __restrict__ tab, float z) {
+// h(theta x) from x and thn = theta * HTAB_PER_UNIT (ThetaSplit): the interval coordinate is ONE fma of x.
+__device__ __forceinline__ float htab_eval(const float4* __restrict__ tab, float x, float thn) {
 #ifdef MFG_ABL_HTAB
-  return z * 0.1f;
+  return x * thn * 0.1f;
 #endif
-  float t = fmaf(z, (float)HTAB_PER_UNIT, -HTAB_ZMIN * (float)HTAB_PER_UNIT);
+  static_assert(HTAB_PER_UNIT == 16, "ThetaSplit::thn assumes 16 intervals per unit of z");
+  float t = fmaf(x, thn, -HTAB_ZMIN * (float)HTAB_PER_UNIT);
   t = __builtin_amdgcn_fmed3f(t, 0.0f, (float)HTAB_N - 0.001f);  // clamp: one instruction
   const unsigned k = (unsigned)t;                                 // truncation == floor (t >= 0)
   const float f = __builtin_amdgcn_fractf(t);
