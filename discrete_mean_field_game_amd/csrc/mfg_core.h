@@ -80,7 +80,7 @@ __device__ __forceinline__ void policy_setup(PolicyElem<FAST>& e, const CoreArgs
     softplus_sigmoid_fast(zh, zl, e.al_f, sg);
     e.ad_f = x * sg;
     if (TD) e.psi_ad = x * htab_eval(a.htab, x, ts.thn);  // fp32 product is ample for a table lookup (|dh/dz| < 1)
-    if (SAMPLE) gamma_setup_hot(e.gs, e.al_f * (float)a.alpha_scale);
+    if (SAMPLE) gamma_setup_hot(e.gs, e.al_f, (float)a.alpha_scale, 9.0f * (float)a.alpha_scale);
   } else {
     const double x = (double)pj - (double)pi - a.shift;
     double sg;
@@ -99,7 +99,7 @@ __device__ __forceinline__ void policy_setup_sep(PolicyElem<true>& e, const Core
   softplus_sigmoid_e(Ej * Fi, e.al_f, sg);
   e.ad_f = x * sg;
   if (TD) e.psi_ad = x * htab_eval(a.htab, x, ts.thn);
-  if (SAMPLE) gamma_setup_hot(e.gs, e.al_f * (float)a.alpha_scale);
+  if (SAMPLE) gamma_setup_hot(e.gs, e.al_f, (float)a.alpha_scale, 9.0f * (float)a.alpha_scale);
 }
 
 // Fold one finished element into the row sums / score.  v = gamma variate (SAMPLE) or stored probability.

@@ -80,6 +80,15 @@ __device__ __forceinline__ void gamma_setup_hot(GammaState& g, float a) {
   g.dd = a - (1.0f / 3.0f);
   g.c = __builtin_amdgcn_rsqf(9.0f * g.dd);  // garbage for a < 1/3: such elements never use the hot-path result
 }
+// The same from the concentration alpha and the scale (shape a = alpha * scale), one instruction shorter: d and 9 d are
+// one fma each of alpha, the small-shape flag is read off d (a < 1 <=> d < 2/3), and the shape itself -- which only the
+// cold small-shape continuation needs -- is d + 1/3.
+__device__ __forceinline__ void gamma_setup_hot(GammaState& g, float alpha, float scale, float scale9) {
+  g.dd = fmaf(alpha, scale, -(1.0f / 3.0f));
+  g.small = g.dd < (2.0f / 3.0f);
+  g.a = g.dd + (1.0f / 3.0f);  // dead on the hot path
+  g.c = __builtin_amdgcn_rsqf(fmaf(alpha, scale9, -3.0f));
+}
 
 // Marsaglia-Tsang acceptance for normal x and uniform u; v = (1 + c x)^3.
 __device__ __forceinline__ bool mt_accept(const GammaState& g, float x, float u, float& v) {
