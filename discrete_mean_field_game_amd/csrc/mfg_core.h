@@ -92,9 +92,10 @@ __device__ __forceinline__ void policy_setup(PolicyElem<FAST>& e, const CoreArgs
 
 // Mixed-precision sampling kernels: e^z = Ej * Fi (see exp_f64arg in mfg_device.h).
 template <bool SAMPLE, bool TD>
+//   pis = pi_i + shift of the element's ROW, formed once per row by the caller: x costs one subtraction per element.
 __device__ __forceinline__ void policy_setup_sep(PolicyElem<true>& e, const CoreArgs& a, const ThetaSplit& ts, float pj, float Ej,
-                                                 float pi, float Fi) {
-  const float x = (pj - pi) - ts.sh;
+                                                 float pis, float Fi) {
+  const float x = pj - pis;
   float sg;
   softplus_sigmoid_e(Ej * Fi, e.al_f, sg);
   e.ad_f = x * sg;
@@ -108,7 +109,7 @@ __device__ __forceinline__ void policy_accumulate(const PolicyElem<FAST>& e, con
                                                   float v, double& A, double& D, double& gacc) {
   if (!TD) return;
   if (FAST) {
-    const float lnv = (!SAMPLE && v == 0.0f) ? (float)LOG_ZERO_P : fast_ln(v);
+    const float lnv = (!SAMPLE && v == 0.0f) ? (float)(LOG_ZERO_P * INV_LN2) : __builtin_amdgcn_logf(v);  // log2 units
     A += (double)e.al_f;
     D += (double)e.ad_f;
     gacc += (double)fmaf(lnv, e.ad_f, -e.psi_ad);
@@ -136,7 +137,8 @@ __device__ __forceinline__ PolicyTerms<FAST> policy_terms(const PolicyElem<FAST>
 #ifdef MFG_ABL_LNY
     const float lnv = v;
 #else
-    const float lnv = (!SAMPLE && v == 0.0f) ? (float)LOG_ZERO_P : fast_ln(v);
+    // log2 units: the h table is stored divided by ln 2 (mfg_device.h), the sums are scaled by ln 2 once per row / step
+    const float lnv = (!SAMPLE && v == 0.0f) ? (float)(LOG_ZERO_P * INV_LN2) : __builtin_amdgcn_logf(v);
 #endif
     o.al = e.al_f;
     o.ad = e.ad_f;
@@ -154,7 +156,8 @@ __device__ __forceinline__ PolicyTerms<FAST> policy_terms(const PolicyElem<FAST>
 // Written so that the two chains of a pair sit in one basic block and interleave (measured on gfx950: a single
 // dependent chain issues one VALU instruction per ~5 cycles per SIMD, two independent chains one per ~2): no branch on
 // the hot path -- the rare exact-acceptance / small-shape continuations hide behind one wave-uniform test per pair.
-//   Per element e: pj / ej = state entry and E_j of its column, pai / Fi = state entry and F_i of its ROW (ej, Fi unused
+//   Per element e: pj / ej = state entry and E_j of its column, pai / Fi = state entry (SEP: state entry + shift, see
+//   policy_setup_sep) and F_i of its ROW (ej, Fi unused
 //   unless SEP), elem = its element id (Philox counter of its own continuation draws), valid = whether it exists
 //   (lanes past the last column compute on clamped inputs and are masked out).
 //   Out: y = gamma variate (0 when !valid); al / ad / gt = its alpha, alpha', score term (0 when !valid; TD only).
@@ -455,12 +458,13 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
           using TT = typename PolicyTerms<FAST>::T;
           const float* ev = pex + tlc * d;
           const uint32_t erow = (uint32_t)(i * d);
+          const float pas = sep ? pai + ts.sh : pai;  // row operand of the sampler (policy_setup_sep takes pi_i + shift)
           const int dq = d & ~3;
 #pragma unroll 1
           for (int j = 0; j < dq; j += 4) {
             float y[4], ys = 0.0f;
             TT as = 0, ds = 0, gs = 0;
-            sample_elems<4, TD, FAST, sep>(a, theta, ts, pav + j, ev + j, pai, Fi, erow + (uint32_t)j, step, traj, y, ys,
+            sample_elems<4, TD, FAST, sep>(a, theta, ts, pav + j, ev + j, pas, Fi, erow + (uint32_t)j, step, traj, y, ys,
                                            as, ds, gs);
 #pragma unroll
             for (int e = 0; e < 4; ++e) trow[j + e] = y[e];
@@ -476,13 +480,13 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
             TT as = 0, ds = 0, gs = 0;
             const int rem = d - dq;
             if (rem == 1)
-              sample_elems<1, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pai, Fi, erow + (uint32_t)dq, step, traj, y,
+              sample_elems<1, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pas, Fi, erow + (uint32_t)dq, step, traj, y,
                                              ys, as, ds, gs);
             else if (rem == 2)
-              sample_elems<2, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pai, Fi, erow + (uint32_t)dq, step, traj, y,
+              sample_elems<2, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pas, Fi, erow + (uint32_t)dq, step, traj, y,
                                              ys, as, ds, gs);
             else
-              sample_elems<3, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pai, Fi, erow + (uint32_t)dq, step, traj, y,
+              sample_elems<3, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pas, Fi, erow + (uint32_t)dq, step, traj, y,
                                              ys, as, ds, gs);
             for (int e = 0; e < rem; ++e) trow[dq + e] = y[e];
             Ssum += (double)ys;
@@ -503,6 +507,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
           }
         }
         MFG_STAMP(2)
+        if (TD && FAST) gacc *= LN2;  // the element terms were summed in log2 units (policy_terms / policy_accumulate)
         if (SAMPLE) {
           // normalise the row.  strict: P_ij = fl32(y_ij / S_i); mixed: P_ij = y_ij * fl32(1 / S_i) (one fp32 multiply per
           // element, within 1.5 ulp of the strict value; rows still sum to 1 within a few 1e-7)
@@ -752,6 +757,7 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
           const bool row1 = NR == 2 && (FULL || i + 1 < d);
           const int i1 = row1 ? i + 1 : i;
           const float pr[2] = {pis[i], pis[i1]};
+          const float prs[2] = {sep ? pr[0] + ts.sh : pr[0], sep ? pr[1] + ts.sh : pr[1]};  // the sampler's row operands
           float fr[2] = {0.0f, 0.0f};
           if (sep) {
             fr[0] = pfs[i];
@@ -765,7 +771,7 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
               const uint32_t e0 = (uint32_t)(i * d + lane + m * WAVE);
               const float pj[4] = {pad[m], pad[m + 1], pad[m + 2], pad[m + 3]};
               const float ej[4] = {Ec[m], Ec[m + 1], Ec[m + 2], Ec[m + 3]};
-              const float pa[4] = {pr[0], pr[0], pr[0], pr[0]};
+              const float pa[4] = {prs[0], prs[0], prs[0], prs[0]};
               const float fi[4] = {fr[0], fr[0], fr[0], fr[0]};
               const uint32_t el[4] = {e0, e0 + WAVE, e0 + 2 * WAVE, e0 + 3 * WAVE};
               const bool ok[4] = {okc[m], okc[m + 1], okc[m + 2], okc[m + 3]};
@@ -794,7 +800,7 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
               if (two) {
                 const float pj[4] = {pad[m], pad[m1], pad[m], pad[m1]};
                 const float ej[4] = {Ec[m], Ec[m1], Ec[m], Ec[m1]};
-                const float pa[4] = {pr[0], pr[0], pr[1], pr[1]};
+                const float pa[4] = {prs[0], prs[0], prs[1], prs[1]};
                 const float fi[4] = {fr[0], fr[0], fr[1], fr[1]};
                 const uint32_t el[4] = {e00, e00 + WAVE, e10, e10 + WAVE};
                 const bool ok[4] = {okc[m], okc[m1], okc[m] && row1, okc[m1] && row1};
@@ -820,7 +826,7 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
                 // odd R: the lane's last column; its two rows share the Box-Muller pair
                 const float pj[2] = {pad[m], pad[m]};
                 const float ej[2] = {Ec[m], Ec[m]};
-                const float pa[2] = {pr[0], pr[1]};
+                const float pa[2] = {prs[0], prs[1]};
                 const float fi[2] = {fr[0], fr[1]};
                 const uint32_t el[2] = {e00, e10};
                 const bool ok[2] = {okc[m], okc[m] && row1};
@@ -993,7 +999,7 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
             if (SAMPLE) guni -= log(rowq[3 * rw + 2]) * Dr;
           }
         }
-        const double gsum = wave_sum_dpp(gacc + guni);
+        const double gsum = wave_sum_dpp((FAST ? gacc * LN2 : gacc) + guni);  // mixed: element terms in log2 units
         if (lane == 0 && a.g) a.g[b * T + s] = gsum;
 #ifdef MFG_ABL_V
         if (false) {

@@ -9,6 +9,7 @@ namespace mfg {
 constexpr int WAVE = 64;
 constexpr float ZERO_GAMMA_REPLACEMENT = 1e-20f;   // mfg_ac2.py:244
 constexpr double LOG_ZERO_P = -230.25850929940458;  // ln(1e-100), mfg_ac2.py:369
+constexpr double LN2 = 0.6931471805599453, INV_LN2 = 1.4426950408889634;
 
 // ---------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11).  Counter layout used by every sampler:
@@ -379,6 +380,8 @@ __device__ __forceinline__ void theta_times_x(const ThetaSplit& t, float pj, flo
 }
 
 // ---------------------------------------------------------------------------
+// (The table stores h / ln 2: the mixed kernels sum the per-element score terms  log2(y) alpha' - x h / ln 2  in log2
+// units -- the hardware logarithm as it is, no multiply by ln 2 per element -- and scale the sum by ln 2 once per row.)
 // h(z) = psi(softplus(z)) * sigmoid(z): the score's -psi(alpha_ij) alpha'_ij term equals -x_ij h(z_ij) with
 // z = theta x, and h is a smooth bounded function of ONE variable (h -> -1 for z -> -inf, ~ln z for z -> inf).
 // Mixed precision evaluates it from a table of per-interval cubics (fitted in fp64 by k_init_htab through

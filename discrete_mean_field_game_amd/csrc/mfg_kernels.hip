@@ -1821,7 +1821,7 @@ __global__ void k_init_htab(float4* __restrict__ tab) {
     const double z = (double)HTAB_ZMIN + ((double)k + (double)q / 3.0) / (double)HTAB_PER_UNIT;
     double sp, sg;
     softplus_sigmoid(z, sp, sg);
-    y[q] = digamma_pos(sp) * sg;
+    y[q] = digamma_pos(sp) * sg * INV_LN2;  // log2 units, see mfg_device.h
   }
   // cubic through f = 0, 1/3, 2/3, 1 (Newton forward differences, t = 3 f)
   const double d1 = y[1] - y[0], d2 = y[2] - 2.0 * y[1] + y[0], d3 = y[3] - 3.0 * y[2] + 3.0 * y[1] - y[0];
