@@ -1,0 +1,24 @@
+#!/bin/bash
+# Copy the summaries of a tools/profile_round.sh run (gpurun_out/<tag>/) into profiles/ under the round's names.
+# usage: bash tools/collect_profiles.sh <tag> [round-prefix, default r02]
+O=gpurun_out/$1; P=${2:-r02}
+cp $O/bench.json profiles/${P}_bench.json
+cp $O/bench_kernel_stats.csv profiles/${P}_bench_kernel_stats.csv
+cp $O/bench_under_rocprof.json profiles/${P}_bench_under_rocprof.json
+cp $O/pmc_traffic_21_15_65536.json profiles/${P}_pmc_traffic.json
+cp $O/pmc_traffic_128_1_16384.json profiles/${P}_pmc_traffic_128_1_16384.json
+cp $O/pmc_traffic_256_1_16384.json profiles/${P}_pmc_traffic_256_1_16384.json
+cp $O/pmc_sq_21_15_65536.json profiles/${P}_pmc_sq.json
+cp $O/pmc_sq_21_15_65536.json profiles/${P}_pmc_sq_21_15_65536.json
+cp $O/pmc_sq_128_40_16384.json profiles/${P}_pmc_sq_128_40_16384.json
+cp $O/pmc_sq_256_40_16384.json profiles/${P}_pmc_sq_256_40_16384.json
+cp $O/other_configs_kernel_stats.csv profiles/${P}_other_configs_kernel_stats.csv
+cp $O/core_probe_under_rocprof.txt profiles/${P}_core_probe_under_rocprof.txt
+python3 - <<PY
+import json
+d = json.load(open('profiles/${P}_bench.json'))
+r = d['roofline']
+print('value %.4g env-steps/s, %.4f ms/step; given-P %.0f GB/s frac %.3f (%.1f us)' % (d['value'], d['ms_per_step'], r['achieved'], r['frac'], r['avg_launch_us']))
+for c in d['configs']:
+    print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in c.items() if k in ('config', 'fused_ms_per_rollout', 'fused_env_steps_per_s', 'given_P_frac', 'env_steps_per_s')})
+PY
