@@ -264,6 +264,15 @@ def main():
                 'achieved_GBs': N * bps / t_step / 1e9, 'frac': N * bps / t_step / 1e9 / HBM_PEAK_GBS,
                 'env_steps_per_s': N / t_step}
 
+    # clock ramp: ~30 ms of untimed streaming work on every CU before anything is measured (a cold device takes the first
+    # few launches to leave its idle power state; with a small --warmup the timed steps would otherwise pay for it).
+    # Not a step of the workload: the W warm-up steps below still run as asked.
+    _heat = torch.empty(64 * 1024 * 1024, device=dev).uniform_()
+    for _ in range(300):
+        _heat.mul_(1.0000001)
+    torch.cuda.synchronize()
+    del _heat
+
     d, T = args.d, args.T
     # ---- headline leg.  strong scaling (default): the GLOBAL batch --batch is split over the ranks; weak: --batch per GPU
     B = args.batch // world if args.scaling == 'strong' else args.batch
