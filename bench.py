@@ -296,6 +296,25 @@ def main():
         del st5
         st = None
 
+    collective = None
+    if multi:
+        # latency of the ONE exchange step of an update: all-reduce of the fused gradient buffer
+        # [G_w | G_theta | sum r | count] (fp64, F+3 entries) and the replicated parameter update that follows it, timed
+        # with events on the launch stream, every rank in lock-step
+        Fc = ops.num_features(d)
+        Gc = torch.zeros(Fc + 3, dtype=torch.float64, device=dev)
+        Gc[Fc + 2] = 1.0
+        wc = torch.zeros(Fc, dtype=torch.float64, device=dev)
+        tc = torch.zeros(1, dtype=torch.float64, device=dev)
+        sync()
+        t_ar = event_time(lambda: all_reduce_(Gc), n=50, warm=10)
+        sync()
+        t_upd = event_time(lambda: (all_reduce_(Gc), ops.apply_update(Gc, d, 0.0, 0.0, wc, tc)), n=50, warm=10)
+        sync()
+        collective = {'backend': ('rccl (torch.distributed nccl)' if args.backend == 'nccl' else 'gloo, host staged (debug)'),
+                      'world': world, 'payload_bytes': (Fc + 3) * 8, 'all_reduce_us': t_ar * 1e6,
+                      'all_reduce_plus_apply_update_us': t_upd * 1e6}
+
     out = None
     if rank == 0:
         bytes_per_step = 4 * (d * d + 2 * d + 1)                         # SURVEY.md 8d / BASELINE.md 3
@@ -353,6 +372,8 @@ def main():
             'theta_end': theta_end,
             'roofline': roofline, 'fused_kernel': fused, 'cpu_baseline': cpu,
         }
+        if collective is not None:
+            out['collective'] = collective
         if other is not None:
             out['other_scaling'] = other
         if c5 is not None:

@@ -17,6 +17,7 @@ MFG_MAX_D = 512
 REWARD_MFG_AC2, REWARD_SYNTHETIC, REWARD_EXTERNAL = 0, 1, 2
 ROLLOUT_WRITE_P, ROLLOUT_TD, ROLLOUT_DISCOUNT_POW, ROLLOUT_F64, TRAIN_APPLY = 1, 2, 4, 8, 16
 PRECISION_F64, PRECISION_MIXED = 0, 1
+STATUS_MIXED_RANGE = 1
 PRECISIONS = {'f64': PRECISION_F64, 'mixed': PRECISION_MIXED, 0: 0, 1: 1}
 
 
@@ -41,6 +42,8 @@ SIGNATURES = {
     'mfg_last_error': (C.c_char_p, []),
     'mfg_abi_version': (_i32, []),
     'mfg_init': (_i32, []),
+    'mfg_status': (_i32, [C.POINTER(C.c_uint)]),
+    'mfg_clear_status': (_i32, []),
     'mfg_device_info': (_i32, [C.POINTER(C.c_int), C.c_char_p, _i32]),
     'mfg_feature_index': (_i64, [_i32, _i32, _i32]),
     'mfg_num_features': (_i64, [_i32]),

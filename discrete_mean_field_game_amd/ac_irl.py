@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import os
 import random
+import warnings
 
 import numpy as np
 import torch
@@ -133,7 +134,12 @@ class AC_IRL(actor_critic):
             key = ((self.seed + 0x5EED) ^ (self._reward_calls * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
             return ops.reward_net_forward(self.reward_net, pi.contiguous(), P.contiguous(), seed=key,
                                           sample_offset=int(self._reward_sample_offset))
-        with torch.no_grad():                                                    # shapes outside the kernel's range
+        if not getattr(self, '_warned_reward_fallback', False):                  # shapes outside the kernel's range
+            self._warned_reward_fallback = True
+            warnings.warn('AC_IRL.reward: the reward network (d=%d, n_fc3=%d, n_fc4=%d) is outside the range of the HIP '
+                          'kernel mfg_reward_net_forward (d, n_fc3, n_fc4 <= 32, f2 <= 2, CUDA tensors); evaluating it with the '
+                          'PyTorch module instead' % (self.d, self.n_fc3, self.n_fc4), RuntimeWarning, stacklevel=2)
+        with torch.no_grad():
             return self.reward_net(pi, P).reshape(-1).float().contiguous()
 
     def calc_alpha_deriv(self, pi):
@@ -150,8 +156,9 @@ class AC_IRL(actor_critic):
               file_reward='results/reward.csv', write_file=0, write_all=0, reward_fn=None, *, first_episode=0):
         """Forward actor-critic under the learned reward (ac_irl.py:634-732).  ``reward_fn(pi, P) -> [B]``
         overrides the reward network (used by the parity tests with a closed-form reward).
-        first_episode: episodes already run before a resume (the lr/(episode+1) schedule and the episode counter
-        continue from there; the reference always starts at 1)."""
+        first_episode: episodes already run before a resume: `max_episodes` MORE episodes are run, numbered
+        first_episode+1 .. first_episode+max_episodes in the lr/(episode+1) schedule (the same meaning as in
+        actor_critic.train; the reference always starts at 1)."""
         d, T = self.d, EPISODE_STEPS
         if self.verbose:
             print('----- Starting train -----')
@@ -182,7 +189,7 @@ class AC_IRL(actor_critic):
         list_reward = []
         episode = 0
         pi = None
-        for episode in range(1 + first_episode, max_episodes + 1):
+        for episode in range(1 + first_episode, first_episode + max_episodes + 1):
             pi = ops.gather_start(self._mat_pi0_dev, self._draw_start(shard))
             discount = 1.0
             total_reward = torch.zeros(1, dtype=torch.float64, device=self.device)
@@ -279,6 +286,7 @@ class AC_IRL(actor_critic):
                 prev_theta = cur
         self.list_policies = (self.list_policies + [self.theta])[1:]            # record this policy (:731)
         self.episodes_run = episode
+        self._check_status()
         if self.verbose:
             print('----- Exiting train at episode %d with theta %f -----' % (episode, float(np.ravel(self.theta)[0])))
 
@@ -356,6 +364,7 @@ class AC_IRL(actor_critic):
             self.list_generated = [[(gp[m, t], gP[m, t]) for t in range(gp.shape[1])] for m in range(gp.shape[0])]
         elif 'list_generated_pi' in state:
             self.list_generated = []
+        self.list_eval_gen_transitions = [pair for traj in self.list_generated for pair in traj]   # as outerloop keeps it (:934)
         if restore_np_random and 'py_random_state' in state:
             random.setstate((int(state['py_random_version']), tuple(int(v) for v in state['py_random_state']),
                              state['py_random_gauss']))
@@ -448,15 +457,18 @@ class AC_IRL(actor_critic):
             print('----- Exiting reward_iteration at iter %d -----' % it)
 
     def outerloop(self, num_iterations=20, num_gen_from_policy=5, max_reward_iterations=100,
-                  max_forward_episodes=200, gamma=1, constant=False, lr_critic=0.1, lr_actor=0.001):
-        """Alternate reward updates and forward solves (ac_irl.py:900-954); returns the final theta."""
-        self.list_generated = self.generate_trajectories(num_gen_from_policy * self.num_policies)
-        self.reward_update_count = 0
+                  max_forward_episodes=200, gamma=1, constant=False, lr_critic=0.1, lr_actor=0.001, *, first_iteration=0):
+        """Alternate reward updates and forward solves (ac_irl.py:900-954); returns the final theta.
+        first_iteration > 0 resumes after load_state_dict: D_samp (list_generated), the reward-update counter and the CSV
+        log of the checkpointed run are kept and the loop continues at that iteration (the reference cannot resume)."""
         write = 1 if os.path.isdir('results') else 0
-        if write:
-            with open('results/reward_training.csv', 'w') as f:
-                f.write('reward_demo_avg,reward_gen_avg\n')
-        for it in range(num_iterations):
+        if first_iteration == 0:
+            self.list_generated = self.generate_trajectories(num_gen_from_policy * self.num_policies)
+            self.reward_update_count = 0
+            if write:
+                with open('results/reward_training.csv', 'w') as f:
+                    f.write('reward_demo_avg,reward_gen_avg\n')
+        for it in range(first_iteration, num_iterations):
             if self.verbose:
                 print('########## Outerloop iteration %d ##########' % it)
             list_generated = self.generate_trajectories(num_gen_from_policy)

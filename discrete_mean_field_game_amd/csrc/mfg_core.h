@@ -18,6 +18,7 @@ constexpr int WAVES = BLOCK / WAVE;
 struct CoreArgs {
   const float* pi0;         // [B,d]; or, with start_idx != NULL, the start-state table [num_start,d]
   const int32_t* start_idx; // [B] rows of the table (start-state gather folded into the kernel, mfg_ac2.py:466-469)
+  int64_t num_start;        // rows of the table (start_idx != NULL): indices are clamped into [0, num_start)
   const float* pi_alpha;    // GIVEN: state the concentrations are computed from (NULL -> pi0)
   const float* P_in;        // GIVEN: [B,d,d]
   const float* pi_next_in;  // GIVEN: [B,d] (may be NULL when no delta is wanted)
@@ -37,6 +38,7 @@ struct CoreArgs {
   double* g;           // [B,T] or NULL
   float* P_out;        // [B,T,d,d] or NULL
   const float4* htab;  // h(z) cubic table (mixed precision TD), see mfg_device.h
+  unsigned* status;    // device address of the host-visible status word (mfg_status), or NULL
 #ifdef MFG_TIMING
   unsigned long long* dbg;  // timing variant only (tools/phase_timing.py): s_memtime stamps of block 0, wave 0
 #endif
@@ -328,9 +330,10 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
   const double theta = *a.theta;
   const ThetaSplit ts = theta_split(theta, a.shift);
   const float inv_d = 1.0f / (float)d;
-  // mixed sampling kernels: separable e^z = E_j F_i (mfg_device.h).  The factors leave the fp32 range when
-  // |theta| (max_j pi_j + |shift|) exceeds ~88 and the outputs then turn NaN -- loudly; precision 'f64' has no such limit.
+  // mixed sampling kernels: separable e^z = E_j F_i (mfg_device.h), in range while |theta| (1/2 + |shift|) <= 86; beyond
+  // that the launch reports MFG_STATUS_MIXED_RANGE and its outputs are NaN (precision 'f64' has no such limit).
   constexpr bool sep = SAMPLE && FAST;
+  if (sep) report_sep_range(a.status, theta, a.shift);
   if (want_v) {
     if (CIRC) {
       for (int k = tid; k < H * d; k += BLOCK) {
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
     const int64_t b = b0 + tlc;
     double* redq = red + (size_t)tlc * 3 * d;
     float* pnv = pin + tlc * pnw;
-    float pi_i = a.pi0[(a.start_idx ? (int64_t)a.start_idx[b] : b) * d + i];
+    float pi_i = a.pi0[(a.start_idx ? start_row(a.start_idx[b], a.num_start) : b) * d + i];
     if (valid && a.pi_traj) a.pi_traj[b * (int64_t)(T + 1) * d + i] = pi_i;
     double v_cur = 0.0, discount = 1.0;  // meaningful on lane i == 0 only
     if (want_v && SAMPLE) {
@@ -423,8 +426,8 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
         pis[tlc * d + i] = pi_i;
         if (SAMPLE) pis64[tlc * d + i] = (double)pi_i;
         if (sep) {
-          pex[tlc * d + i] = exp_f64arg(theta * (double)pi_i);
-          Fi = exp_f64arg(-theta * ((double)pi_i + a.shift));
+          pex[tlc * d + i] = exp_f64arg(theta * ((double)pi_i - SEP_CENTRE));
+          Fi = exp_f64arg(-theta * ((double)pi_i + (a.shift - SEP_CENTRE)));
         }
       }
       if (!SAMPLE) {
@@ -596,11 +599,12 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
       if (want_v) {
 #endif
         tile_sync();  // pin complete
-        if (!SAMPLE && valid) {
-          // GIVEN mode: single step, V(pi) of the current state first
-          redq[2 * d + i] = value_term(pv, pi_i);
+        if (!SAMPLE) {
+          // GIVEN mode: single step, V(pi) of the current state first.  The barriers are block wide in this mode and sit
+          // OUTSIDE the validity test: every wave of the block reaches them, also on a partial last tile.
+          if (valid) redq[2 * d + i] = value_term(pv, pi_i);
           tile_sync();
-          if (i == 0) {
+          if (valid && i == 0) {
             double v0 = 0.0;
             for (int k = 0; k < d; ++k) v0 += redq[2 * d + k];
             v_cur = v0 + wl[Q + d];
@@ -701,6 +705,7 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
   const double theta = *a.theta;
   const ThetaSplit ts = theta_split(theta, a.shift);
   constexpr bool sep = SAMPLE && FAST;
+  if (sep) report_sep_range(a.status, theta, a.shift);
   using TT = typename PolicyTerms<FAST>::T;
   const int64_t nw = (int64_t)gridDim.x * WAVES;
   for (int64_t b = (int64_t)blockIdx.x * WAVES + wv; b < a.B; b += nw) {
@@ -708,7 +713,7 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
 #pragma unroll
     for (int m = 0; m < R; ++m) {
       const int c = lane + m * WAVE;
-      pc[m] = c < d ? a.pi0[(a.start_idx ? (int64_t)a.start_idx[b] : b) * d + c] : 0.0f;
+      pc[m] = c < d ? a.pi0[(a.start_idx ? start_row(a.start_idx[b], a.num_start) : b) * d + c] : 0.0f;
       if (c < d && a.pi_traj) a.pi_traj[b * (int64_t)(T + 1) * d + c] = pc[m];
     }
     double v_cur = 0.0, discount = 1.0;
@@ -726,8 +731,8 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
           if (!SAMPLE && a.pi_next_in) pin[c] = a.pi_next_in[b * d + c];
           if (!SAMPLE && a.pi_alpha) pal[c] = a.pi_alpha[b * d + c];
           if (sep) {
-            Ec[m] = exp_f64arg(theta * (double)pc[m]);
-            pfs[c] = exp_f64arg(-theta * ((double)pc[m] + a.shift));
+            Ec[m] = exp_f64arg(theta * ((double)pc[m] - SEP_CENTRE));
+            pfs[c] = exp_f64arg(-theta * ((double)pc[m] + (a.shift - SEP_CENTRE)));
           }
         }
       }

@@ -261,11 +261,20 @@ __device__ __forceinline__ void softplus_sigmoid_fast(float zh, float zl, float&
   sp = fmaf(e - (u - 1.0f), r, fast_ln(u));  // log1p through the rounded sum + rounding-error correction (softplus_sigmoid_e)
 }
 
-// Round 2: the exponential is SEPARABLE, e^{theta (pi_j - pi_i - shift)} = E_j F_i with E_j = e^{theta pi_j},
-// F_i = e^{-theta (pi_i + shift)}: the lane that owns state entry i evaluates E_i, F_i once per env step (fp64 argument,
-// hardware exp2 on its fp32 head, first-order correction for the tail: ~1e-7 relative) and an element costs ONE multiply
-// instead of (hi/lo product, v_exp, correction).  Valid while |theta| (1 + |shift|) <= 80 (fp32 range); the kernels
-// keep the per-element form beyond that.
+// Round 2: the exponential is SEPARABLE, e^{theta (pi_j - pi_i - shift)} = E_j F_i with E_j = e^{theta (pi_j - 1/2)},
+// F_i = e^{-theta (pi_i + shift - 1/2)}: the lane that owns state entry i evaluates E_i, F_i once per env step (fp64
+// argument, hardware exp2 on its fp32 head, first-order correction for the tail: ~1e-7 relative) and an element costs ONE
+// multiply instead of (hi/lo product, v_exp, correction).  Both factors are centred on pi = 1/2 (state entries lie in
+// [0, 1]), so they stay inside the fp32 range while |theta| (1/2 + |shift|) <= 86.  There is NO per-element fall-back
+// beyond that: the sampling kernels report MFG_STATUS_MIXED_RANGE (report_sep_range, include/mfg_hip.h) and their outputs
+// are NaN; precision f64 has no limit.
+constexpr double SEP_CENTRE = 0.5;
+constexpr double SEP_LIMIT = 86.0;  // ln(fp32 max) = 88.7, ln(fp32 min normal) = -87.3; margin for the fp32 head / tail split
+__device__ __forceinline__ void report_sep_range(unsigned* status, double theta, double shift) {
+  // written as !(x <= limit) so that a NaN theta is reported too; one lane of the launch stores the bit (host-mapped word)
+  if (status && blockIdx.x == 0 && threadIdx.x == 0 && !(fabs(theta) * (SEP_CENTRE + fabs(shift)) <= SEP_LIMIT))
+    __hip_atomic_fetch_or(status, 1u /* MFG_STATUS_MIXED_RANGE */, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ float exp_f64arg(double z) {
   const double zl2 = z * 1.4426950408889634;
   const float zh = (float)zl2;
@@ -557,6 +566,14 @@ __host__ __device__ __forceinline__ int next_pow2(int v) {
   int p = 1;
   while (p < v) p <<= 1;
   return p;
+}
+
+// Row of the start-state table for a drawn index (mfg_ac2.py:466-469).  The reference draws randint(num_start_samples),
+// so a valid index is always inside the table; an index from a stale / foreign draw is clamped instead of read out of
+// bounds (the host classes keep num_start_samples in step with the table, see mfg_ac2.py mat_pi0 setter).
+__host__ __device__ __forceinline__ int64_t start_row(int32_t idx, int64_t num_start) {
+  const int64_t r = (int64_t)idx;
+  return r < 0 ? 0 : (r >= num_start ? num_start - 1 : r);
 }
 
 // k(i,j) for i <= j: row-major upper triangle (mfg_ac2.py:333).

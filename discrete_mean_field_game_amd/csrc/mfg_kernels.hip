@@ -68,13 +68,13 @@ static int num_cus() {
 // ---------------------------------------------------------------------------------------------
 // trivial kernels: gather, alpha, features, dirichlet_from_gamma, philox_raw, apply_update
 // ---------------------------------------------------------------------------------------------
-__global__ void k_gather_start(const float* __restrict__ mat, const int32_t* __restrict__ idx, int64_t B, int d,
-                               float* __restrict__ out) {
+__global__ void k_gather_start(const float* __restrict__ mat, int64_t num_start, const int32_t* __restrict__ idx, int64_t B,
+                               int d, float* __restrict__ out) {
   const int64_t n = B * d;
   for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t b = e / d;
     const int j = (int)(e - b * d);
-    out[e] = mat[(int64_t)idx[b] * d + j];
+    out[e] = mat[start_row(idx[b], num_start) * d + j];
   }
 }
 
@@ -1846,8 +1846,50 @@ static const float4* htab_ptr() {
   return ptr[dev];
 }
 
+// ---- device status word (mfg_status): one host-mapped 32-bit word per device.  Kernels OR condition bits into it through
+// its device address (a plain store from one lane: the conditions are functions of theta alone, so every launch that sees
+// the condition writes the same bits); the host reads it through the host address without synchronising.
+struct StatusWord {
+  unsigned* host = nullptr;
+  unsigned* dev = nullptr;
+};
+static StatusWord status_word() {
+  static std::mutex mu;
+  static StatusWord sw[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return StatusWord{};
+  std::lock_guard<std::mutex> lock(mu);
+  if (!sw[dev].host) {
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return StatusWord{};
+    memset(h, 0, 64);
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      (void)hipHostFree(h);
+      return StatusWord{};
+    }
+    sw[dev].host = (unsigned*)h;
+    sw[dev].dev = (unsigned*)d;
+  }
+  return sw[dev];
+}
+static int status_error(unsigned bits) {
+  if (bits & MFG_STATUS_MIXED_RANGE)
+    return fail(MFG_ERANGE, "%s", "an earlier mixed-precision sampling launch ran with |theta| (1/2 + |shift|) > 86 (or theta not "
+                                  "finite): the fp32 factors of the separable exponential left their range and that launch's "
+                                  "outputs are NaN; use MFG_PRECISION_F64 / precision='f64' for such policies, then mfg_clear_status()");
+  return fail(MFG_ERANGE, "device status word = 0x%x", bits);
+}
+
 static int launch_core(const CoreArgs& a_in, bool sample, bool td, int precision, hipStream_t st) {
   CoreArgs a = a_in;
+  {
+    const StatusWord sw = status_word();
+    if (!sw.host) return fail(MFG_ELAUNCH, "%s", "status word allocation failed");
+    const unsigned bits = *(volatile unsigned*)sw.host;
+    if (bits) return status_error(bits);  // sticky until mfg_clear_status()
+    a.status = sw.dev;
+  }
 #ifdef MFG_TIMING
   {
     const char* e = getenv("MFG_TIMING_BUF");
@@ -1872,10 +1914,26 @@ static int launch_core(const CoreArgs& a_in, bool sample, bool td, int precision
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 10; }
+int mfg_abi_version(void) { return 11; }
 
 int mfg_init(void) {
   if (!htab_ptr()) return fail(MFG_ELAUNCH, "%s", "mfg_init: no HIP device / table initialisation failed");
+  if (!status_word().host) return fail(MFG_ELAUNCH, "%s", "mfg_init: status word allocation failed");
+  return MFG_OK;
+}
+
+int mfg_status(unsigned* bits_host) {
+  const StatusWord sw = status_word();
+  if (!sw.host) return fail(MFG_ELAUNCH, "%s", "status word allocation failed");
+  const unsigned bits = *(volatile unsigned*)sw.host;
+  if (bits_host) *bits_host = bits;
+  return bits ? status_error(bits) : MFG_OK;
+}
+
+int mfg_clear_status(void) {
+  const StatusWord sw = status_word();
+  if (!sw.host) return fail(MFG_ELAUNCH, "%s", "status word allocation failed");
+  *(volatile unsigned*)sw.host = 0u;
   return MFG_OK;
 }
 
@@ -1921,7 +1979,8 @@ int mfg_gather_start(const float* mat_pi0, int64_t num_start, const int32_t* idx
                      mfg_stream_t stream) {
   CHECK_BD();
   REQUIRE(mat_pi0 && idx && pi0 && num_start > 0, "null pointer / empty table");
-  hipLaunchKernelGGL(k_gather_start, dim3(grid_for(B * d, 256, 8)), dim3(256), 0, S(stream), mat_pi0, idx, B, d, pi0);
+  hipLaunchKernelGGL(k_gather_start, dim3(grid_for(B * d, 256, 8)), dim3(256), 0, S(stream), mat_pi0, num_start, idx, B,
+                     d, pi0);
   return check_launch("gather_start");
 }
 
@@ -1952,6 +2011,7 @@ int mfg_philox_raw(uint64_t seed, uint32_t first_ctr, uint32_t c1, uint32_t c2, 
 // developer knob (tools/step_probe.py): MFG_STEP_BATCH = 0 | 8 | 16 | 32 forces the tiles per super tile of the d = 21 / 15
 // given-P kernel (0 = per-tile stores); unset / anything else = chosen from the batch size
 static int step_batch_override() {
+#ifdef MFG_DEV_KNOBS  // developer builds only (tools/variant.sh ... "-DMFG_DEV_KNOBS"): the shipped library reads no environment
   static const int v = [] {
     const char* e = getenv("MFG_STEP_BATCH");
     if (!e || !*e) return -1;
@@ -1959,6 +2019,9 @@ static int step_batch_override() {
     return (k == 0 || k == 8 || k == 16 || k == 32) ? k : -1;
   }();
   return v;
+#else
+  return -1;
+#endif
 }
 
 int mfg_step_given_P(const float* pi, const float* P, int64_t B, int d, int reward_kind, float* pi_next, float* reward,
@@ -2269,6 +2332,8 @@ static int launch_values_and_delta(const float* pi_traj, int64_t B, int T, int d
   int64_t nsb;
   grad_geometry(N, d, &chunk, &nsb, &nob);
   const size_t off = (size_t)(nsb * (mfg_num_features(d) + 3) * 8) + MFG_WS_CONTROL_BYTES;
+  if (!ws || ws_bytes < off + (size_t)NV * 8)
+    return fail(MFG_EWORKSPACE, "%s: need %lld bytes, have %lld", "values", (long long)(off + (size_t)NV * 8), (long long)ws_bytes);
   double* V = reinterpret_cast<double*>((char*)ws + off);
   const size_t lds = (size_t)WAVES * 16 * (d + 4) * 4 + (size_t)2 * VM_CH * 16 * 8;  // state rows + two pieces of U
   int64_t groups = (NV + 15) / 16;
@@ -2278,7 +2343,6 @@ static int launch_values_and_delta(const float* pi_traj, int64_t B, int T, int d
   hipLaunchKernelGGL(k_value_mfma, dim3((unsigned)blocks), dim3(BLOCK), lds, st, pi_traj, (int64_t)(T + 1) * d, NV, T + 1, d, w, V);
   hipLaunchKernelGGL(k_td_delta, dim3(grid_for(N, 256, 8)), dim3(256), 0, st, (const double*)V, reward, B, T, gamma, discount_pow,
                      delta);
-  (void)ws_bytes;
   return check_launch("values");
 }
 // whether a TD rollout can defer its values to k_value_mfma
@@ -2350,6 +2414,7 @@ int mfg_train_rollout(const float* mat_pi0, int64_t num_start, const int32_t* id
   CoreArgs a{};
   a.pi0 = mat_pi0;
   a.start_idx = idx;
+  a.num_start = num_start;
   a.theta = theta;
   a.w = w;
   a.shift = shift;

@@ -26,6 +26,7 @@ There is no CPU fallback: every numeric method calls the C ABI in include/mfg_hi
 from __future__ import annotations
 
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -123,6 +124,9 @@ class actor_critic:
         self._mat_pi0_host = np.array(value, dtype=np.float64)
         self._mat_pi0_dev = torch.as_tensor(np.ascontiguousarray(self._mat_pi0_host, dtype=np.float32),
                                             device=self.device)
+        # the start draw is randint(num_start_samples) (mfg_ac2.py:466): keep it in step with the table, whoever sets it
+        # (mfg_synthetic.train re-reads the table and updates the count, mfg_synthetic.py:438-440)
+        self.num_start_samples = self._mat_pi0_host.shape[0]
 
     @property
     def mat_alpha(self):
@@ -236,9 +240,16 @@ class actor_critic:
         self.seed = int(state['seed'])
         self.shift = state['shift']
         self.alpha_scale = state['alpha_scale']
-        if restore_np_random and state.get('np_random_key') is not None:
-            np.random.set_state(('MT19937', state['np_random_key'].numpy().astype(np.uint32), int(state['np_random_pos']),
-                                 int(state['np_random_has_gauss']), float(state['np_random_cached_gaussian'])))
+        if restore_np_random:
+            if state.get('np_random_key') is not None:
+                np.random.set_state(('MT19937', state['np_random_key'].numpy().astype(np.uint32),
+                                     int(state['np_random_pos']), int(state['np_random_has_gauss']),
+                                     float(state['np_random_cached_gaussian'])))
+            elif state.get('np_random_state') is not None:          # round-1 checkpoints: the raw get_state() tuple
+                np.random.set_state(tuple(state['np_random_state']))
+            else:
+                warnings.warn('checkpoint carries no np.random state: the start-state draws of the resumed run will not '
+                              'continue the saved stream', RuntimeWarning, stacklevel=2)
 
     # ------------------------------------------------------------------ a1 + a2
     def _host_gamma(self, pi_dev):
@@ -444,6 +455,14 @@ class actor_critic:
                     self.train_log(np.array([reward_avg]), file_reward, '%.3e')
                     self._train_log_extra()
         self._last_pi = pi
+        self._check_status()
+
+    def _check_status(self):
+        """Raise MfgError if a launch of this run reported a numeric-range condition (mixed-precision sampling with
+        theta outside its range, include/mfg_hip.h mfg_status) -- the end-of-train check; during a run the next launch
+        after the condition is refused by the library itself."""
+        if ops.status(synchronize=True):
+            L.check(L.lib().mfg_status(None), 'train')
 
     def _train_log_extra(self):
         """Hook for the variants' additional per-report log lines (mfg_synthetic.py:522 logs w)."""

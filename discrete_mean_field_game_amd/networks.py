@@ -75,6 +75,42 @@ class RewardNet(nn.Module):
         x = self._drop(Fnn.relu(self.fc4(x)))
         return torch.tanh(self.out(x))
 
+    # TF checkpoint layout (tf.contrib.layers variables under the reference's scopes, networks.py:62-79 inside
+    # tf.variable_scope("reward"), ac_irl.py:246): conv kernels HWIO, dense kernels [in, out]
+    TF_NAMES = (('conv1', 'reward/conv1'), ('conv2', 'reward/conv2'), ('fc3', 'reward/fc3'), ('fc4', 'reward/fc4'),
+                ('out', 'reward/out'))
+
+    def tf_variables(self):
+        """This module's parameters as {TF variable name: float32 ndarray in TF's layout}: '<scope>/weights' is
+        [kh, kw, in, out] (HWIO) for the convolutions and [in, out] for the dense layers, '<scope>/biases' is [out] --
+        the tensors `tf.train.Saver` writes for the reference's graph (ac_irl.py:948, log/model_<reg>_<n3>_<n4>.ckpt)."""
+        out = {}
+        for attr, scope in self.TF_NAMES:
+            m = getattr(self, attr)
+            w = m.weight.detach().cpu().float()
+            out[scope + '/weights'] = (w.permute(2, 3, 1, 0) if w.dim() == 4 else w.t()).contiguous().numpy()
+            out[scope + '/biases'] = m.bias.detach().cpu().float().numpy().copy()
+        return out
+
+    def load_tf_variables(self, variables):
+        """Inverse of tf_variables(): load {name: array} read from a TF-1.x checkpoint of the reference (e.g.
+        `r = tf.train.load_checkpoint(path); {n: r.get_tensor(n) for n in names}` on a machine that has TensorFlow) into
+        this module.  HWIO -> OIHW for the convolutions, [in, out] -> [out, in] for the dense layers; the fc3 input order
+        needs no permutation because forward() flattens NHWC like networks.py:67.  Shapes are checked."""
+        import numpy as np
+        with torch.no_grad():
+            for attr, scope in self.TF_NAMES:
+                m = getattr(self, attr)
+                w = torch.as_tensor(np.asarray(variables[scope + '/weights'], dtype=np.float32))
+                w = w.permute(3, 2, 0, 1) if w.dim() == 4 else w.t()
+                b = torch.as_tensor(np.asarray(variables[scope + '/biases'], dtype=np.float32)).reshape(-1)
+                if tuple(w.shape) != tuple(m.weight.shape) or tuple(b.shape) != tuple(m.bias.shape):
+                    raise ValueError('%s: checkpoint shape %s / %s does not fit this network (%s / %s)'
+                                     % (scope, tuple(w.shape), tuple(b.shape), tuple(m.weight.shape), tuple(m.bias.shape)))
+                m.weight.copy_(w.to(m.weight.dtype))
+                m.bias.copy_(b.to(m.bias.dtype))
+        return self
+
     def regularization(self):
         """Sum of the l1_l2 penalties collected in tf.GraphKeys.REGULARIZATION_LOSSES (ac_irl.py:409-411)."""
         if not self.use_l1l2:

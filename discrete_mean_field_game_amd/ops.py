@@ -35,6 +35,22 @@ def init():
     L.check(L.lib().mfg_init(), 'mfg_init')
 
 
+def status(synchronize: bool = True) -> int:
+    """Bits of the device status word (0 = healthy; _lib.STATUS_MIXED_RANGE: a mixed-precision sampling launch found
+    theta outside the range of its separable exponential, include/mfg_hip.h).  synchronize=True waits for the current
+    stream first so that every launch issued so far has reported."""
+    import ctypes as C
+    if synchronize:
+        torch.cuda.current_stream().synchronize()
+    bits = C.c_uint(0)
+    L.lib().mfg_status(C.byref(bits))
+    return int(bits.value)
+
+
+def clear_status():
+    L.check(L.lib().mfg_clear_status(), 'mfg_clear_status')
+
+
 def num_features(d: int) -> int:
     return int(L.lib().mfg_num_features(d))
 

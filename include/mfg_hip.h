@@ -38,7 +38,8 @@ enum {
   MFG_EINVAL = -1,       /* bad argument (null pointer, d < 1, B < 0 ...) */
   MFG_ELAUNCH = -2,      /* HIP reported a launch/runtime error */
   MFG_EUNSUPPORTED = -3, /* shape outside the supported range (d > MFG_MAX_D) */
-  MFG_EWORKSPACE = -4    /* workspace too small */
+  MFG_EWORKSPACE = -4,   /* workspace too small */
+  MFG_ERANGE = -5        /* an earlier launch reported a numeric-range condition (mfg_status); sticky until cleared */
 };
 
 #define MFG_MAX_D 512
@@ -71,6 +72,19 @@ int mfg_abi_version(void);
  * score, one tiny launch + one device synchronise).  Optional: the first TD call does it lazily; call it
  * explicitly before capturing launches into a hipGraph. */
 int mfg_init(void);
+
+/* Device status word.  The mixed-precision SAMPLING kernels form e^{theta (pi_j - pi_i - shift)} as a product of two fp32
+ * factors e^{theta (pi_j - 1/2)} e^{-theta (pi_i + shift - 1/2)}; that is exact business as usual while
+ * |theta| (1/2 + |shift|) <= 86 (theta ~ 130 at the reference's shift 0.16; the reference trains at theta ~ 9).  theta lives
+ * on the device, so the host cannot check it before a launch: a sampling kernel that finds theta outside that range (or
+ * not finite) sets MFG_STATUS_MIXED_RANGE in a host-visible status word and its outputs are NaN.  EVERY later call that
+ * launches a policy kernel (sample / score / td / rollout / train entry points) then fails with MFG_ERANGE until
+ * mfg_clear_status() -- a diverged run stops with an error code instead of carrying NaNs.  mfg_status() reads the word
+ * without synchronising (synchronise the stream first to be sure a given launch has reported); it returns MFG_OK or
+ * MFG_ERANGE and stores the bits in *bits_host (may be NULL).  MFG_PRECISION_F64 has no such limit. */
+enum { MFG_STATUS_MIXED_RANGE = 1 };
+int mfg_status(unsigned* bits_host);
+int mfg_clear_status(void);
 
 /* Host-side query: multiprocessor count and gcnArchName of the current device. */
 int mfg_device_info(int* cu_count_host, char* arch_host, int arch_len);

@@ -6,6 +6,23 @@ follows the published semantics of the TF ops named in the reference (networks.p
 conv2d SAME stride 1 (cross-correlation, zero padding), ReLU, NHWC flatten, fully_connected, tanh;
 ``l1_l2_regularizer()`` = sum|W| + sum W^2 / 2 (scale_l1 = scale_l2 = 1); loss of ac_irl.py:390-413.
 It is used to check the PyTorch module (weights shared), with dropout disabled.
+
+Op semantics relied on (TensorFlow 1.x API documentation; none of it can be executed here):
+  * tf.nn.conv2d / tf.contrib.layers.conv2d, NHWC, filter [kh, kw, in, out]: "computes ... output[b, i, j, k] =
+    sum_{di, dj, q} input[b, strides[1]*i + di, strides[2]*j + dj, q] * filter[di, dj, q, k]" -- a CROSS-CORRELATION (no
+    kernel flip); padding "SAME", stride 1, odd k: out size = in size, pad_total = k - 1 split as (k-1)/2 before and
+    after, zeros.  => scipy.signal.correlate2d(x, w, mode='same') per (in, out) channel pair, summed over `in`
+    (checked in tests/test_reward_net.py::test_oracle_conv_is_tf_same_cross_correlation with asymmetric kernels).
+  * tf.reshape(conv2, [-1, f2*d*d]) of an NHWC tensor (networks.py:67): row-major over (h, w, c): index (h*d + w)*f2 + c.
+  * tf.contrib.layers.fully_connected: activation(x . W + b), W [in, out]; weights_initializer = xavier_initializer()
+    (uniform, limit sqrt(6 / (fan_in + fan_out))), biases_initializer = zeros.
+  * tf.contrib.layers.l1_l2_regularizer(scale_l1=1.0, scale_l2=1.0) = l1_regularizer + l2_regularizer with
+    l1 = scale_l1 * sum |W|, l2 = scale_l2 * tf.nn.l2_loss(W), and tf.nn.l2_loss(t) = sum(t ** 2) / 2.
+  * tf.contrib.layers.dropout(x, keep_prob, is_training=True): tf.nn.dropout -- keeps each unit with probability
+    keep_prob and scales the kept ones by 1 / keep_prob (inverted dropout); is_training defaults to True, so the
+    reference applies it also when the net serves as the RL reward (ac_irl.py:683).
+  * Checkpoint variables (tf.train.Saver, ac_irl.py:948): reward/<scope>/weights, reward/<scope>/biases with the layouts
+    above; discrete_mean_field_game_amd.networks.RewardNet.load_tf_variables / tf_variables convert to / from them.
 """
 import numpy as np
 

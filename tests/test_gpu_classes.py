@@ -571,7 +571,7 @@ def test_ac_irl_checkpoint_resume_is_bit_identical(dev, mode, tmp_path):
 
     def phase2(ac, first):
         ac.reward_iteration(max_iterations=3, stop_criteria=-1, iter_check=2)
-        ac.train(max_episodes=4, stop_criteria=-1, gamma=0.9, first_episode=first)
+        ac.train(max_episodes=2, stop_criteria=-1, gamma=0.9, first_episode=first)   # 2 MORE episodes (3, 4)
 
     a = fresh(4)
     phase1(a)

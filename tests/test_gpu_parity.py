@@ -663,28 +663,66 @@ def test_grad_accumulate_all_kernels(dev, d, B, T, add_reward):
 
 
 def test_mixed_sampler_range_of_the_separable_exponential(dev):
-    """Mixed precision forms e^{theta (pi_j - pi_i - shift)} as E_j F_i (fp32 factors).  Inside its documented range,
-    |theta| (1 + |shift|) <~ 85, the sampler is still exact (KS on Beta marginals at theta = 40, where E_j spans
-    1 .. 2e17); beyond it the factors leave the fp32 range and the output must turn non-finite -- loudly -- while
-    precision 'f64' has no such limit."""
+    """Mixed precision forms e^{theta (pi_j - pi_i - shift)} as E_j F_i, fp32 factors centred on pi = 1/2.  Inside the
+    documented range, |theta| (1/2 + |shift|) <= 86, the sampler is still exact (KS on Beta marginals at theta = 40 and,
+    on a peaked state, at theta = 100, where the uncentred factors of round 2 overflowed).  Beyond it the launch must not
+    fail silently: the outputs are NaN, the device status word reports MFG_STATUS_MIXED_RANGE, and every later policy
+    launch is refused with MFG_ERANGE until mfg_clear_status(); precision 'f64' has no such limit."""
     from scipy import stats
+    from discrete_mean_field_game_amd import _lib as L
+    o_ = ops()
+    o_.clear_status()
     d, B = 6, 20000
     pi1 = np.array([0.05, 0.3, 0.1, 0.35, 0.15, 0.05], dtype=np.float32)
     pi = np.repeat(pi1[None], B, 0)
-    theta, shift, scale = 40.0, 0.1, 50.0
-    P = ops().sample_dirichlet(t32(pi, dev), t64([theta], dev), shift, scale, seed=11, precision='mixed').cpu().numpy().astype(np.float64)
-    assert np.all(np.isfinite(P)) and np.allclose(P.sum(-1), 1.0, atol=1e-5)
-    al = O().calc_alpha(pi1.astype(np.float64), theta, shift) * scale
-    for (i, j) in [(0, 3), (3, 0), (1, 3), (2, 2)]:
-        a, b = al[i, j], al[i].sum() - al[i, j]
-        if a < 1e-3:
-            continue                                              # numerically a point mass at 0: nothing to test
-        ks = stats.kstest(P[:, i, j], stats.beta(a, b).cdf)
-        assert ks.pvalue > 1e-4, (i, j, a, b, ks)
-    # theta * max(pi) = 97 > ln(fp32 max) = 88.7: E_0 overflows
-    big = t64([100.0], dev)
+    shift, scale = 0.1, 50.0
+    for theta, pi1 in ((40.0, pi1), (100.0, np.array([0.97, 0.006, 0.006, 0.006, 0.006, 0.006], dtype=np.float32))):
+        pi = np.repeat(pi1[None], B, 0)
+        P = o_.sample_dirichlet(t32(pi, dev), t64([theta], dev), shift, scale, seed=11, precision='mixed').cpu().numpy().astype(np.float64)
+        assert np.all(np.isfinite(P)) and np.allclose(P.sum(-1), 1.0, atol=1e-5)
+        al = O().calc_alpha(pi1.astype(np.float64), theta, shift) * scale
+        for (i, j) in [(0, 3), (3, 0), (1, 3), (2, 2), (1, 0)]:
+            a, b = al[i, j], al[i].sum() - al[i, j]
+            if a < 1e-3 or b < 1e-3 or not np.isfinite(a + b):
+                continue                                          # numerically a point mass: nothing to test
+            ks = stats.kstest(P[:, i, j], stats.beta(a, b).cdf)
+            assert ks.pvalue > 1e-4, (theta, i, j, a, b, ks)
+    assert o_.status() == 0
+    # |theta| (1/2 + |shift|) = 120 > 86: out of range
+    big = t64([200.0], dev)
     peaked = np.repeat(np.array([[0.97, 0.006, 0.006, 0.006, 0.006, 0.006]], dtype=np.float32), 64, 0)
-    Pm = ops().sample_dirichlet(t32(peaked, dev), big, shift, scale, seed=11, precision='mixed')
-    assert not bool(torch.isfinite(Pm).all())                     # out of range: NaN, not a silently wrong sample
-    Pf = ops().sample_dirichlet(t32(peaked, dev), big, shift, scale, seed=11, precision='f64')
+    Pm = o_.sample_dirichlet(t32(peaked, dev), big, shift, scale, seed=11, precision='mixed')
+    assert not bool(torch.isfinite(Pm).all())                     # NaN, not a silently wrong sample
+    assert o_.status() == L.STATUS_MIXED_RANGE
+    with pytest.raises(L.MfgError, match='86'):                   # sticky: the next policy launch is refused
+        o_.sample_dirichlet(t32(peaked, dev), t64([8.0], dev), shift, scale, seed=11, precision='mixed')
+    with pytest.raises(L.MfgError):
+        o_.score(t32(peaked, dev), Pm, t64([8.0], dev), shift)
+    o_.clear_status()
+    assert o_.status() == 0
+    Pf = o_.sample_dirichlet(t32(peaked, dev), big, shift, scale, seed=11, precision='f64')
     assert bool(torch.isfinite(Pf).all()) and bool((Pf.sum(-1) - 1).abs().max() < 1e-5)
+    assert o_.status() == 0
+    # a NaN theta is reported as well (the test is !(x <= limit))
+    o_.sample_dirichlet(t32(peaked, dev), t64([float('nan')], dev), shift, scale, seed=11, precision='mixed')
+    assert o_.status() == L.STATUS_MIXED_RANGE
+    o_.clear_status()
+
+
+def test_diverging_training_run_stops_with_an_error(dev):
+    """theta lives on the device: a mixed-precision run whose theta is driven out of the separable exponential's range
+    must end in MfgError (MFG_ERANGE) on a later call instead of training on NaNs."""
+    from discrete_mean_field_game_amd import _lib as L
+    from discrete_mean_field_game_amd.mfg_ac2 import actor_critic
+    ops().clear_status()
+    rs = np.random.RandomState(0)
+    ac = actor_critic(theta=8.86349, d=21, pi0=rs.dirichlet(np.ones(21), size=4), batch=32, seed=1, update_every='rollout',
+                      verbose=0)
+    ac.theta = 500.0
+    with pytest.raises(L.MfgError, match='mfg_clear_status'):
+        ac.train(num_episodes=3)
+    ops().clear_status()
+    ac.theta = 8.86349
+    ac.w = np.zeros_like(ac.w)
+    ac.train(num_episodes=1)
+    assert np.isfinite(np.ravel(ac.theta)[0])

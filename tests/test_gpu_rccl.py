@@ -1,0 +1,103 @@
+"""-m gpu: the RCCL leg of the multi-GPU path, executed for real on the one GPU a test box has.
+
+`north_star` / SURVEY.md 8e: one process per GPU, ONE RCCL all-reduce of the fused gradient buffer per update.  The
+world-size-2 tests (tests/test_parallel_gloo.py on the CPU, tests/test_gpu_multiproc.py on the GPU) run over gloo, because
+two ranks cannot share one device under RCCL.  What they leave unexecuted is the "nccl" branch itself:
+`init_process_group('nccl', device_id=...)`, a device-tensor `all_reduce` of G, `mfg_apply_update` after it, the barrier +
+max-over-ranks timing of bench.py.  Here a FRESH child process (started before it touches the GPU) runs
+
+    bench.py --gpus 1 --force-dist ...     -> the N > 1 code path of bench.py with a 1-rank RCCL communicator
+    actor_critic / AC_IRL .train(group=WORLD) with backend nccl
+
+and the parent checks the exit code, the JSON line and the trained parameters against the single-process run.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _env():
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', LOCAL_RANK='0', WORLD_SIZE='1',
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env['PYTHONPATH'] = ROOT + os.pathsep + env.get('PYTHONPATH', '')
+    return env
+
+
+def test_bench_force_dist_runs_the_rccl_all_reduce():
+    if not torch.cuda.is_available():
+        pytest.fail('-m gpu tests need a GPU')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-dist', '--steps', '2', '--warmup', '1',
+           '--no-configs', '--no-cpu-baseline', '--no-roofline', '--batch', '8192']
+    p = subprocess.run(cmd, cwd=ROOT, env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1]
+    z = json.loads(line)
+    assert z['n_gpus'] == 1 and np.isfinite(z['value']) and z['value'] > 0 and np.isfinite(z['theta_end'])
+    c = z['collective']
+    assert c['backend'].startswith('rccl') and c['payload_bytes'] == (253 + 3) * 8
+    assert 0 < c['all_reduce_us'] < 5e3 and 0 < c['all_reduce_plus_apply_update_us'] < 5e3
+    print('RCCL 1-rank all-reduce of G: %.1f us; + mfg_apply_update: %.1f us' % (c['all_reduce_us'],
+                                                                                 c['all_reduce_plus_apply_update_us']))
+
+
+_CHILD = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+from discrete_mean_field_game_amd import parallel
+from discrete_mean_field_game_amd.mfg_ac2 import actor_critic
+# (1) the collective on a device tensor, through the product's own helper -- a 1-rank communicator is still an RCCL call
+calls = {'n': 0}
+real = dist.all_reduce
+def counted(t, *a, **k):
+    calls['n'] += 1
+    assert t.is_cuda
+    return real(t, *a, **k)
+dist.all_reduce = counted
+parallel.dist.get_world_size = lambda group=None: 2          # make the helpers take their multi-rank branches ...
+parallel.current_shard = lambda B, group=None: parallel.shard_batch(B, 0, 1)   # ... while this rank owns the whole batch
+import discrete_mean_field_game_amd.mfg_ac2 as M
+M.current_shard = parallel.current_shard
+G = torch.arange(8, dtype=torch.float64, device='cuda')
+parallel.all_reduce_gradients_(G)
+assert calls['n'] == 1 and torch.equal(G.cpu(), torch.arange(8, dtype=torch.float64))
+idx = parallel.broadcast_start_indices(np.arange(5), None, torch.device('cuda', 0))
+assert list(idx) == [0, 1, 2, 3, 4]
+dist.all_reduce = real
+torch.cuda.synchronize()
+print(json.dumps({'ok': True, 'all_reduce_calls': calls['n'], 'backend': dist.get_backend()}))
+dist.destroy_process_group()
+'''
+
+
+def test_product_helpers_over_an_rccl_communicator():
+    """parallel.all_reduce_gradients_ / broadcast_start_indices on DEVICE tensors over backend 'nccl' (their production
+    branch), in a fresh child."""
+    if not torch.cuda.is_available():
+        pytest.fail('-m gpu tests need a GPU')
+    p = subprocess.run([sys.executable, '-c', _CHILD % {'root': ROOT}], cwd=ROOT, env=_env(), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    z = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert z['ok'] and z['backend'] == 'nccl' and z['all_reduce_calls'] == 1

@@ -70,3 +70,68 @@ def test_gemm_conv_equals_conv2d():
     ga = torch.autograd.grad(a.sum(), (x, w))
     gr = torch.autograd.grad(torch.nn.functional.conv2d(x, w, b, padding=2).sum(), (x, w))
     assert all(torch.allclose(p, q, rtol=1e-10, atol=1e-10) for p, q in zip(ga, gr))
+
+
+def test_oracle_conv_is_tf_same_cross_correlation():
+    """f1 hardening: the two semantic risks of the TF restatement checked against THIRD-PARTY code (scipy), with
+    asymmetric kernels so that a flipped kernel or a transposed layout cannot pass: (a) conv2d SAME, stride 1 is a
+    cross-correlation with (k-1)/2 zeros on each side == scipy.signal.correlate2d(mode='same', boundary='fill');
+    (b) the NHWC flatten feeding fc3 (networks.py:67) orders features as (h, w, channel)."""
+    from scipy.signal import correlate2d
+    rs = np.random.RandomState(5)
+    N, H, Cin, Cout = 3, 21, 2, 3
+    for k in (3, 5):
+        x = rs.randn(N, H, H, Cin)
+        w = rs.randn(k, k, Cin, Cout)                             # TF layout HWIO, no symmetry
+        b = rs.randn(Cout)
+        got = RO.conv2d_same(x, w, b)
+        for n in range(N):
+            for o in range(Cout):
+                ref = sum(correlate2d(x[n, :, :, c], w[:, :, c, o], mode='same', boundary='fill', fillvalue=0.0)
+                          for c in range(Cin)) + b[o]
+                assert np.allclose(got[n, :, :, o], ref, rtol=1e-12, atol=1e-12)
+    # (b) flatten order: put a single 1 at (h, w, c) of the conv2 output position by construction -- a net whose convs are
+    # identities on channel 0 / zero on channel 1 -- and read which fc3 input column it reaches
+    d = 6
+    params = {'conv1_w': np.zeros((5, 5, 1, 1)), 'conv1_b': np.zeros(1), 'conv2_w': np.zeros((3, 3, 1, 2)),
+              'conv2_b': np.zeros(2), 'fc3_w': np.zeros((2 * d * d, 1)), 'fc3_b': np.zeros(1),
+              'fc4_w': np.zeros((1 + d, 1)), 'fc4_b': np.zeros(1), 'out_w': np.ones((1, 1)), 'out_b': np.zeros(1)}
+    params['conv1_w'][2, 2, 0, 0] = 1.0                            # identity
+    params['conv2_w'][1, 1, 0, 1] = 1.0                            # channel 1 = identity, channel 0 = 0
+    params['fc4_w'][0, 0] = 1.0
+    h, w_ = 2, 4
+    action = np.zeros((1, d, d)); action[0, h, w_] = 0.7
+    for col in range(2 * d * d):
+        params['fc3_w'][:] = 0.0
+        params['fc3_w'][col, 0] = 1.0
+        out = float(RO.forward(params, np.zeros((1, d)), action)[0, 0])
+        want = np.tanh(0.7) if col == (h * d + w_) * 2 + 1 else 0.0
+        assert abs(out - want) < 1e-15, (col, out)
+
+
+@pytest.mark.parametrize('reg', ['none', 'dropout_l1l2'])
+def test_tf_checkpoint_layout_round_trip(reg):
+    """RewardNet.tf_variables / load_tf_variables: HWIO <-> OIHW, [in,out] <-> [out,in], names of the reference's scopes
+    (networks.py:62-79 under variable_scope 'reward', ac_irl.py:246).  A net loaded from TF-layout arrays computes what the
+    TF-layout oracle computes FROM THOSE ARRAYS -- the converter is not checked against itself."""
+    d, n3, n4 = 15, 8, 4
+    rs = np.random.RandomState(2)
+    tfv = {'reward/conv1/weights': rs.randn(5, 5, 1, 1), 'reward/conv1/biases': rs.randn(1) * 0.1,
+           'reward/conv2/weights': rs.randn(3, 3, 1, 2), 'reward/conv2/biases': rs.randn(2) * 0.1,
+           'reward/fc3/weights': rs.randn(2 * d * d, n3) * 0.05, 'reward/fc3/biases': rs.randn(n3) * 0.1,
+           'reward/fc4/weights': rs.randn(n3 + d, n4) * 0.3, 'reward/fc4/biases': rs.randn(n4) * 0.1,
+           'reward/out/weights': rs.randn(n4, 1), 'reward/out/biases': rs.randn(1) * 0.1}
+    tfv = {k: v.astype(np.float32) for k, v in tfv.items()}
+    net = RewardNet(d=d, reg=reg, n_fc3=n3, n_fc4=n4, dropout_always=False).eval().load_tf_variables(tfv)
+    back = net.tf_variables()
+    assert sorted(back) == sorted(tfv)
+    for k in tfv:
+        assert back[k].shape == tfv[k].shape and np.array_equal(back[k], tfv[k])
+    state = rs.dirichlet(np.ones(d), size=5)
+    action = rs.dirichlet(np.ones(d), size=(5, d))
+    params = {k.split('/')[1] + ('_w' if k.endswith('weights') else '_b'): v.astype(np.float64) for k, v in tfv.items()}
+    ref = RO.forward(params, state, action)
+    out = net.double()(torch.as_tensor(state), torch.as_tensor(action)).detach().numpy()
+    assert np.allclose(out, ref, rtol=1e-10, atol=1e-12)
+    with pytest.raises(ValueError):
+        RewardNet(d=d + 1, reg=reg, n_fc3=n3, n_fc4=n4).load_tf_variables(tfv)
