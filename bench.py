@@ -407,6 +407,41 @@ def other_configs(training_leg, given_p_leg, d0, T0, B0, args):
             del st
         except Exception as exc:  # informational: never fail the headline on it
             out.append({'config': name, 'error': repr(exc)})
+    # strong-scaling shards of the headline batch on THIS GPU (what each rank of an N-GPU run executes per update before
+    # its all-reduce: rollout + batch sums, then update), so the scaling projection is driver-visible without a node
+    try:
+        sh = []
+        for n in (2, 4, 8):
+            b = B0 // n
+            if b < 1:
+                continue
+            e, _, st = training_leg(d0, T0, b, 40, 5)
+            sh.append({'gpus': n, 'batch_per_gpu': b, 'ms_per_update': e / 40 * 1e3, 'env_steps_per_s_per_gpu': b * T0 * 40 / e})
+            del st
+        out.append({'config': 'strong-scaling shards of the headline batch, one GPU each (no collective)', 'd': d0, 'T': T0,
+                    'shards': sh})
+    except Exception as exc:
+        out.append({'config': 'shards', 'error': repr(exc)})
+    # reference semantics: theta and w move after EVERY env step (mfg_ac2.py:505-522), batch-mean gradient; the 15-step
+    # episode is issued natively (mfg_train_episode: 15 x [fused step kernel | batch sums + update])
+    try:
+        from discrete_mean_field_game_amd.mfg_ac2 import actor_critic
+        rs = np.random.RandomState(0)
+        mat = rs.dirichlet(np.ones(21), size=64)
+        for Bs, episodes in ((65536, 20), (4096, 60)):
+            np.random.seed(5)
+            ac = actor_critic(d=21, pi0=mat, batch=Bs, seed=3, update_every='step', verbose=0)
+            ac.train(num_episodes=3, consecutive=10 ** 9)
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            ac.train(num_episodes=episodes, consecutive=10 ** 9, first_episode=3)
+            torch.cuda.synchronize()
+            dt = _t.perf_counter() - t0
+            out.append({'config': 'mfg_ac2.train, update per env step (reference semantics), class API', 'd': 21, 'T': 15,
+                        'batch': Bs, 'episodes': episodes, 'env_steps_per_s': Bs * 15 * episodes / dt,
+                        'ms_per_episode': dt / episodes * 1e3})
+    except Exception as exc:
+        out.append({'config': 'mfg_ac2.train step mode', 'error': repr(exc)})
     # headline shape, strict f64 policy math
     try:
         e, _, st = training_leg(d0, T0, B0, 5, 1, precision='f64')

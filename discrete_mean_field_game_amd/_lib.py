@@ -75,6 +75,20 @@ SIGNATURES = {
                                      _p, C.c_float, _u64, _u64, _p, _p]),
 }
 
+
+
+class RewardNetStruct(C.Structure):
+    """mfg_reward_net_t of include/mfg_hip.h."""
+    _fields_ = ([(n, C.c_int) for n in ('k1', 'f2', 'k2', 'n3', 'n4')]
+                + [(n, C.c_void_p) for n in ('conv1_w', 'conv1_b', 'conv2_w', 'conv2_b', 'fc3_w', 'fc3_b', 'fc4_w', 'fc4_b',
+                                             'out_w', 'out_b')]
+                + [('keep_prob', C.c_float)])
+
+
+SIGNATURES['mfg_train_episode_irl'] = (_i32, [_p, _p, _i64, _i32, _i32, _p, _f64, _f64, _p, _f64, _u64, _u32, _u64, _i32, _f64,
+                                              _f64, C.POINTER(RewardNetStruct), _u64, _u64, _u64, _p, _p, _p, _p, _p, _p, _p,
+                                              _sz, _p])
+
 _lib = None
 
 

@@ -185,12 +185,20 @@ class AC_IRL(actor_critic):
                      'P': torch.empty(Bl, T, d, d, dtype=torch.float32, device=self.device),
                      'delta': torch.empty(Bl, T, dtype=torch.float64, device=self.device),
                      'g': torch.empty(Bl, T, dtype=torch.float64, device=self.device)}
+        # per-step updates on one GPU with the reward network's HIP kernel: the whole episode (15 x [sample + transition +
+        # score | reward net | batch sums + update]) is issued by native code (mfg_train_episode_irl)
+        native_episode = (self.update_every == 'step' and self.rng == 'philox' and shard.world == 1 and reward_fn is None
+                          and self.trace is None and not write_all and self.reward_net is not None
+                          and ops.reward_net_supported(self.reward_net))
+        if native_episode:
+            nbufs = dict(ops.episode_buffers(Bl, d, self.device), P=rbufs['P'])
         prev_theta = float(self._theta.cpu()[0])
         list_reward = []
         episode = 0
         pi = None
+        draws = self._start_draws(shard, max_episodes, lookahead=(stop_criteria == -1))
         for episode in range(1 + first_episode, first_episode + max_episodes + 1):
-            pi = ops.gather_start(self._mat_pi0_dev, self._draw_start(shard))
+            pi = ops.gather_start(self._mat_pi0_dev, next(draws))
             discount = 1.0
             total_reward = torch.zeros(1, dtype=torch.float64, device=self.device)
             sc, sa = lr_scales(episode, constant)          # lr/(episode+1) with the 1-indexed episode (:700)
@@ -216,7 +224,16 @@ class AC_IRL(actor_critic):
                 total_reward = total_reward * T
                 self._theta_is_array = True
                 pi = o['pi_last']
-            for step in range(0 if fused_episode else T):
+            if native_episode:
+                ops.train_episode_irl(pi, T, self._theta, self.shift, self.alpha_scale, self._w, gamma, lr_critic * sc,
+                                      lr_actor * sa, self.reward_net, G, ws, nbufs, seed=self.seed, first_step=self._rng_step,
+                                      traj_offset=shard.traj_offset, rn_seed=self.seed + 0x5EED, rn_call0=self._reward_calls,
+                                      rn_sample_offset=shard.traj_offset, reward_acc=total_reward, precision=self.precision)
+                self._rng_step += T
+                self._reward_calls += T                    # the dropout-mask keys of T reward() calls were consumed
+                self._reward_sample_offset = shard.traj_offset
+                self._theta_is_array = True
+            for step in range(0 if (fused_episode or native_episode) else T):
                 acc = (self.update_every == 'rollout' and step > 0)
                 step_applied = False
                 if self.rng == 'philox':

@@ -351,12 +351,12 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
   // staging against all later reads once, here (one block barrier per launch)
   __syncthreads();
   // A wave only ever touches the tile rows / state slots of its OWN G trajectories, so when nothing is staged
-  // or copied out block-wide (SAMPLE without P_out) the per-step barriers need not span the block: waves of a
+  // block-wide (SAMPLE; the P copy-out is per wave too) the per-step barriers need not span the block: waves of a
   // block then run their serial chains without waiting for the slowest of the four.
 #ifdef MFG_NO_WAVE_LOCAL
   const bool wave_local = false;
 #else
-  const bool wave_local = SAMPLE && a.P_out == nullptr;
+  const bool wave_local = SAMPLE;
 #endif
   auto tile_sync = [&]() {
     if (wave_local) {
@@ -559,24 +559,31 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
           pnv[i] = pi_n;
           if (CIRC) pnv[d + i] = pi_n;
         }
-        if (a.P_out) {
-          // coalesced copy-out of the block's P tile into [B,T,d,d]
-          const int n = nb * dd;
-          float* dst = a.P_out + (b0 * (int64_t)T) * dd;
+        if (a.P_out && wv * G < nb) {
+          // copy-out of THIS WAVE's trajectories into [B,T,d,d] (coalesced: a trajectory's matrix is contiguous on both
+          // sides when the LDS tile is unpadded).  Wave local on purpose: the rows were written by this wave's own lanes, so
+          // no block barrier is needed and the per-step barriers stay wave-local also when P is materialised (round 2
+          // copied the block's tile with all four waves behind a __syncthreads: +4.4 us per T = 1 launch at B = 4 096).
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_wave_barrier();
+          const int ntr = (nb - wv * G) < G ? (nb - wv * G) : G;  // trajectories of this wave in the tile
+          const float* src = tile + (size_t)wv * G * d * dp;
+          float* dst = a.P_out + ((b0 + wv * G) * (int64_t)T + s) * dd;
+          const int n = ntr * dd;
           if (dp == d) {
-            // odd d: the tile is unpadded, i.e. [nb][d*d] contiguous -> one division per element
+            // odd d: the tile is unpadded, i.e. [ntr][d*d] contiguous -> one division per element
             const float inv_dd = 1.0f / (float)dd;
-            for (int k = tid; k < n; k += BLOCK) {
+            for (int k = lane; k < n; k += WAVE) {
               const int tl2 = (int)(((float)k + 0.5f) * inv_dd);
-              dst[((int64_t)tl2 * T + s) * dd + (k - tl2 * dd)] = tile[k];
+              dst[(int64_t)tl2 * T * dd + (k - tl2 * dd)] = src[k];
             }
           } else {
-            for (int k = tid; k < n; k += BLOCK) {
+            for (int k = lane; k < n; k += WAVE) {
               const int row = (int)(((float)k + 0.5f) * inv_d);  // tl*d + i
               const int colj = k - row * d;
               const int tl2 = (int)(((float)row + 0.5f) * inv_d);
               const int ii = row - tl2 * d;
-              dst[((int64_t)tl2 * T + s) * dd + ii * d + colj] = tile[row * dp + colj];
+              dst[(int64_t)tl2 * T * dd + ii * d + colj] = src[row * dp + colj];
             }
           }
         }

@@ -1045,6 +1045,8 @@ __global__ __launch_bounds__(BLOCK) void k_step_large(const float* __restrict__ 
 // samples (staged in LDS) x a chunk of 4*BLOCK outputs; partials go to the workspace and are summed
 // in a fixed order by k_reduce_partials, so results are run-to-run deterministic.
 // ---------------------------------------------------------------------------------------------
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+constexpr int MFG_GRAD_SMALL_MAX_D = 28;  // k_grad_mfma_small: d + 4 augmented entries fit two 16-wide halves
 constexpr int GR_OUT_PER_THREAD = 4;
 constexpr int GR_OUT_PER_BLOCK = GR_OUT_PER_THREAD * BLOCK;
 
@@ -1145,110 +1147,187 @@ __global__ void k_add_reward(double* __restrict__ delta, const float* __restrict
     delta[n] += (double)reward[n];
 }
 
-// Compile-time-d version for the packed sizes (d = 21, 15): lane = (sample slot g, row i), G = 64/D samples per
-// wave iteration.  Each lane keeps row i of  M = sum_n delta_n pi_n pi_n^T  in D fp64 registers; pi_n is broadcast
-// to the lanes of its slot through a per-wave LDS line.  ~70 instructions per 3 samples (the generic kernel above
-// needs 3 LDS reads per FMA).  Partial rows are combined in a fixed order (deterministic).
-struct GradSample {
-  float pin;         // pi_n[i]
-  double de, dg, rr; // delta_n, g_n, reward_n (0 when the lane holds no sample)
-};
+// Small d (d <= 28; compile-time for the reference's 21 and 15): ALL the batch sums of an update on the fp64 matrix cores.
+// Per sample n two augmented vectors of length d + 4 <= 32,
+//     a_n = [ delta pi_0 .. delta pi_{d-1} | delta | 1 | 0 | 0 ]        (A operand, "row" index i)
+//     b_n = [ pi_0 .. pi_{d-1}             | 1 | g | r | 1 ]            (B operand, "column" index j)
+// and C = sum_n a_n b_n^T holds every entry of G = [sum delta phi | sum delta g | sum r | N] in its upper triangle:
+//     C[i][j], i <= j < d   = sum delta pi_i pi_j     (quadratic features)      C[i][d]     = sum delta pi_i   (linear)
+//     C[d][d]   = sum delta (bias)     C[d][d+1] = sum delta g     C[d+1][d+2] = sum r     C[d+1][d+3] = N.
+// v_mfma_f64_16x16x4_f64: a wave keeps the three 16 x 16 tiles (0,0), (0,1), (1,1) of the 32 x 32 product (12 fp64
+// accumulators per lane) and retires FOUR samples per K step with three matrix instructions; lane (li = lane & 15,
+// lk = lane >> 4) feeds entries li and 16 + li of sample 4 ks + lk, straight from global memory (pi_traj / delta / g /
+// reward as the rollout left them; the next batch of K steps is loaded while this one is multiplied).  The round-2 kernel
+// kept row i of the sum in d fp64 registers per lane and fetched pi_n[j] from LDS for every FMA: one LDS read per FMA,
+// 109 us for the 983 040 samples of the bench rollout against ~20 us of matrix-core time here.
+// Partial rows are combined in a fixed order (k_reduce_partials, or in-kernel by the last block for few rows): run-to-run
+// deterministic, no floating-point atomics.
+// Data path (second version): a wave works through chunks of 64 consecutive samples.  Their pi rows are fetched with d
+// fully used load instructions (flat element e = 64 k + lane of the chunk -> sample e / d, entry e % d: consecutive lanes
+// read consecutive floats except at trajectory boundaries), delta / g / reward with one load each (lane = sample), all
+// into registers while the previous chunk is multiplied, then parked in the wave's own LDS region (compact rows, no
+// block barrier) from where the 16 K steps of the chunk read their operands in the matrix layout.  The first version
+// loaded the operands directly (5 load instructions per K step, delta / g / reward fetched by 16 lanes each): the
+// kernel was bound by the vector-memory issue rate of the CU, 58 us whatever the occupancy.
+constexpr int GS_CH = 64;  // samples per chunk = 16 K steps
+#ifndef MFG_GS_BPC
+#define MFG_GS_BPC 2  // blocks per CU of the launch (2 waves per SIMD: measured)
+#endif
 
 template <int D>
-__device__ __forceinline__ GradSample grad_load(const GradArgs& a, int64_t n, int i, bool act, double invT) {
-  GradSample s{0.0f, 0.0, 0.0, 0.0};
-  if (act && n < a.N) {
-    const int64_t b = (int64_t)(((double)n + 0.5) * invT);
-    const int sidx = (int)(n - b * a.T);
-    s.pin = a.pi[b * a.stride_b + (int64_t)sidx * D + i];
-    s.de = a.delta[n];
-    if (a.g) s.dg = a.g[n];
-    if (a.reward) s.rr = (double)a.reward[n];
-    if (a.add_reward) {
-      s.de += s.rr;
-      if (i == 0) const_cast<double*>(a.delta)[n] = s.de;  // every lane of the slot has issued its load of delta[n] above
-    }
+struct GradChunk {
+  static constexpr int NL = D ? D : MFG_GRAD_SMALL_MAX_D;  // pi loads per lane and chunk
+  float pi[NL];
+  double de, dg;
+  float rr;
+};
+
+// n0 = first sample of the chunk (wave uniform); (b0, s0) = its trajectory / step.  Sample n0 + j sits at trajectory
+// b0 + (s0 + j) / T, step (s0 + j) % T: small integers, so the division is an fp32 multiply (exact below 2^22).
+template <int D>
+__device__ __forceinline__ void grad_chunk_load(GradChunk<D>& c, const GradArgs& a, const double* gp, const float* rp, int d,
+                                                int64_t n0, int64_t b0, int s0, int lane, float invT, float inv_d) {
+  const int last = (int)((a.N - 1 - n0) < (GS_CH - 1) ? (a.N - 1 - n0) : (GS_CH - 1));  // last live sample of the chunk
+  {
+    const int64_t n = n0 + (lane < last ? lane : last);  // lane = sample for the per-sample scalars (clamped: masked at use)
+    c.de = a.delta[n];
+    c.dg = gp[n];
+    c.rr = rp[n];
   }
-  return s;
+#pragma unroll
+  for (int k = 0; k < GradChunk<D>::NL; ++k) {
+    if (!D && k * WAVE >= GS_CH * d) {                    // run-time d: loads past the chunk are not needed
+      c.pi[k] = 0.0f;
+      continue;
+    }
+    const int e = k * WAVE + lane;                        // flat element of the chunk's [64][d] block
+    int j = (int)(((float)e + 0.5f) * inv_d);             // sample of the chunk (e < 64 * 28: exact in fp32)
+    int col = e - j * d;
+    if (j > last) { j = last; col = 0; }                  // past the end of the batch / of a run-time-d chunk: any live entry
+    const int sj = s0 + j;
+    const int q = (int)(((float)sj + 0.5f) * invT);
+    const int64_t off = (b0 + q) * a.stride_b + (int64_t)((sj - q * a.T) * d + col);
+    c.pi[k] = a.pi[off];
+  }
 }
 
 template <int D>
-__global__ __launch_bounds__(BLOCK) void k_grad_small(GradArgs a) {
-  constexpr int G = WAVE / D, Q = D * (D + 1) / 2, F = Q + D + 1, FO = F + 3;
-  __shared__ double line[WAVES][2][G * D];  // fp64 so the inner loop is one LDS read + one FMA per product
-  __shared__ double red[D * D + D + 4];
-  __shared__ double rows[WAVES][D * D + D + 4];
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-  const int g = lane / D, i = lane - g * D;
-  const bool act = g < G;
-  double acc[D], lin = 0.0, s_d = 0.0, s_dg = 0.0, s_r = 0.0, s_n = 0.0;
-#pragma unroll
-  for (int j = 0; j < D; ++j) acc[j] = 0.0;
-  const double invT = 1.0 / (double)a.T;
-  // two sample groups per iteration, the next iteration's loads issued before this one's FMAs
-  const int64_t stride = (int64_t)gridDim.x * WAVES * G * 2;
-  int64_t n0 = ((int64_t)blockIdx.x * WAVES + wv) * G * 2;
-  GradSample c0 = grad_load<D>(a, n0 + g, i, act, invT), c1 = grad_load<D>(a, n0 + G + g, i, act, invT);
-  const double* lp0 = line[wv][0] + (act ? g * D : 0);
-  const double* lp1 = line[wv][1] + (act ? g * D : 0);
-  for (; n0 < a.N; n0 += stride) {
-    const GradSample x0 = grad_load<D>(a, n0 + stride + g, i, act, invT);
-    const GradSample x1 = grad_load<D>(a, n0 + stride + G + g, i, act, invT);
+__global__ __launch_bounds__(BLOCK) void k_grad_mfma_small(GradArgs a) {
+  const int d = D ? D : a.d;
+  const int Q = d * (d + 1) / 2, F = Q + d + 1, FO = F + 3;
+  constexpr int DMAX = D ? D : MFG_GRAD_SMALL_MAX_D;
+  // per wave: pi rows [64][d] (+ 16 floats: the hi-half read of the last row may run past it), then per sample
+  // (delta, g, reward as double) -- 64 x 3 doubles; the block reduction reuses the space
+  constexpr int PI_FL = GS_CH * DMAX + 16;
+  constexpr int W_BYTES = ((PI_FL * 4 + 15) / 16) * 16 + GS_CH * 3 * 8;
+  constexpr int RED_BYTES = WAVES * 3 * 4 * WAVE * 8;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(WAVES * W_BYTES > RED_BYTES) ? WAVES * W_BYTES : RED_BYTES];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane(tid / WAVE);
+  float* lpi = reinterpret_cast<float*>(smem + (size_t)wv * W_BYTES);
+  double* lsc = reinterpret_cast<double*>(smem + (size_t)wv * W_BYTES + ((PI_FL * 4 + 15) / 16) * 16);
+  const int li = lane & 15, lk = lane >> 4;
+  // lane constants of the augmented entries li (lo half) and 16 + li (hi half)
+  auto consts = [&](int idx, float& a_d, double& a_1, float& b_1, double& b_g, double& b_r) {
+    a_d = idx == d ? 1.0f : 0.0f;       // a: delta at idx == d
+    a_1 = idx == d + 1 ? 1.0 : 0.0;     // a: 1 at idx == d + 1
+    b_1 = (idx == d || idx == d + 3) ? 1.0f : 0.0f;
+    b_g = idx == d + 1 ? 1.0 : 0.0;
+    b_r = idx == d + 2 ? 1.0 : 0.0;
+  };
+  float ad_lo, b1_lo, ad_hi, b1_hi;
+  double a1_lo, a1_hi, bg_lo, br_lo, bg_hi, br_hi;
+  consts(li, ad_lo, a1_lo, b1_lo, bg_lo, br_lo);
+  consts(16 + li, ad_hi, a1_hi, b1_hi, bg_hi, br_hi);
+  const bool pi_lo = li < d, pi_hi = 16 + li < d;
+  const int ilo = pi_lo ? li : 0, ihi = pi_hi ? 16 + li : 0;
+  // optional inputs: a valid address to load from, and whether the loaded value counts
+  const bool has_g = a.g != nullptr, has_r = a.reward != nullptr;
+  const double* gp = has_g ? a.g : a.delta;
+  const float* rp = has_r ? a.reward : a.pi;
+  v4d_t c00 = (v4d_t)(0.0), c01 = (v4d_t)(0.0), c11 = (v4d_t)(0.0);
+  const float invT = 1.0f / (float)a.T, inv_d = 1.0f / (float)d;
+  const int64_t NC = (a.N + GS_CH - 1) / GS_CH;           // chunks
+  const int64_t W = (int64_t)gridDim.x * WAVES;           // waves of the launch
+  const int64_t gw = (int64_t)blockIdx.x * WAVES + wv;
+  GradChunk<D> nx;
+  if (gw < NC) grad_chunk_load<D>(nx, a, gp, rp, d, gw * GS_CH, (gw * GS_CH) / a.T, (int)((gw * GS_CH) % a.T), lane, invT, inv_d);
+  for (int64_t ch = gw; ch < NC; ch += W) {
+    const int64_t n0 = ch * GS_CH;
+    // park the chunk in LDS (the previous chunk's reads are complete: wave-local barrier)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    if (act) {
-      line[wv][0][lane] = (double)c0.pin;
-      line[wv][1][lane] = (double)c1.pin;
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0) only: the prefetched global loads stay in flight
-    __builtin_amdgcn_wave_barrier();
-    if (i == 0) {
-      s_d += c0.de + c1.de;
-      s_dg = fma(c0.de, c0.dg, fma(c1.de, c1.dg, s_dg));
-      s_r += c0.rr + c1.rr;
-      s_n += ((act && n0 + g < a.N) ? 1.0 : 0.0) + ((act && n0 + G + g < a.N) ? 1.0 : 0.0);
-    }
-    const double ad0 = c0.de * (double)c0.pin, ad1 = c1.de * (double)c1.pin;
 #pragma unroll
-    for (int j = 0; j < D; ++j) acc[j] = fma(ad0, lp0[j], fma(ad1, lp1[j], acc[j]));
-    lin += ad0 + ad1;
-    c0 = x0;
-    c1 = x1;
-  }
-  // block reduction in a fixed (slot, wave) order: inside a wave the G slots fold into the wave's LDS row one after
-  // the other (wave-local barriers only), then each output is added up over the WAVES rows by one thread.  (One row
-  // per slot needed 45 KB of LDS and cost a block per CU; one barrier per slot cost ~4 us on the small-batch path.)
-  constexpr int RW = D * D + D + 4;
-  double* mine = rows[wv];
-  for (int q = 0; q < G; ++q) {
-    if (act && g == q) {
-#pragma unroll
-      for (int j = 0; j < D; ++j) mine[i * D + j] = (q == 0 ? 0.0 : mine[i * D + j]) + acc[j];
-      mine[D * D + i] = (q == 0 ? 0.0 : mine[D * D + i]) + lin;
-      if (i == 0) {
-        mine[D * D + D + 0] = (q == 0 ? 0.0 : mine[D * D + D + 0]) + s_d;
-        mine[D * D + D + 1] = (q == 0 ? 0.0 : mine[D * D + D + 1]) + s_dg;
-        mine[D * D + D + 2] = (q == 0 ? 0.0 : mine[D * D + D + 2]) + s_r;
-        mine[D * D + D + 3] = (q == 0 ? 0.0 : mine[D * D + D + 3]) + s_n;
+    for (int k = 0; k < GradChunk<D>::NL; ++k)
+      if (D || k * WAVE < GS_CH * d) lpi[k * WAVE + lane] = nx.pi[k];
+    {
+      const bool ok = n0 + lane < a.N;
+      const double rr = (ok && has_r) ? (double)nx.rr : 0.0;
+      double de = ok ? nx.de : 0.0;
+      if (a.add_reward) {
+        de += rr;
+        if (ok) const_cast<double*>(a.delta)[n0 + lane] = de;  // the lane that owns sample n writes it back
       }
+      lsc[3 * lane] = de;
+      lsc[3 * lane + 1] = (ok && has_g) ? nx.dg : 0.0;
+      lsc[3 * lane + 2] = rr;
+    }
+    const int nvalid = (int)((a.N - n0) < GS_CH ? (a.N - n0) : GS_CH);  // samples of this chunk (wave uniform)
+    if (ch + W < NC) {
+      const int64_t n1 = (ch + W) * GS_CH;
+      grad_chunk_load<D>(nx, a, gp, rp, d, n1, n1 / a.T, (int)(n1 % a.T), lane, invT, inv_d);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+    for (int ks = 0; ks < GS_CH / 4; ++ks) {
+      const int j = 4 * ks + lk;
+      const float plo = lpi[j * d + ilo], phi = lpi[j * d + ihi];
+      const double de = lsc[3 * j], dg = lsc[3 * j + 1];
+      const double rr = lsc[3 * j + 2];
+      const double one = j < nvalid ? 1.0 : 0.0;               // slots past the last sample hold zeros and count nothing
+      const double A_lo = fma(de, (double)(pi_lo ? plo : ad_lo), a1_lo * one);
+      const double A_hi = fma(de, (double)(pi_hi ? phi : ad_hi), a1_hi * one);
+      const double B_lo = fma(bg_lo, dg, fma(br_lo, rr, (double)(pi_lo ? plo : b1_lo)));
+      const double B_hi = fma(bg_hi, dg, fma(br_hi, rr, (double)(pi_hi ? phi : b1_hi)));
+      c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(A_lo, B_lo, c00, 0, 0, 0);
+      c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(A_lo, B_hi, c01, 0, 0, 0);
+      c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A_hi, B_hi, c11, 0, 0, 0);
+    }
   }
-  __syncthreads();
-  for (int k = tid; k < RW; k += BLOCK) {
-    double t = rows[0][k];
+  __syncthreads();  // every wave is done with its staging region: the block reduction reuses the space
+  double (*red)[3][4][WAVE] = reinterpret_cast<double (*)[3][4][WAVE]>(smem);
+  // block reduction in a fixed order: every wave parks its tiles, then each output is added up over the WAVES copies
 #pragma unroll
-    for (int q = 1; q < WAVES; ++q) t += rows[q][k];
-    red[k] = t;
+  for (int v = 0; v < 4; ++v) {
+    red[wv][0][v][lane] = c00[v];
+    red[wv][1][v][lane] = c01[v];
+    red[wv][2][v][lane] = c11[v];
   }
   __syncthreads();
   double* out = a.partial + (int64_t)blockIdx.x * FO;
-  for (int k = tid; k < D * D; k += BLOCK) {
-    const int r_ = k / D, c_ = k - r_ * D;
-    if (c_ >= r_) out[feat_idx(r_, c_, D)] = red[k];  // M is symmetric; feature (r,c), r <= c, is M[r][c]
+  for (int e = tid; e < 3 * 4 * WAVE; e += BLOCK) {
+    const int t = e / (4 * WAVE), v = (e / WAVE) & 3, l = e & (WAVE - 1);
+    // D[i][j] of a tile: lane l holds row (l >> 4) + 4 v, column l & 15 (f64 MFMA layout)
+    const int gi = (t == 2 ? 16 : 0) + 4 * v + (l >> 4), gj = (t == 0 ? 0 : 16) + (l & 15);
+    int k = -1;
+    if (gj < d) {
+      if (gi <= gj) k = feat_idx(gi, gj, d);
+    } else if (gj == d) {
+      if (gi <= d) k = Q + gi;            // linear terms, then the bias at gi == d
+    } else if (gj == d + 1) {
+      if (gi == d) k = F;                 // sum delta g
+    } else if (gj == d + 2) {
+      if (gi == d + 1) k = F + 1;         // sum r
+    } else if (gj == d + 3) {
+      if (gi == d + 1) k = F + 2;         // N
+    }
+    if (k >= 0) {
+      double tsum = red[0][t][v][l];
+#pragma unroll
+      for (int q = 1; q < WAVES; ++q) tsum += red[q][t][v][l];
+      out[k] = tsum;
+    }
   }
-  for (int k = tid; k < D; k += BLOCK) out[Q + k] = red[D * D + k];
-  if (tid < 4) out[Q + D + tid] = red[D * D + D + tid];
   if (!a.counter) return;
   // Few rows (small batches, per-step updates): the last block to finish sums the rows in a fixed order, writes G
   // and, when asked, applies the parameter update -- one launch instead of three dependent ones.
@@ -1259,6 +1338,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_small(GradArgs a) {
   __syncthreads();
   if (!s_last) return;
   __threadfence();
+  double* fin = &red[0][0][0][0];  // FO <= 32 * 33 / 2 + ... < 3 * 4 * 64 * WAVES doubles
   const int nrows = (int)gridDim.x;
   for (int k = tid; k < FO; k += BLOCK) {
     // plain loads: the agent-scope fence above already invalidated this CU's L1, and nothing here was read before it
@@ -1282,24 +1362,23 @@ __global__ __launch_bounds__(BLOCK) void k_grad_small(GradArgs a) {
     const double tot = (s0 + s1) + (s2 + s3);
     const double gk = a.accumulate ? a.G[k] + tot : tot;
     a.G[k] = gk;
-    red[k] = gk;  // FO <= D*D + D + 4
+    fin[k] = gk;  // (`red` as tiles was last read before the barriers around the completion counter)
   }
   __syncthreads();
   if (a.apply) {
     // identical arithmetic to k_apply_update
-    const double count = red[F + 2];
+    const double count = fin[F + 2];
     if (count > 0.0) {
       const double inv = 1.0 / count;
-      for (int k = tid; k < F; k += BLOCK) a.w[k] += a.lr_c * (red[k] * inv);
+      for (int k = tid; k < F; k += BLOCK) a.w[k] += a.lr_c * (fin[k] * inv);
       if (tid == 0) {
-        if (a.reward_acc) *a.reward_acc += red[F + 1] * inv;
-        *a.theta += a.lr_a * (red[F] * inv);
+        if (a.reward_acc) *a.reward_acc += fin[F + 1] * inv;
+        *a.theta += a.lr_a * (fin[F] * inv);
       }
     }
   }
   if (tid == 0) *a.counter = 0u;
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Critic-gradient sums on the fp64 matrix cores for d a multiple of 16 (d >= 64): the one GEMM-shaped piece of the
@@ -1310,7 +1389,6 @@ __global__ __launch_bounds__(BLOCK) void k_grad_small(GradArgs a) {
 // k_grad_partial, which ran at 4.5 % of the fp64 peak: 3.1 ms per C3 rollout).  Split-K over grid.x with one partial
 // row per x, tiles split over grid.y; the linear / scalar sums ride on the y = 0 blocks.  Deterministic.
 // ---------------------------------------------------------------------------------------------
-typedef double v4d_t __attribute__((ext_vector_type(4)));
 constexpr int GM_KC = 32;    // samples staged per chunk
 constexpr int GM_TPW = 8;    // max tiles per wave
 
@@ -1741,25 +1819,23 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
   a.chunk = chunk;
   a.nsb = nsb;
   a.partial = reinterpret_cast<double*>((char*)ws + MFG_WS_CONTROL_BYTES);
-  // (the packed kernel folds delta += reward into its own load: every sample is read by exactly one wave there; the
+  // (the small-d kernel folds delta += reward into its own load: every sample is read by exactly one wave there; the
   //  other kernels read a sample from several blocks, so the update is a separate elementwise launch first)
-  if (add_reward && !(d == 21 || d == 15))
+  const bool small = d <= MFG_GRAD_SMALL_MAX_D;
+  if (add_reward && !small)
     hipLaunchKernelGGL(k_add_reward, dim3(grid_for(N, 256, 8)), dim3(256), 0, st, const_cast<double*>(delta), reward, N);
-  if (d == 21 || d == 15) {
+  if (small) {
     a.add_reward = add_reward ? 1 : 0;
-    // one partial row per block; nsb rows fit the workspace by construction (grad_geometry)
-    const int per = WAVE / d;
-    const int64_t per_block_iter = (int64_t)WAVES * per * 2;  // samples one block covers per loop iteration
-    int64_t blocks = (N + per_block_iter * 8 - 1) / (per_block_iter * 8);  // >= 8 iterations per wave ...
-    if (N <= per_block_iter * 8 * MFG_GRAD_FUSE_MAX_ROWS) {
-      // ... except for small batches (per-step updates): spread them over up to MFG_GRAD_FUSE_MAX_ROWS blocks so that
-      // the kernel is a few loop iterations deep and its last block can finish the sums (and the update) itself
-      blocks = (N + per_block_iter - 1) / per_block_iter;
-      if (blocks > MFG_GRAD_FUSE_MAX_ROWS) blocks = MFG_GRAD_FUSE_MAX_ROWS;
-    }
+    // one partial row per block; nsb rows fit the workspace by construction (grad_geometry).  A wave works through chunks of
+    // 64 samples: one chunk per wave while the batch is small, then more chunks per wave (two blocks per CU at most)
+    const int64_t NC = (N + GS_CH - 1) / GS_CH;  // chunks of 64 samples, one wave each at a time
+    int64_t blocks = (NC + WAVES - 1) / WAVES;
+    const int64_t cap = (int64_t)num_cus() * MFG_GS_BPC;
+    if (blocks > cap) blocks = cap;
     if (blocks > nsb) blocks = nsb;
     if (blocks < 1) blocks = 1;
     a.nsb = blocks;
+    // few rows (small batches, per-step updates): the last block to finish sums them (and applies the update) itself
     const bool fuse = blocks <= MFG_GRAD_FUSE_MAX_ROWS;
     if (fuse) {
       a.counter = reinterpret_cast<unsigned*>(ws);
@@ -1775,13 +1851,14 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
         if (applied) *applied = true;
       }
     }
-    if (d == 21) hipLaunchKernelGGL((k_grad_small<21>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
-    else hipLaunchKernelGGL((k_grad_small<15>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
-    if (fuse) return check_launch("grad_small");
+    if (d == 21) hipLaunchKernelGGL((k_grad_mfma_small<21>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
+    else if (d == 15) hipLaunchKernelGGL((k_grad_mfma_small<15>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((k_grad_mfma_small<0>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
+    if (fuse) return check_launch("grad_mfma_small");
     hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
                        (const double*)a.partial, blocks, FO, accumulate, G, rap);
     if (applied && rap.on) *applied = true;
-    return check_launch("grad_small");
+    return check_launch("grad_mfma_small");
   }
   if (d % 16 == 0 && d >= 64 && d <= 4 * BLOCK) {
     const int nt = d / 16, ntiles = nt * (nt + 1) / 2;
@@ -2537,6 +2614,65 @@ int mfg_train_episode(float* pi_io, float* pi_scratch, int64_t B, int d, int T, 
   if (cur != pi_io && hipMemcpyAsync(pi_io, cur, (size_t)B * d * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
     return fail(MFG_ELAUNCH, "%s", "train_episode: final state copy failed");
   return check_launch("train_episode");
+}
+
+int mfg_train_episode_irl(float* pi_io, float* pi_scratch, int64_t B, int d, int T, double* theta, double shift,
+                          double alpha_scale, double* w, double gamma, uint64_t seed, uint32_t first_step,
+                          uint64_t traj_offset, int precision, double lr_critic, double lr_actor,
+                          const mfg_reward_net_t* net, uint64_t rn_seed, uint64_t rn_call0, uint64_t rn_sample_offset,
+                          float* P, float* reward, double* delta, double* g, double* G, double* reward_acc, void* workspace,
+                          size_t workspace_bytes, mfg_stream_t stream) {
+  CHECK_BD();
+  CHECK_PRECISION();
+  REQUIRE(T >= 1, "T < 1");
+  REQUIRE(pi_io && pi_scratch && theta && w && net && P && reward && delta && g && G && workspace, "null pointer");
+  hipStream_t st = S(stream);
+  float* cur = pi_io;
+  float* nxt = pi_scratch;
+  double discount = 1.0;  // running gamma^t of ac_irl.py:691, :710
+  for (int s = 0; s < T; ++s) {
+    CoreArgs a{};
+    a.pi0 = cur;
+    a.theta = theta;
+    a.w = w;
+    a.shift = shift;
+    a.alpha_scale = alpha_scale;
+    a.gamma = discount;
+    a.B = B;
+    a.d = d;
+    a.T = 1;
+    a.reward_kind = MFG_REWARD_EXTERNAL;  // delta = discount V(pi') - V(pi); the reward joins it in the gradient kernel
+    a.seed = seed;
+    a.first_step = first_step + (uint32_t)s;
+    a.traj_offset = traj_offset;
+    a.pi_next_out = nxt;
+    a.delta = delta;
+    a.g = g;
+    a.P_out = P;
+    int rc = launch_core(a, true, true, precision, st);
+    if (rc != MFG_OK) return rc;
+    const uint64_t key = rn_seed ^ ((rn_call0 + (uint64_t)s + 1ull) * 0x9E3779B97F4A7C15ull);
+    rc = mfg_reward_net_forward(cur, P, B, d, net->k1, net->f2, net->k2, net->n3, net->n4, net->conv1_w, net->conv1_b,
+                                net->conv2_w, net->conv2_b, net->fc3_w, net->fc3_b, net->fc4_w, net->fc4_b, net->out_w,
+                                net->out_b, net->keep_prob, key, rn_sample_offset, reward, stream);
+    if (rc != MFG_OK) return rc;
+    const ApplyArgs ap{lr_critic, lr_actor, w, theta, reward_acc};
+    bool applied = false;
+    rc = launch_grad(cur, d, delta, g, reward, B, 1, d, G, 0, workspace, workspace_bytes, st, &ap, &applied, true);
+    if (rc != MFG_OK) return rc;
+    if (!applied) {
+      const int64_t F = mfg_num_features(d);
+      hipLaunchKernelGGL(k_apply_update, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, G, F, lr_critic, lr_actor,
+                         w, theta, reward_acc);
+    }
+    discount *= gamma;
+    float* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+  if (cur != pi_io && hipMemcpyAsync(pi_io, cur, (size_t)B * d * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return fail(MFG_ELAUNCH, "%s", "train_episode_irl: final state copy failed");
+  return check_launch("train_episode_irl");
 }
 
 }  // extern "C"

@@ -344,6 +344,25 @@ class actor_critic:
             idx = idx[shard.traj_offset:shard.traj_offset + shard.local_batch]
         return torch.as_tensor(idx.astype(np.int32), device=self.device)
 
+    def _start_draws(self, shard, num_episodes, lookahead=True):
+        """Iterator over the per-episode start-state index vectors (device int32 [local batch]).  The np.random draws
+        are the ones _draw_start makes, in the same order; with the in-kernel sampler nothing else consumes np.random
+        inside train(), so up to 16 episodes are drawn and uploaded in one host-to-device copy (the per-episode
+        synchronous copy left the GPU idle for ~50 us per episode at small batches).  `lookahead=False` (early stopping,
+        rng='numpy', several ranks) draws episode by episode."""
+        block = 16 if (lookahead and self.rng == 'philox' and shard.world == 1 and self.batch > 1) else 1
+        done = 0
+        while done < num_episodes:
+            k = min(block, num_episodes - done)
+            if k == 1:
+                yield self._draw_start(shard)
+            else:
+                idx = np.stack([np.random.randint(self.num_start_samples, size=self.batch) for _ in range(k)])
+                dev = torch.as_tensor(idx.astype(np.int32), device=self.device)
+                for r in range(k):
+                    yield dev[r]
+            done += k
+
     def train(self, num_episodes=4000, gamma=1, constant=0, lr_critic=0.1, lr_actor=0.001, consecutive=100,
               file_theta='results/theta.csv', file_pi='results/pi.csv', file_reward='results/reward.csv',
               write_file=0, write_all=0, *, first_episode=0):
@@ -374,11 +393,12 @@ class actor_critic:
                      'reward': torch.empty(Bl, T, dtype=torch.float32, device=self.device),
                      'delta': torch.empty(Bl, T, dtype=torch.float64, device=self.device),
                      'g': torch.empty(Bl, T, dtype=torch.float64, device=self.device)}
+        draws = self._start_draws(shard, num_episodes)
         for episode in range(num_episodes):
             if write_all:
                 with open('temp.csv', 'a') as f:
                     f.write('Episode %d \n\n' % episode)
-            idx = self._draw_start(shard)
+            idx = next(draws)
             pi = None if fused_rollout else ops.gather_start(self._mat_pi0_dev, idx)
             sc, sa = lr_scales(episode + first_episode, constant == 1)
             if native_episode:

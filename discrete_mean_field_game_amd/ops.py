@@ -288,6 +288,42 @@ def train_episode(pi, T, theta, shift, alpha_scale, w, gamma, lr_critic, lr_acto
     return pi
 
 
+def reward_net_struct(net, dropout=None):
+    """mfg_reward_net_t for a networks.RewardNet (device pointers of its parameters; keep the module alive while in use)."""
+    if dropout is None:
+        dropout = net.use_dropout and (net.dropout_always or net.training)
+    st = L.RewardNetStruct()
+    st.k1, st.f2, st.k2 = net.conv1.kernel_size[0], net.conv2.out_channels, net.conv2.kernel_size[0]
+    st.n3, st.n4 = net.fc3.out_features, net.fc4.out_features
+    for name, t in (('conv1_w', net.conv1.weight), ('conv1_b', net.conv1.bias), ('conv2_w', net.conv2.weight),
+                    ('conv2_b', net.conv2.bias), ('fc3_w', net.fc3.weight), ('fc3_b', net.fc3.bias), ('fc4_w', net.fc4.weight),
+                    ('fc4_b', net.fc4.bias), ('out_w', net.out.weight), ('out_b', net.out.bias)):
+        if not t.is_contiguous():
+            raise ValueError('reward net parameters must be contiguous')
+        setattr(st, name, t.data_ptr())
+    st.keep_prob = float(net.keep_prob) if dropout else 1.0
+    return st
+
+
+def train_episode_irl(pi, T, theta, shift, alpha_scale, w, gamma, lr_critic, lr_actor, net, G, ws, bufs, seed=0, first_step=0,
+                      traj_offset=0, rn_seed=0, rn_call0=0, rn_sample_offset=0, reward_acc=None, precision='mixed'):
+    """T env steps of AC_IRL.train with per-step updates, issued natively (single GPU): sample + transition + score,
+    reward network, batch sums + update per step.  `pi` [B,d] is updated in place to the final states; `bufs` =
+    dict(scratch [B,d] f32, P [B,d,d] f32, reward [B] f32, delta [B] f64, g [B] f64); `net` = networks.RewardNet."""
+    import ctypes as C
+    _chk_f32(pi, 'pi'); _chk_f64(theta, 'theta'); _chk_f64(w, 'w')
+    B, d = pi.shape
+    st = reward_net_struct(net)
+    L.check(L.lib().mfg_train_episode_irl(pi.data_ptr(), bufs['scratch'].data_ptr(), B, d, int(T), theta.data_ptr(),
+                                          float(shift), float(alpha_scale), w.data_ptr(), float(gamma), int(seed),
+                                          int(first_step), int(traj_offset), L.PRECISIONS[precision], float(lr_critic),
+                                          float(lr_actor), C.byref(st), int(rn_seed) & 0xFFFFFFFFFFFFFFFF, int(rn_call0),
+                                          int(rn_sample_offset), bufs['P'].data_ptr(), bufs['reward'].data_ptr(),
+                                          bufs['delta'].data_ptr(), bufs['g'].data_ptr(), G.data_ptr(), _ptr(reward_acc),
+                                          ws.data_ptr(), ws.numel() * 8, _stream()), 'mfg_train_episode_irl')
+    return pi
+
+
 def episode_buffers(B, d, device):
     return {'scratch': torch.empty(B, d, dtype=torch.float32, device=device),
             'reward': torch.empty(B, dtype=torch.float32, device=device),

@@ -240,6 +240,31 @@ int mfg_train_episode(float* pi_io, float* pi_scratch, int64_t B, int d, int T, 
                       double* g, double* G, double* reward_acc, void* workspace, size_t workspace_bytes,
                       mfg_stream_t stream);
 
+/* Weights of the reward network of networks.py:46-81 as device pointers (layouts as for mfg_reward_net_forward). */
+typedef struct mfg_reward_net {
+  int k1, f2, k2, n3, n4;
+  const float *conv1_w, *conv1_b, *conv2_w, *conv2_b, *fc3_w, *fc3_b, *fc4_w, *fc4_b, *out_w, *out_b;
+  float keep_prob; /* < 1: inverted dropout after fc3 and fc4 (the reference leaves it on, ac_irl.py:683) */
+} mfg_reward_net_t;
+
+/* a9 (IRL flavour), native inner loop of AC_IRL.train with the reference's per-step updates (ac_irl.py:664-712) on ONE
+ * GPU.  For s < T, all launches issued back to back from native code (no interpreter between the dependent kernels):
+ *   sample P ~ policy(pi), pi' = P^T pi, g, delta0 = discount V(pi') - V(pi)     (one fused launch, P materialised, :674-679)
+ *   r = r_net(pi, P)                                                              (mfg_reward_net_forward, :683)
+ *   delta = r + delta0; batch sums; w += lr_critic G_w/B, theta += lr_actor G_theta/B; *reward_acc += mean r   (:691-708)
+ *   discount *= gamma; pi <- pi'                                                   (:710-711)
+ * The dropout masks of step s use the Philox key  rn_seed ^ ((rn_call0 + s + 1) * 0x9E3779B97F4A7C15)  (mod 2^64) and the
+ * sample counter rn_sample_offset + b -- the keys the host class would have passed to T separate
+ * mfg_reward_net_forward calls numbered rn_call0 + 1 ... .  pi_io [B,d]: start states in, final states out; pi_scratch
+ * [B,d]; P [B,d,d], reward / delta / g [B] hold the last step's values on return; G [F+3]; workspace as for
+ * mfg_td_pg_accumulate(B).  Philox steps first_step .. first_step+T-1 for the actions. */
+int mfg_train_episode_irl(float* pi_io, float* pi_scratch, int64_t B, int d, int T, double* theta, double shift,
+                          double alpha_scale, double* w, double gamma, uint64_t seed, uint32_t first_step,
+                          uint64_t traj_offset, int precision, double lr_critic, double lr_actor,
+                          const mfg_reward_net_t* net_host, uint64_t rn_seed, uint64_t rn_call0, uint64_t rn_sample_offset,
+                          float* P, float* reward, double* delta, double* g, double* G, double* reward_acc, void* workspace,
+                          size_t workspace_bytes, mfg_stream_t stream);
+
 /* f1 (optional importance weights, ac_irl.py:270-289 calc_pdf_action, :324-379 calc_z): log-density of the
  * product-Dirichlet policy for N (state, action) pairs under K policies theta_k (device array):
  *   out[n*K + k] = sum_i log Dirichlet(P_n[i,:] ; a_i),  a_ij = max(alpha_floor, alpha_scale * softplus(theta_k x_ij)).

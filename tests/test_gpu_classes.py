@@ -394,6 +394,36 @@ def test_native_episode_loop_equals_python_step_loop(dev, d, B, precision):
     assert np.array_equal(runs[0][2], runs[1][2])
 
 
+@pytest.mark.parametrize('d,B,precision,reg', [(21, 300, 'mixed', 'dropout_l1l2'), (21, 4096, 'mixed', 'dropout_l1l2'),
+                                               (15, 64, 'f64', 'l1l2'), (21, 7, 'f64', 'dropout')])
+def test_native_irl_episode_equals_python_step_loop(dev, d, B, precision, reg):
+    """mfg_train_episode_irl (ac_irl.py:664-712: per env step sample + transition + score | reward network | batch sums +
+    update, the whole 15-step episode issued natively) gives bit for bit what the per-step Python sequence
+    rollout(T=1, EXTERNAL) -> reward() -> grad_apply gives: same kernels, same order, same Philox steps, and the same
+    dropout-mask keys (dropout stays ON in the reference when the net serves as the RL reward)."""
+    import random
+    rs = np.random.RandomState(d + B)
+    mat = rs.dirichlet(np.ones(d), size=9)
+    runs = []
+    for use_native in (True, False):
+        np.random.seed(21); torch.manual_seed(21); random.seed(21)
+        ac = IRL(d=d, pi0=mat, demonstrations=[], batch=B, rng='philox', seed=5, update_every='step', precision=precision,
+                 reg=reg, verbose=0)
+        with torch.no_grad():
+            for p in ac.reward_net.parameters():
+                if p.dim() == 1:
+                    p.uniform_(-0.2, 0.2)
+        if not use_native:
+            ac.trace = []                       # tracing forces the per-step Python path
+        np.random.seed(22)
+        ac.train(max_episodes=3, stop_criteria=-1, gamma=0.95, constant=False, consecutive=2)
+        runs.append((np.ravel(ac.theta).copy(), ac.w.copy(), ac._rng_step, ac._reward_calls))
+    assert runs[0][2] == runs[1][2] == 45 and runs[0][3] == runs[1][3] == 45
+    assert np.array_equal(runs[0][0], runs[1][0])
+    assert np.array_equal(runs[0][1], runs[1][1])
+    assert runs[0][0][0] != 8.64
+
+
 def test_training_step_is_hip_graph_capturable(dev):
     """The C ABI launches on the caller's stream and never allocates or synchronises (after mfg_init), so a whole
     update (fused TD rollout + gradient kernels + parameter update) can be captured into a HIP graph and replayed;
@@ -535,16 +565,29 @@ def test_checkpoint_resume_is_bit_identical(dev, mode, tmp_path):
 
 def test_check_finite_raises_like_the_reference_warning_filter(dev):
     """check_finite=True is the stand-in for the reference's warnings-as-errors (mfg_ac2.py:21): a run that blows up
-    raises FloatingPointError at the end of the offending episode instead of silently carrying NaNs."""
+    raises FloatingPointError at the end of the offending episode instead of silently carrying NaNs.  Without it a
+    diverged mixed-precision run still cannot go on unnoticed: the sampling kernel that meets the non-finite theta reports
+    it through the device status word and the library refuses the next launch (MFG_ERANGE, include/mfg_hip.h)."""
+    from discrete_mean_field_game_amd import ops, _lib as L
     d = 21
     rs = np.random.RandomState(0)
+    ops.clear_status()
     ac = AC(d=d, pi0=rs.dirichlet(np.ones(d), size=4), batch=32, seed=1, update_every='rollout', check_finite=True, verbose=0)
     ac.train(num_episodes=2)                                   # healthy run: no exception
     with pytest.raises(FloatingPointError):
         ac.train(num_episodes=3, lr_actor=1e300, lr_critic=1e300)
+    ops.clear_status()
     ok = AC(d=d, pi0=rs.dirichlet(np.ones(d), size=4), batch=32, seed=1, update_every='rollout', verbose=0)
-    ok.train(num_episodes=3, lr_actor=1e300, lr_critic=1e300)  # default: unchecked, like running with warnings ignored
-    assert not np.isfinite(np.ravel(ok.theta)[0]) or not np.all(np.isfinite(ok.w))
+    with pytest.raises(L.MfgError, match='mfg_clear_status'):  # default: no per-episode check, the status word stops the run
+        ok.train(num_episodes=3, lr_actor=1e300, lr_critic=1e300)
+    th = np.ravel(ok.theta)[0]
+    assert not np.isfinite(th) or abs(th) > 1e100               # (the run was stopped as soon as the diverged theta was used)
+    ops.clear_status()
+    # strict precision has no range limit and no status report: unchecked, like running with warnings ignored
+    f64 = AC(d=d, pi0=rs.dirichlet(np.ones(d), size=4), batch=32, seed=1, update_every='rollout', precision='f64', verbose=0)
+    f64.train(num_episodes=4, lr_actor=1e300, lr_critic=1e300)
+    assert not (np.isfinite(np.ravel(f64.theta)[0]) and np.all(np.isfinite(f64.w)) and np.abs(f64.w).max() < 1e100)
+    assert ops.status() == 0
 
 
 @pytest.mark.parametrize('mode', ['step', 'rollout'])

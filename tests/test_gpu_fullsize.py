@@ -236,12 +236,15 @@ def test_config_full_T_large_d(dev, d, B, T, nsub):
     assert np.max(np.abs(got_g - ogg) / np.maximum(np.abs(ogg), 1.0)) < 1e-5
 
 
+@pytest.mark.parametrize('precision,tol', [('f64', 5e-8), ('mixed', 2e-6)])
 @pytest.mark.parametrize('mode', ['step', 'rollout'])
-def test_config_C4_irl_train_with_reward_net_in_the_loop(dev, mode):
+def test_config_C4_irl_train_with_reward_net_in_the_loop(dev, mode, precision, tol):
     """C4: AC_IRL.train at d=21, B=4096 with the HIP reward-net kernel inside the loop (reg='l1l2': no dropout, so the
     run is replayable), one episode with gamma=0.9, replayed by the oracle: actions re-drawn from the same Philox
     counters, reward = oracle/reward_net_oracle.forward on them, 1-indexed episode schedule, running discount
-    (ac_irl.py:664-712), batch-mean updates per step / once per episode."""
+    (ac_irl.py:664-712), batch-mean updates per step / once per episode.  Step mode runs through the native episode loop
+    (mfg_train_episode_irl).  precision 'mixed' (the default of the class): the oracle's score is exact fp64, the kernel's
+    is within ~2e-7 of it, so the replayed parameters agree a little less tightly."""
     from discrete_mean_field_game_amd.ac_irl import AC_IRL
     from oracle import reward_net_oracle as RO
     o = ops()
@@ -250,7 +253,7 @@ def test_config_C4_irl_train_with_reward_net_in_the_loop(dev, mode):
     mat = rs.dirichlet(np.ones(d), size=64)
     np.random.seed(31); torch.manual_seed(31)
     ac = AC_IRL(theta=8.64, shift=0.0, alpha_scale=1e4, d=d, pi0=mat, demonstrations=[], batch=B, rng='philox', seed=13,
-                reg='l1l2', update_every=mode, precision='f64', verbose=0)
+                reg='l1l2', update_every=mode, precision=precision, verbose=0)
     with torch.no_grad():                                           # non-trivial biases (zero by default)
         for p in ac.reward_net.parameters():
             if p.dim() == 1:
@@ -270,7 +273,7 @@ def test_config_C4_irl_train_with_reward_net_in_the_loop(dev, mode):
     disc = 1.0
     for t in range(15):
         th = torch.tensor([theta], dtype=torch.float64, device=dev)
-        P = o.sample_dirichlet(torch.as_tensor(pi, device=dev), th, 0.0, 1e4, seed=13, step=t, precision='f64').cpu().numpy()
+        P = o.sample_dirichlet(torch.as_tensor(pi, device=dev), th, 0.0, 1e4, seed=13, step=t, precision=precision).cpu().numpy()
         pn = O().transition(P, pi).astype(np.float32)
         r = RO.forward(params, pi.astype(np.float64), P.astype(np.float64))[:, 0]
         r = r.astype(np.float32).astype(np.float64)                 # the kernel hands the reward over as fp32
@@ -286,8 +289,8 @@ def test_config_C4_irl_train_with_reward_net_in_the_loop(dev, mode):
         w = w + 0.1 * sc * Gw_acc / (15 * B)
         theta = theta + 0.001 * sa * Gt_acc / (15 * B)
     # fp32 reward kernel vs fp64 restatement: rewards agree to ~1e-6 absolute, so the updates agree to ~1e-9
-    assert abs(float(np.ravel(ac.theta)[0]) - theta) < 5e-8
-    assert np.max(np.abs(ac.w[:, 0] - w)) < 5e-8
+    assert abs(float(np.ravel(ac.theta)[0]) - theta) < tol
+    assert np.max(np.abs(ac.w[:, 0] - w)) < tol
 
 
 @pytest.mark.parametrize('d,B,T', [(80, 7, 3), (128, 5, 6), (144, 33, 2), (256, 3, 5), (512, 2, 2)])

@@ -1,0 +1,80 @@
+#!/bin/bash
+# Cycle table of the fused rollout kernels (GPU box): the DYNAMIC instruction-class mix from the SQ class counters
+# (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32/F64, INT32, INT64, CVT; separate --pmc passes, --kernel-trace only), priced with
+# the per-class issue costs measured by tools/micro/valu_rates on the same chip, against the MEASURED VALU-active cycles
+# (SQ_ACTIVE_INST_VALU, quad-cycles x 4).  Optional ablation builds (tools/ablate.sh build) split the cycles by piece.
+# usage: bash tools/cycle_table.sh d,T,B > gpurun_out/<tag>/cycle_table_d<d>.txt
+R=$GRAFT_REPO_ROOT; SH=${1:-21,15,65536}; V=$R/discrete_mean_field_game_amd/csrc/variants
+cd /tmp && export TMPDIR=/tmp
+P1="SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_BUSY_CYCLES"
+P2="SQ_WAVES SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64"
+P3="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE"
+run() {  # $1 = out dir, $2 = counters, $3 = library ('' = shipped)
+  rm -rf $1
+  if [ -n "$3" ]; then export MFG_HIP_LIB=$3; else unset MFG_HIP_LIB; fi
+  rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $1 -o p -- python3 $R/tools/pmc_rollout.py $SH > $1.log 2>&1
+}
+run /tmp/ct1 "$P1" ""; run /tmp/ct2 "$P2" ""; run /tmp/ct3 "$P3" ""
+ABL=""
+for a in PHILOX BM SETUP TRY HTAB LNY EPI COLREW V; do
+  if [ -f $V/libabl_$a.so ]; then run /tmp/cta_$a "$P1" $V/libabl_$a.so; ABL="$ABL $a"; fi
+done
+python3 - "$SH" $ABL <<'PY'
+import csv, glob, collections, sys
+shape = sys.argv[1]; abl = sys.argv[2:]
+d, T, B = (int(x) for x in shape.split(','))
+def load(dirn):
+    f = glob.glob(dirn + '/**/*counter_collection.csv', recursive=True)
+    acc = collections.defaultdict(list); dur = []
+    if not f: return {}, 0.0
+    for r in csv.DictReader(open(f[0])):
+        if 'k_core_' in r['Kernel_Name']:
+            acc[r['Counter_Name']].append(float(r['Counter_Value']))
+    seen = set()
+    for r in csv.DictReader(open(f[0])):
+        if 'k_core_' in r['Kernel_Name'] and r['Dispatch_Id'] not in seen:
+            seen.add(r['Dispatch_Id']); dur.append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    return {k: sum(v) / len(v) for k, v in acc.items()}, (sum(dur) / len(dur) if dur else 0.0)
+m = {}
+durs = []
+for dn in ('/tmp/ct1', '/tmp/ct2', '/tmp/ct3'):
+    c, du = load(dn); m.update(c); durs.append(du)
+# issue cost per wave64 instruction per SIMD, cycles (tools/micro/valu_rates.hip, MI355X, loop glue subtracted)
+COST = collections.OrderedDict([('FMA_F32', 2.2), ('ADD_F32', 2.2), ('MUL_F32', 2.2), ('INT32', 2.2), ('CVT', 2.2), ('TRANS_F32', 8.0),
+                                ('INT64', 6.4), ('FMA_F64', 4.6), ('ADD_F64', 4.6), ('MUL_F64', 4.6), ('TRANS_F64', 16.0)])
+W = m.get('SQ_WAVES', 1.0)
+tot_i = m.get('SQ_INSTS_VALU', 0.0); act = 4.0 * m.get('SQ_ACTIVE_INST_VALU', 0.0)
+elems = (d * T) if d <= 64 else ((d * d // 64) * T)   # matrix elements per lane per launch
+print('shape d,T,B = %s   kernel time under PMC %.1f / %.1f / %.1f us   waves %.0f   matrix elements per lane per launch %d' % (shape, *durs, W, elems))
+print('VALU instructions per wave %.0f (%.1f per element)   VALU-active cycles per wave %.0f (%.1f per element)   => %.2f cycles per instruction'
+      % (tot_i / W, tot_i / W / elems, act / W, act / W / elems, act / max(tot_i, 1)))
+print('%-34s %12s %10s %8s %12s %8s' % ('class (SQ_INSTS_VALU_*)', 'instr/wave', 'per elem', 'cost', 'cycles/wave', 'share'))
+rows = []; known_i = 0.0; known_c = 0.0
+for k, c in COST.items():
+    v = m.get('SQ_INSTS_VALU_' + k, 0.0)
+    rows.append((k, v, c)); known_i += v; known_c += v * c
+rest = tot_i - known_i
+rest_cost = (act - known_c) / rest if rest > 0 else 0.0
+for k, v, c in rows:
+    print('%-34s %12.0f %10.2f %8.1f %12.0f %7.1f%%' % (k, v / W, v / W / elems, c, v * c / W, 100 * v * c / max(act, 1)))
+print('%-34s %12.0f %10.2f %8.2f %12.0f %7.1f%%   (moves, selects, compares, DPP, bit-field ops, readlane: cost = what is left of the measured cycles)'
+      % ('not in a class counter', rest / W, rest / W / elems, rest_cost, (act - known_c) / W, 100 * (act - known_c) / max(act, 1)))
+print('%-34s %12.0f %10.2f %8s %12.0f %7.1f%%' % ('TOTAL (measured)', tot_i / W, tot_i / W / elems, '', act / W, 100.0))
+if 'SQ_WAVE_CYCLES' in m:
+    wc = 4.0 * m['SQ_WAVE_CYCLES']
+    print('wave cycles per wave %.0f: VALU-active %.1f %%, waiting on s_waitcnt/barrier %.1f %%, issue stalls %.1f %%; LDS instr/wave %.0f, SALU instr/wave %.0f'
+          % (wc / W, 100 * act / wc, 100 * 4 * m.get('SQ_WAIT_ANY', 0) / wc, 100 * 4 * m.get('SQ_WAIT_INST_ANY', 0) / wc, m.get('SQ_INSTS_LDS', 0) / W, m.get('SQ_INSTS_SALU', 0) / W))
+if abl:
+    print('\nby piece (shipped build minus the build with that piece replaced by a 1-4 instruction stand-in, tools/ablate.sh):')
+    print('%-10s %14s %14s %10s %12s' % ('piece', 'instr/elem', 'cycles/elem', 'cyc/instr', 'share of cyc'))
+    ti = tc = 0.0
+    for a in abl:
+        c, _ = load('/tmp/cta_' + a)
+        if not c: continue
+        di = (tot_i - c.get('SQ_INSTS_VALU', 0.0) * W / max(c.get('SQ_WAVES', W), 1)) / W / elems
+        dc = (act - 4.0 * c.get('SQ_ACTIVE_INST_VALU', 0.0) * W / max(c.get('SQ_WAVES', W), 1)) / W / elems
+        ti += di; tc += dc
+        print('%-10s %14.2f %14.1f %10.2f %11.1f%%' % (a, di, dc, dc / di if di else 0.0, 100 * dc * W * elems / max(act, 1)))
+    print('%-10s %14.2f %14.1f %10.2f %11.1f%%' % ('the rest', tot_i / W / elems - ti, act / W / elems - tc,
+                                                 (act / W / elems - tc) / max(tot_i / W / elems - ti, 1e-9), 100 * (1 - tc * W * elems / max(act, 1))))
+PY
