@@ -45,8 +45,10 @@ struct CoreArgs {
 };
 #ifdef MFG_TIMING
 #define MFG_STAMP(k) if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && s < 4) a.dbg[s * 16 + (k)] = __builtin_amdgcn_s_memtime();
+#define MFG_STAMP0(k) if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[(k)] = __builtin_amdgcn_s_memtime();  // slots 8..15 of row 0
 #else
 #define MFG_STAMP(k)
+#define MFG_STAMP0(k)
 #endif
 
 int set_error(int code, const char* msg);  // records mfg_last_error() (defined in mfg_kernels.hip)
@@ -303,6 +305,7 @@ __device__ __forceinline__ double value_wave(const float* pis, const double* __r
 template <bool SAMPLE, bool TD, bool FAST, int D>
 __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core_small(CoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  MFG_STAMP0(8)
   const int d = D ? D : a.d;
   const int dd = d * d, dp = d | 1, T = a.T;
   const int G = WAVE / d, TB = WAVES * G;
@@ -334,6 +337,17 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
   // that the launch reports MFG_STATUS_MIXED_RANGE and its outputs are NaN (precision 'f64' has no such limit).
   constexpr bool sep = SAMPLE && FAST;
   if (sep) report_sep_range(a.status, theta, a.shift);
+  // first tile's start state: the load is issued BEFORE the weight staging so that its latency (L2 / HBM, ~1 us) overlaps
+  // the staging instead of stalling the first use (a T = 1 launch spent 4 300 of its 20 900 cycles waiting for it)
+  float pi_first = 0.0f;
+  {
+    const int64_t b0f = (int64_t)blockIdx.x * TB;
+    const int tlf = wv * G + t;
+    if (b0f < a.B) {
+      const int64_t bf = b0f + ((t < G && b0f + tlf < a.B) ? tlf : 0);
+      pi_first = a.pi0[(a.start_idx ? start_row(a.start_idx[bf], a.num_start) : bf) * d + i];
+    }
+  }
   if (want_v) {
     if (CIRC) {
       for (int k = tid; k < H * d; k += BLOCK) {
@@ -350,6 +364,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
   // wl is staged block-wide but read by every wave; the per-step barriers below may be wave-local, so order the
   // staging against all later reads once, here (one block barrier per launch)
   __syncthreads();
+  MFG_STAMP0(9)
   // A wave only ever touches the tile rows / state slots of its OWN G trajectories, so when nothing is staged
   // block-wide (SAMPLE; the P copy-out is per wave too) the per-step barriers need not span the block: waves of a
   // block then run their serial chains without waiting for the slowest of the four.
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
     const int64_t b = b0 + tlc;
     double* redq = red + (size_t)tlc * 3 * d;
     float* pnv = pin + tlc * pnw;
-    float pi_i = a.pi0[(a.start_idx ? start_row(a.start_idx[b], a.num_start) : b) * d + i];
+    float pi_i = tileid == blockIdx.x ? pi_first : a.pi0[(a.start_idx ? start_row(a.start_idx[b], a.num_start) : b) * d + i];
     if (valid && a.pi_traj) a.pi_traj[b * (int64_t)(T + 1) * d + i] = pi_i;
     double v_cur = 0.0, discount = 1.0;  // meaningful on lane i == 0 only
     if (want_v && SAMPLE) {
@@ -418,6 +433,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
         v_cur = (v0 + v1) + wl[Q + d];
       }
     }
+    MFG_STAMP0(10)
     for (int s = 0; s < T; ++s) {
       MFG_STAMP(0)
       tile_sync();
@@ -569,15 +585,31 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
           const int ntr = (nb - wv * G) < G ? (nb - wv * G) : G;  // trajectories of this wave in the tile
           const float* src = tile + (size_t)wv * G * d * dp;
           float* dst = a.P_out + ((b0 + wv * G) * (int64_t)T + s) * dd;
-          const int n = ntr * dd;
-          if (dp == d) {
-            // odd d: the tile is unpadded, i.e. [ntr][d*d] contiguous -> one division per element
-            const float inv_dd = 1.0f / (float)dd;
-            for (int k = lane; k < n; k += WAVE) {
-              const int tl2 = (int)(((float)k + 0.5f) * inv_dd);
-              dst[(int64_t)tl2 * T * dd + (k - tl2 * dd)] = src[k];
+          if constexpr (D > 0 && (D & 1)) {
+            // odd compile-time d: the tile is unpadded, a trajectory's matrix is [d*d] contiguous in LDS and in P_out;
+            // all LDS reads of a matrix are issued before its stores (a rolled loop paid one LDS round trip per 64 floats)
+            constexpr int NIT = (D * D + WAVE - 1) / WAVE;
+#pragma unroll
+            for (int tl2 = 0; tl2 < WAVE / D; ++tl2) {
+              if (tl2 < ntr) {
+                float v[NIT];
+#pragma unroll
+                for (int u = 0; u < NIT; ++u) {
+                  const int k = lane + u * WAVE;
+                  v[u] = src[tl2 * D * D + (k < D * D ? k : 0)];
+                }
+#pragma unroll
+                for (int u = 0; u < NIT; ++u) {
+                  const int k = lane + u * WAVE;
+                  if (k < D * D) dst[(int64_t)tl2 * T * dd + k] = v[u];
+                }
+              }
             }
+          } else if (dp == d) {
+            for (int tl2 = 0; tl2 < ntr; ++tl2)
+              for (int k = lane; k < dd; k += WAVE) dst[(int64_t)tl2 * T * dd + k] = src[tl2 * dd + k];
           } else {
+            const int n = ntr * dd;
             for (int k = lane; k < n; k += WAVE) {
               const int row = (int)(((float)k + 0.5f) * inv_d);  // tl*d + i
               const int colj = k - row * d;
@@ -670,6 +702,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
       MFG_STAMP(5)
     }
     if (valid && a.pi_next_out) a.pi_next_out[b * d + i] = pi_i;
+    MFG_STAMP0(11)
   }
 }
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the summaries of a tools/profile_round.sh run (gpurun_out/<tag>/) into profiles/ under the round's names.
 # usage: bash tools/collect_profiles.sh <tag> [round-prefix, default r02]
-O=gpurun_out/$1; P=${2:-r02}
+O=gpurun_out/$1; P=${2:-r03}
 cp $O/bench.json profiles/${P}_bench.json
 cp $O/bench_kernel_stats.csv profiles/${P}_bench_kernel_stats.csv
 cp $O/bench_under_rocprof.json profiles/${P}_bench_under_rocprof.json
@@ -22,3 +22,6 @@ print('value %.4g env-steps/s, %.4f ms/step; given-P %.0f GB/s frac %.3f (%.1f u
 for c in d['configs']:
     print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in c.items() if k in ('config', 'fused_ms_per_rollout', 'fused_env_steps_per_s', 'given_P_frac', 'env_steps_per_s')})
 PY
+for f in shards valu_rates mfma_f64_rate cycle_table_d21 cycle_table_d128 cycle_table_d256 irl_step_mode_trace perf_train_4096 perf_train_65536; do
+  [ -f $O/$f.txt ] && cp $O/$f.txt profiles/${P}_$f.txt
+done

@@ -3,7 +3,7 @@
 # kernels at d = 21 / 128 / 256, SQ issue counters of the fused rollout kernels at the bench shape, C3 and the C5 share).
 # Counters are collected in their own runs (never combined with the trace domains gpurun refuses).
 # usage: bash tools/profile_round.sh <tag>     (outputs under gpurun_out/<tag>/; copy the summaries into profiles/)
-R=$GRAFT_REPO_ROOT; TAG=${1:-r02}; O=$R/gpurun_out/$TAG; mkdir -p $O
+R=$GRAFT_REPO_ROOT; TAG=${1:-r03}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 $R/bench.py --steps 10 --warmup 2 > $O/bench_under_rocprof.json 2> $O/prof.err
@@ -27,3 +27,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg -o cfg -- py
 cp $(find $O/prof_cfg -name "*kernel_stats.csv" | head -1) $O/other_configs_kernel_stats.csv
 rm -rf $O/prof $O/prof_cfg $O/pmc_fetch_* $O/pmc_write_* $O/pmc_sq1_* $O/pmc_sq2_*
 ls $O; cat $O/bench.json | head -c 600
+# round 3: shard table (strong-scaling shards of the headline batch), cycle tables of the fused kernels, issue-rate micro
+python3 $R/tools/shard_table.py > $O/shards.txt 2>&1
+[ -x $R/tools/micro/valu_rates ] && $R/tools/micro/valu_rates > $O/valu_rates.txt 2>&1
+[ -x $R/tools/micro/mfma_f64_rate ] && $R/tools/micro/mfma_f64_rate > $O/mfma_f64_rate.txt 2>&1
+for SH in 21,15,65536 128,40,16384 256,40,16384; do bash $R/tools/cycle_table.sh $SH > $O/cycle_table_d${SH%%,*}.txt 2>&1; done
+bash $R/tools/trace_gaps.sh $R/tools/irl_mode_probe.py 4096 > $O/irl_step_mode_trace.txt 2>&1
+python3 $R/tools/perf_train.py 4096 > $O/perf_train_4096.txt 2>&1
+python3 $R/tools/perf_train.py 65536 > $O/perf_train_65536.txt 2>&1
