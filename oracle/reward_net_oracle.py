@@ -41,17 +41,42 @@ def conv2d_same(x, w, b):
     return out + b
 
 
-def forward(params, state, action):
+def dropout_masks(keep_prob, seed, sample_offset, N, n3, n4):
+    """The dropout masks the HIP kernel draws (csrc/mfg_reward_net.hip): unit o of FC3 / FC4 of sample n is kept iff
+    u01(Philox4x32-10(key = seed, counter = (o, 3 | 4, sample_offset + n, block 0)).x) <= keep_prob; kept units are scaled
+    by 1 / keep_prob (tf.nn.dropout).  TF's own generator cannot be matched; what this pins is that the kernel evaluates
+    the documented function of the documented bits, so a run WITH dropout (the reference's default reg='dropout_l1l2',
+    active also when the net serves as the RL reward) can be replayed.  Returns (m3 [N,n3], m4 [N,n4]) of 0 / (1/keep)."""
+    from oracle import philox_ref as PR
+    n = np.arange(N, dtype=np.uint64) + np.uint64(sample_offset)
+    inv = np.float32(1.0) / np.float32(keep_prob)
+    out = []
+    for units, step in ((n3, 3), (n4, 4)):
+        o = np.arange(units, dtype=np.uint64)
+        r = PR.philox_elem(int(seed), o[None, :], step, n[:, None], 0)[0]
+        u = PR.u01(r)
+        out.append(np.where(u <= np.float32(keep_prob), inv, np.float32(0.0)).astype(np.float64))
+    return out[0], out[1]
+
+
+def forward(params, state, action, dropout=None):
     """params: dict of TF-layout arrays conv1_w [5,5,1,1], conv1_b, conv2_w [3,3,1,2], conv2_b,
-    fc3_w [2d^2,n3], fc3_b, fc4_w [n3+d,n4], fc4_b, out_w [n4,1], out_b.  Returns [N,1]."""
+    fc3_w [2d^2,n3], fc3_b, fc4_w [n3+d,n4], fc4_b, out_w [n4,1], out_b.  Returns [N,1].
+    dropout = (keep_prob, seed, sample_offset): apply the kernel's counter-based masks after fc3 and fc4."""
     N, d = state.shape
     x = action.reshape(N, d, d, 1).astype(np.float64)
     x = np.maximum(conv2d_same(x, params['conv1_w'], params['conv1_b']), 0)
     x = np.maximum(conv2d_same(x, params['conv2_w'], params['conv2_b']), 0)
     x = x.reshape(N, -1)                                            # NHWC flatten (networks.py:67)
     x = np.maximum(x.dot(params['fc3_w']) + params['fc3_b'], 0)
+    m3 = m4 = None
+    if dropout is not None:
+        m3, m4 = dropout_masks(dropout[0], dropout[1], dropout[2], N, params['fc3_w'].shape[1], params['fc4_w'].shape[1])
+        x = x * m3                                                   # networks.py:70
     x = np.concatenate([x, state.astype(np.float64)], axis=1)        # networks.py:72
     x = np.maximum(x.dot(params['fc4_w']) + params['fc4_b'], 0)
+    if m4 is not None:
+        x = x * m4                                                   # networks.py:75
     return np.tanh(x.dot(params['out_w']) + params['out_b'])
 
 

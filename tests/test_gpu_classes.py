@@ -263,6 +263,34 @@ def test_reward_net_hip_forward_matches_torch_and_numpy(dev, reg, d, n3, n4):
     assert np.max(np.abs(out)) < 1
 
 
+@pytest.mark.parametrize('d,n3,n4', [(21, 8, 4), (15, 8, 4), (32, 32, 32), (21, 6, 8)])
+def test_reward_net_hip_dropout_masks_are_the_documented_philox_bits(dev, d, n3, n4):
+    """With dropout ON (the reference's default reg and its behaviour when the net serves as the RL reward) the kernel's
+    output equals the oracle evaluated with masks redrawn from the documented counters: unit o of FC3 / FC4 of sample n
+    <- Philox4x32-10(key = seed; counter = (o, 3 | 4, sample_offset + n, 0)).  Any (seed, sample_offset), incl. offsets
+    beyond 2^32 (the high trajectory bits of the counter)."""
+    from discrete_mean_field_game_amd import ops
+    from discrete_mean_field_game_amd.networks import RewardNet
+    from oracle import reward_net_oracle as RO
+    torch.manual_seed(d + n4)
+    net = RewardNet(d=d, reg='dropout_l1l2', n_fc3=n3, n_fc4=n4).to(dev).eval()
+    for p in net.parameters():
+        if p.dim() == 1:
+            torch.nn.init.uniform_(p, -0.2, 0.2)
+    rs = np.random.RandomState(d)
+    B = 257
+    state = rs.dirichlet(np.ones(d), size=B).astype(np.float32)
+    action = rs.dirichlet(np.ones(d), size=(B, d)).astype(np.float32)
+    s_t, a_t = torch.as_tensor(state, device=dev), torch.as_tensor(action, device=dev)
+    params = RO.params_from_torch(net)
+    for seed, off in ((77, 0), (0x9E3779B97F4A7C15, 1000), (5, (1 << 33) + 12345)):
+        out = ops.reward_net_forward(net, s_t, a_t, seed=seed, sample_offset=off).cpu().numpy()
+        ref = RO.forward(params, state.astype(np.float64), action.astype(np.float64), dropout=(0.4, seed, off))[:, 0]
+        assert np.max(np.abs(out - ref)) < 5e-6, (seed, off)
+        m3, m4 = RO.dropout_masks(0.4, seed, off, B, n3, n4)
+        assert 0.3 < (m3 > 0).mean() < 0.5 and 0.25 < (m4 > 0).mean() < 0.55       # keep probability 0.4
+
+
 def test_reward_net_hip_dropout_statistics(dev):
     """Dropout (keep 0.4, inverted scaling) stays on when the net is the RL reward, like the reference
     (tf.contrib.layers.dropout defaults to is_training=True): masks differ per call and per sample, and the

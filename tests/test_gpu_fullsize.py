@@ -236,15 +236,30 @@ def test_config_full_T_large_d(dev, d, B, T, nsub):
     assert np.max(np.abs(got_g - ogg) / np.maximum(np.abs(ogg), 1.0)) < 1e-5
 
 
-@pytest.mark.parametrize('precision,tol', [('f64', 5e-8), ('mixed', 2e-6)])
+def _forward_with_masks(RO, params, pi, P, m3, m4):
+    """reward_net_oracle.forward with explicit dropout masks (rows picked out of a larger call's mask block)."""
+    N, d = pi.shape
+    x = P.reshape(N, d, d, 1).astype(np.float64)
+    x = np.maximum(RO.conv2d_same(x, params['conv1_w'], params['conv1_b']), 0)
+    x = np.maximum(RO.conv2d_same(x, params['conv2_w'], params['conv2_b']), 0)
+    x = np.maximum(x.reshape(N, -1).dot(params['fc3_w']) + params['fc3_b'], 0) * m3
+    x = np.concatenate([x, pi.astype(np.float64)], axis=1)
+    x = np.maximum(x.dot(params['fc4_w']) + params['fc4_b'], 0) * m4
+    return np.tanh(x.dot(params['out_w']) + params['out_b'])[:, 0]
+
+
+@pytest.mark.parametrize('precision,tol,reg', [('f64', 5e-8, 'l1l2'), ('mixed', 2e-6, 'l1l2'), ('mixed', 2e-6, 'dropout_l1l2')])
 @pytest.mark.parametrize('mode', ['step', 'rollout'])
-def test_config_C4_irl_train_with_reward_net_in_the_loop(dev, mode, precision, tol):
+def test_config_C4_irl_train_with_reward_net_in_the_loop(dev, mode, precision, tol, reg):
     """C4: AC_IRL.train at d=21, B=4096 with the HIP reward-net kernel inside the loop (reg='l1l2': no dropout, so the
     run is replayable), one episode with gamma=0.9, replayed by the oracle: actions re-drawn from the same Philox
     counters, reward = oracle/reward_net_oracle.forward on them, 1-indexed episode schedule, running discount
     (ac_irl.py:664-712), batch-mean updates per step / once per episode.  Step mode runs through the native episode loop
     (mfg_train_episode_irl).  precision 'mixed' (the default of the class): the oracle's score is exact fp64, the kernel's
-    is within ~2e-7 of it, so the replayed parameters agree a little less tightly."""
+    is within ~2e-7 of it, so the replayed parameters agree a little less tightly.  reg='dropout_l1l2' is the class
+    default (ac_irl.py:33): dropout stays on when the net serves as the RL reward, and the oracle redraws the kernel's
+    counter-based masks (reward_net_oracle.dropout_masks) with the keys the host class documents -- the default path is
+    replayed end to end, not only checked statistically."""
     from discrete_mean_field_game_amd.ac_irl import AC_IRL
     from oracle import reward_net_oracle as RO
     o = ops()
@@ -253,7 +268,7 @@ def test_config_C4_irl_train_with_reward_net_in_the_loop(dev, mode, precision, t
     mat = rs.dirichlet(np.ones(d), size=64)
     np.random.seed(31); torch.manual_seed(31)
     ac = AC_IRL(theta=8.64, shift=0.0, alpha_scale=1e4, d=d, pi0=mat, demonstrations=[], batch=B, rng='philox', seed=13,
-                reg='l1l2', update_every=mode, precision=precision, verbose=0)
+                reg=reg, update_every=mode, precision=precision, verbose=0)
     with torch.no_grad():                                           # non-trivial biases (zero by default)
         for p in ac.reward_net.parameters():
             if p.dim() == 1:
@@ -275,7 +290,16 @@ def test_config_C4_irl_train_with_reward_net_in_the_loop(dev, mode, precision, t
         th = torch.tensor([theta], dtype=torch.float64, device=dev)
         P = o.sample_dirichlet(torch.as_tensor(pi, device=dev), th, 0.0, 1e4, seed=13, step=t, precision=precision).cpu().numpy()
         pn = O().transition(P, pi).astype(np.float32)
-        r = RO.forward(params, pi.astype(np.float64), P.astype(np.float64))[:, 0]
+        drop = None
+        if 'dropout' in reg and mode == 'step':
+            # AC_IRL.reward(): Philox key = (seed + 0x5EED) ^ (call number * 0x9E3779B97F4A7C15), sample counter = trajectory
+            drop = (0.4, ((13 + 0x5EED) ^ ((t + 1) * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF, 0)
+        r = RO.forward(params, pi.astype(np.float64), P.astype(np.float64), dropout=drop)[:, 0]
+        if 'dropout' in reg and mode == 'rollout':
+            # one reward() call over all B*T transitions of the episode, sample n = b*T + t: redraw its masks for step t
+            key = ((13 + 0x5EED) ^ (1 * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+            m3, m4 = RO.dropout_masks(0.4, key, 0, B * 15, 8, 4)
+            r = _forward_with_masks(RO, params, pi, P, m3[t::15], m4[t::15])
         r = r.astype(np.float32).astype(np.float64)                 # the kernel hands the reward over as fp32
         delta, g, G_w, G_t, _ = O().batched_td_pg(pi, pn, P, r, w, theta, 0.0, disc)
         if mode == 'step':
