@@ -39,6 +39,7 @@ struct CoreArgs {
   float* P_out;        // [B,T,d,d] or NULL
   const float4* htab;  // h(z) cubic table (mixed precision TD), see mfg_device.h
   unsigned* status;    // device address of the host-visible status word (mfg_status), or NULL
+  double* part_rows;   // SUMS variant (T == 1, one tile per block): partial rows [ntiles][F+3] of the batch sums, or NULL
 #ifdef MFG_TIMING
   unsigned long long* dbg;  // timing variant only (tools/phase_timing.py): s_memtime stamps of block 0, wave 0
 #endif
@@ -52,6 +53,21 @@ struct CoreArgs {
 #endif
 
 int set_error(int code, const char* msg);  // records mfg_last_error() (defined in mfg_kernels.hip)
+
+// IRL env step: reward network + the batch sums of the TD update over the same samples in one launch
+// (mfg_reward_net.hip; used by mfg_train_episode_irl)
+struct RnSums {
+  const double* delta0;  // [B] discount V(pi') - V(pi) from the step kernel
+  const double* g;       // [B] scores
+  double* delta_out;     // [B] delta = delta0 + r (may alias delta0)
+  double* part_rows;     // [max_rows][F+3]
+  int64_t max_rows;
+};
+int reward_net_forward_sums(const float* state, const float* action, int64_t B, int d, int k1, int f2, int k2, int n3, int n4,
+                            const float* conv1_w, const float* conv1_b, const float* conv2_w, const float* conv2_b,
+                            const float* fc3_w, const float* fc3_b, const float* fc4_w, const float* fc4_b,
+                            const float* out_w, const float* out_b, float keep_prob, uint64_t seed, uint64_t sample_offset,
+                            float* reward, const RnSums* sums, int* rows_out, mfg_stream_t stream);
 
 // launchers defined in mfg_core_small.hip / mfg_core_large_*.hip; return 0 or MFG_EUNSUPPORTED
 int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st);
@@ -302,8 +318,13 @@ __device__ __forceinline__ double value_wave(const float* pis, const double* __r
 #ifndef MFG_CORE_SMALL_WAVES
 #define MFG_CORE_SMALL_WAVES 3  // waves per SIMD the mixed-precision kernel is register-capped for (168 VGPRs)
 #endif
-template <bool SAMPLE, bool TD, bool FAST, int D>
-__global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core_small(CoreArgs a) {
+// SUMS (per-step updates, T == 1; compile-time d): the block also leaves the batch sums of ITS trajectories' transitions
+// -- [sum delta phi(pi) | sum delta g | sum r | count], the augmented-vector fp64-MFMA form of k_grad_mfma_small -- as one
+// partial row in a.part_rows: the separate gradient kernel (a launch, a re-read of pi / delta / g / reward, a
+// fence-and-last-block finish: 10.6 us per env step at B = 4 096) shrinks to the row reduction.  Register budget of two
+// waves per SIMD (the three-wave cap spills 31 registers here); used while all tiles are resident at that occupancy.
+template <bool SAMPLE, bool TD, bool FAST, int D, bool SUMS = false>
+__global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) void k_core_small(CoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   MFG_STAMP0(8)
   const int d = D ? D : a.d;
@@ -328,6 +349,7 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
   float* pin = pis + TB * d;       // [TB][pnw]
   float* pal = pin + TB * 2 * d;
   float* pex = pal + TB * d;       // SAMPLE, mixed: E_j = e^{theta pi_j} (separable exponential, mfg_device.h)
+  double* scal = reinterpret_cast<double*>(pex + TB * d + ((TB * d) & 1));  // SUMS: (delta, g, r) per trajectory of the tile
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
   const int t = lane / d, i = lane - t * d;
   const double theta = *a.theta;
@@ -682,6 +704,10 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
           const double gd = a.discount_pow ? discount : a.gamma;
           const double del = r + gd * v_next - v_cur;
           if (a.delta) a.delta[b * T + s] = del;
+          if (SUMS) {
+            scal[tlc * 3] = del;
+            scal[tlc * 3 + 2] = (double)(float)r;  // the reward as the caller sees it (fp32 output)
+          }
           v_cur = v_next;
           discount *= a.gamma;
         }
@@ -696,12 +722,76 @@ __global__ __launch_bounds__(BLOCK, FAST ? MFG_CORE_SMALL_WAVES : 2) void k_core
         }
         if (k < d) g0 += redq[d + k];
         a.g[b * T + s] = g0 + g1;
+        if (SUMS) scal[tlc * 3 + 1] = g0 + g1;
       }
       if (valid && a.pi_traj) a.pi_traj[(b * (int64_t)(T + 1) + s + 1) * d + i] = pi_n;
       pi_i = pi_n;
       MFG_STAMP(5)
     }
     if (valid && a.pi_next_out) a.pi_next_out[b * d + i] = pi_i;
+    if constexpr (SUMS && SAMPLE && TD && D > 0) {
+      if (a.part_rows) {
+        // batch sums of this tile's transitions (T == 1): sample = trajectory, state = pis (the step's start state).
+        // Operand layout and augmented vectors exactly as in k_grad_mfma_small (mfg_kernels.hip).
+        constexpr int FO = D * (D + 1) / 2 + D + 1 + 3;
+        static_assert(WAVES * FO * 8 <= WAVES * (WAVE / D) * D * (D | 1) * 4, "the partial rows reuse the tile region");
+        tile_sync();
+        const int li = lane & 15, lk = lane >> 4;
+        const int trj = wv * G + lk;
+        const bool ok = lk < G && trj < nb;
+        const int trc = ok ? trj : 0;
+        const bool plo_ok = li < D, phi_ok = 16 + li < D;
+        const float plo = pis[trc * D + (plo_ok ? li : 0)], phi = pis[trc * D + (phi_ok ? 16 + li : 0)];
+        const double de = ok ? scal[trc * 3] : 0.0, dg = ok ? scal[trc * 3 + 1] : 0.0, rr = ok ? scal[trc * 3 + 2] : 0.0;
+        const double one = ok ? 1.0 : 0.0;
+        auto aug = [&](int idx, float pv, bool is_pi, double& A, double& B) {
+          const float ad = idx == D ? 1.0f : 0.0f, b1 = (idx == D || idx == D + 3) ? 1.0f : 0.0f;
+          const double a1 = idx == D + 1 ? 1.0 : 0.0, bg = idx == D + 1 ? 1.0 : 0.0, br = idx == D + 2 ? 1.0 : 0.0;
+          A = fma(de, (double)(is_pi ? pv : ad), a1 * one);
+          B = fma(bg, dg, fma(br, rr, (double)(is_pi ? pv : b1)));
+        };
+        double A_lo, B_lo, A_hi, B_hi;
+        aug(li, plo, plo_ok, A_lo, B_lo);
+        aug(16 + li, phi, phi_ok, A_hi, B_hi);
+        const v4d_t z = (v4d_t)(0.0);
+        const v4d_t c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A_lo, B_lo, z, 0, 0, 0);
+        const v4d_t c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A_lo, B_hi, z, 0, 0, 0);
+        const v4d_t c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(A_hi, B_hi, z, 0, 0, 0);
+        __syncthreads();  // every wave is done with the tile region: it now holds the waves' rows
+        double* rows = reinterpret_cast<double*>(tile);
+        constexpr int Qc = D * (D + 1) / 2, Fc = Qc + D + 1;
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            // D[i][j] of a tile: this lane holds row lk + 4 v, column li (f64 MFMA layout)
+            const int gi = (tt == 2 ? 16 : 0) + 4 * v + lk, gj = (tt == 0 ? 0 : 16) + li;
+            int k = -1;
+            if (gj < D) {
+              if (gi <= gj) k = feat_idx(gi, gj, D);
+            } else if (gj == D) {
+              if (gi <= D) k = Qc + gi;
+            } else if (gj == D + 1) {
+              if (gi == D) k = Fc;
+            } else if (gj == D + 2) {
+              if (gi == D + 1) k = Fc + 1;
+            } else if (gj == D + 3) {
+              if (gi == D + 1) k = Fc + 2;
+            }
+            const double val = tt == 0 ? c0[v] : (tt == 1 ? c1[v] : c2[v]);
+            if (k >= 0) rows[wv * FO + k] = val;
+          }
+        }
+        __syncthreads();
+        for (int k = tid; k < FO; k += BLOCK) {
+          double tsum = rows[k];
+#pragma unroll
+          for (int q = 1; q < WAVES; ++q) tsum += rows[q * FO + k];
+          a.part_rows[tileid * FO + k] = tsum;
+        }
+        __syncthreads();  // (a further tile of this block would reuse the region)
+      }
+    }
     MFG_STAMP0(11)
   }
 }
@@ -710,7 +800,8 @@ inline size_t core_small_lds(int d, bool want_v, bool sample) {
   const int G = WAVE / d, TB = WAVES * G, dp = d | 1;
   const size_t F = (size_t)d * (d + 1) / 2 + d + 1;
   const size_t fl = (size_t)TB * d * dp + 5 * (size_t)TB * d;  // floats: tile, pis, pin (doubled), pal, pex
-  return (want_v ? F * 8 : 0) + (sample ? (size_t)TB * d * 8 : 0) + (size_t)3 * TB * d * 8 + fl * 4;
+  return (want_v ? F * 8 : 0) + (sample ? (size_t)TB * d * 8 : 0) + (size_t)3 * TB * d * 8 + (fl + (fl & 1)) * 4 +
+         (size_t)TB * 3 * 8;  // + SUMS scalars
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ namespace mfg {
 // resident blocks): exactly-resident persistent grid 2.30 ms, x1.5 2.21, x2 2.14, x4 2.07, one tile per block 2.07 --
 // tiles do not take equal time (rejection retries), so the hardware dispatcher back-filling finished blocks beats
 // a static tile split.
-template <bool SAMPLE, bool TD, bool FAST, int D>
+template <bool SAMPLE, bool TD, bool FAST, int D, bool SUMS = false>
 static void go(const CoreArgs& a, int num_cus, size_t lds, hipStream_t st) {
   // occupancy of this instantiation at this LDS size, cached per device
   static std::atomic<size_t> cached_lds[64];
@@ -20,18 +20,26 @@ static void go(const CoreArgs& a, int num_cus, size_t lds, hipStream_t st) {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (cached_lds[dev].load() != lds + 1) {  // (+1: zero-initialised slots never match)
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_small<SAMPLE, TD, FAST, D>, BLOCK, lds) != hipSuccess || n < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_small<SAMPLE, TD, FAST, D, SUMS>, BLOCK, lds) != hipSuccess || n < 1)
       n = 1;
     cached_bpc[dev].store(n);
     cached_lds[dev].store(lds + 1);
   }
   const int G = WAVE / a.d, TB = WAVES * G;
   const int grid = core_grid(a.B, TB, cached_bpc[dev].load() * MFG_CORE_OVERSUBSCRIBE, num_cus);
-  hipLaunchKernelGGL((k_core_small<SAMPLE, TD, FAST, D>), dim3(grid), dim3(BLOCK), lds, st, a);
+  hipLaunchKernelGGL((k_core_small<SAMPLE, TD, FAST, D, SUMS>), dim3(grid), dim3(BLOCK), lds, st, a);
 }
 
 template <int D>
 static void dispatch(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, size_t lds, hipStream_t st) {
+  if constexpr (D > 0) {
+    // per-step updates: the variant that also leaves the tile's batch sums (launch_core_sums in mfg_kernels.hip)
+    if (sample && td && a.part_rows) {
+      if (fast) go<true, true, true, D, true>(a, num_cus, lds, st);
+      else go<true, true, false, D, true>(a, num_cus, lds, st);
+      return;
+    }
+  }
   if (fast) {
     if (sample && td) go<true, true, true, D>(a, num_cus, lds, st);
     else if (sample) go<true, false, true, D>(a, num_cus, lds, st);

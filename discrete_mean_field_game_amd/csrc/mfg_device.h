@@ -7,6 +7,7 @@
 namespace mfg {
 
 constexpr int WAVE = 64;
+typedef double v4d_t __attribute__((ext_vector_type(4)));  // accumulators of v_mfma_f64_16x16x4_f64
 constexpr float ZERO_GAMMA_REPLACEMENT = 1e-20f;   // mfg_ac2.py:244
 constexpr double LOG_ZERO_P = -230.25850929940458;  // ln(1e-100), mfg_ac2.py:369
 constexpr double LN2 = 0.6931471805599453, INV_LN2 = 1.4426950408889634;

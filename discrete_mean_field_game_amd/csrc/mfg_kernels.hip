@@ -1045,7 +1045,6 @@ __global__ __launch_bounds__(BLOCK) void k_step_large(const float* __restrict__ 
 // samples (staged in LDS) x a chunk of 4*BLOCK outputs; partials go to the workspace and are summed
 // in a fixed order by k_reduce_partials, so results are run-to-run deterministic.
 // ---------------------------------------------------------------------------------------------
-typedef double v4d_t __attribute__((ext_vector_type(4)));
 constexpr int MFG_GRAD_SMALL_MAX_D = 28;  // k_grad_mfma_small: d + 4 augmented entries fit two 16-wide halves
 constexpr int GR_OUT_PER_THREAD = 4;
 constexpr int GR_OUT_PER_BLOCK = GR_OUT_PER_THREAD * BLOCK;
@@ -1694,9 +1693,11 @@ __global__ void k_td_delta(const double* __restrict__ V, const float* __restrict
   }
 }
 
-// Sum nsb partial rows in a fixed order: block = 16 slices (waves) x 64 outputs (lanes, coalesced);
-// slice s adds rows s, s+16, ... ; the 16 slice sums are combined in slice order through LDS.
-constexpr int RP_SLICES = 16;
+// Sum nsb partial rows in a fixed order: block = 64 slices x 16 outputs (16 consecutive doubles = one 128-byte line per
+// slice); slice s adds rows s, s+64, ... (eight loads in flight), the 64 slice sums are combined in slice order through
+// LDS.  (Round 2: 16 slices x 64 outputs -- four blocks for the 256 outputs of d = 21, each thread a chain of 4-6
+// dependent L2 round trips: 4.8-6 us for the 342-512 rows of a per-step update; now FO / 16 blocks and one or two rounds.)
+constexpr int RP_SLICES = 64, RP_OUT = 16;
 // `ap` != NULL (single-GPU training rollout, accumulate == 0): the parameter update rides along -- the number of samples
 // is known on the host (count), so every output updates its own parameter without waiting for another block's sum:
 // k < F: w[k] += lr_c G[k] / count; k == F: theta += lr_a G[F] / count; k == F+1: *reward_acc += G[F+1] / count
@@ -1706,30 +1707,54 @@ struct ReduceApply {
   double *w, *theta, *reward_acc;
   int on;
 };
-__global__ __launch_bounds__(RP_SLICES* WAVE) void k_reduce_partials(const double* __restrict__ partial, int64_t nsb, int64_t FO,
-                                                                    int accumulate, double* __restrict__ G, ReduceApply ap) {
-  __shared__ double red[RP_SLICES][WAVE];
-  const int lane = threadIdx.x & (WAVE - 1), sl = threadIdx.x / WAVE;
-  const int64_t k = (int64_t)blockIdx.x * WAVE + lane;
+__global__ __launch_bounds__(RP_SLICES* RP_OUT) void k_reduce_partials(const double* __restrict__ partial, int64_t nsb, int64_t FO,
+                                                                      int accumulate, double* __restrict__ G, ReduceApply ap) {
+  __shared__ double red[RP_SLICES][RP_OUT + 1];
+  const int lo = threadIdx.x & (RP_OUT - 1), sl = threadIdx.x / RP_OUT;
+  const int64_t k = (int64_t)blockIdx.x * RP_OUT + lo;
   double s = 0.0;
   if (k < FO) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int64_t p = sl;
-    for (; p + 3 * RP_SLICES < nsb; p += 4 * RP_SLICES) {
-      s0 += partial[p * FO + k];
-      s1 += partial[(p + RP_SLICES) * FO + k];
-      s2 += partial[(p + 2 * RP_SLICES) * FO + k];
-      s3 += partial[(p + 3 * RP_SLICES) * FO + k];
+    for (; p + 7 * RP_SLICES < nsb; p += 8 * RP_SLICES) {
+      const double v0 = partial[p * FO + k], v1 = partial[(p + RP_SLICES) * FO + k], v2 = partial[(p + 2 * RP_SLICES) * FO + k],
+                   v3 = partial[(p + 3 * RP_SLICES) * FO + k], v4 = partial[(p + 4 * RP_SLICES) * FO + k],
+                   v5 = partial[(p + 5 * RP_SLICES) * FO + k], v6 = partial[(p + 6 * RP_SLICES) * FO + k],
+                   v7 = partial[(p + 7 * RP_SLICES) * FO + k];
+      s0 += v0;
+      s1 += v1;
+      s2 += v2;
+      s3 += v3;
+      s0 += v4;
+      s1 += v5;
+      s2 += v6;
+      s3 += v7;
     }
-    for (; p < nsb; p += RP_SLICES) s0 += partial[p * FO + k];
+    // tail: up to seven rows, loaded together
+    double t[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) t[u] = (p + u * RP_SLICES < nsb) ? partial[(p + u * RP_SLICES) * FO + k] : 0.0;
+    s0 += t[0];
+    s1 += t[1];
+    s2 += t[2];
+    s3 += t[3];
+    s0 += t[4];
+    s1 += t[5];
+    s2 += t[6];
     s = (s0 + s1) + (s2 + s3);
   }
-  red[sl][lane] = s;
+  red[sl][lo] = s;
   __syncthreads();
   if (sl == 0 && k < FO) {
-    double tot = 0.0;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
 #pragma unroll
-    for (int q = 0; q < RP_SLICES; ++q) tot += red[q][lane];
+    for (int q = 0; q < RP_SLICES; q += 4) {
+      t0 += red[q][lo];
+      t1 += red[q + 1][lo];
+      t2 += red[q + 2][lo];
+      t3 += red[q + 3][lo];
+    }
+    const double tot = (t0 + t1) + (t2 + t3);
     const double gk = accumulate ? G[k] + tot : tot;
     G[k] = gk;
     if (ap.on) {
@@ -1855,7 +1880,7 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
     else if (d == 15) hipLaunchKernelGGL((k_grad_mfma_small<15>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
     else hipLaunchKernelGGL((k_grad_mfma_small<0>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
     if (fuse) return check_launch("grad_mfma_small");
-    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
+    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + RP_OUT - 1) / RP_OUT)), dim3(RP_SLICES * RP_OUT), 0, st,
                        (const double*)a.partial, blocks, FO, accumulate, G, rap);
     if (applied && rap.on) *applied = true;
     return check_launch("grad_mfma_small");
@@ -1874,14 +1899,14 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
       case 16: hipLaunchKernelGGL((k_grad_mfma<16>), dim3((unsigned)nsb, (unsigned)ny), dim3(BLOCK), lds_m, st, a, tpw); break;
       default: hipLaunchKernelGGL((k_grad_mfma<0>), dim3((unsigned)nsb, (unsigned)ny), dim3(BLOCK), lds_m, st, a, tpw); break;
     }
-    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
+    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + RP_OUT - 1) / RP_OUT)), dim3(RP_SLICES * RP_OUT), 0, st,
                        (const double*)a.partial, nsb, FO, accumulate, G, rap);
     if (applied && rap.on) *applied = true;
     return check_launch("grad_mfma");
   }
   const size_t lds = (size_t)chunk * 3 * 8 + (size_t)chunk * d * 4;
   hipLaunchKernelGGL(k_grad_partial, dim3((unsigned)nsb, (unsigned)nob), dim3(BLOCK), lds, st, a);
-  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + WAVE - 1) / WAVE)), dim3(RP_SLICES * WAVE), 0, st,
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + RP_OUT - 1) / RP_OUT)), dim3(RP_SLICES * RP_OUT), 0, st,
                      (const double*)a.partial, nsb, FO, accumulate, G, rap);
   if (applied && rap.on) *applied = true;
   return check_launch("grad_reduce");
@@ -1985,6 +2010,41 @@ static int launch_core(const CoreArgs& a_in, bool sample, bool td, int precision
   return check_launch("core");
 }
 
+// Per-step updates at the packed sizes (T == 1, d = 21 / 15, in-kernel reward): the step kernel itself leaves one partial
+// row of the batch sums per tile (k_core_small<..., SUMS>), so an update is [step kernel | row reduction (+ apply)]
+// instead of [step kernel | gradient kernel with its own finish].  Used while every tile has its own resident block
+// (MFG_CORE_SUMS_MAX_ROWS tiles = 6 144 trajectories at d = 21) and the workspace has room for the rows; otherwise the
+// caller takes the two-kernel path.
+constexpr int64_t MFG_CORE_SUMS_MAX_ROWS = 512;  // = blocks resident at the SUMS variant's two waves per SIMD (256 CUs x 2)
+static int64_t core_sums_rows(int d, int64_t B) {
+  if (!(d == 21 || d == 15)) return 0;
+  const int TB = WAVES * (WAVE / d);
+  const int64_t nt = (B + TB - 1) / TB;
+  return nt <= MFG_CORE_SUMS_MAX_ROWS ? nt : 0;
+}
+static bool core_sums_ok(int d, int64_t B, int T, int reward_kind, const void* ws, size_t ws_bytes) {
+  if (T != 1 || reward_kind == MFG_REWARD_EXTERNAL || !ws) return false;
+  const int64_t nt = core_sums_rows(d, B);
+  return nt > 0 && ws_bytes >= (size_t)(nt * (mfg_num_features(d) + 3) * 8) + MFG_WS_CONTROL_BYTES;
+}
+// the row reduction (+ optional parameter update) that follows a SUMS launch
+static int reduce_core_sums(int d, int64_t B, double* G, int accumulate, void* ws, const ApplyArgs* apply, hipStream_t st) {
+  const int64_t FO = mfg_num_features(d) + 3, nt = core_sums_rows(d, B);
+  ReduceApply rap{};
+  if (apply && !accumulate) {
+    rap.on = 1;
+    rap.lr_c = apply->lr_c;
+    rap.lr_a = apply->lr_a;
+    rap.count = (double)B;
+    rap.w = apply->w;
+    rap.theta = apply->theta;
+    rap.reward_acc = apply->reward_acc;
+  }
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + RP_OUT - 1) / RP_OUT)), dim3(RP_SLICES * RP_OUT), 0, st,
+                     (const double*)((char*)ws + MFG_WS_CONTROL_BYTES), nt, FO, accumulate, G, rap);
+  return check_launch("core_sums");
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
@@ -2043,6 +2103,12 @@ size_t mfg_workspace_bytes(int64_t N, int d) {
   int chunk, nob;
   int64_t nsb;
   grad_geometry(N, d, &chunk, &nsb, &nob);
+  const int64_t rows_sums = core_sums_rows(d, N);  // T = 1 updates with the sums fused into the step kernel: a row per tile
+  if (rows_sums > nsb) nsb = rows_sums;
+  if (d <= 32) {  // IRL steps with the sums fused into the reward-network launch: a row per block of eight samples, <= 512
+    const int64_t rows_rn = (N + 7) / 8 < 512 ? (N + 7) / 8 : 512;
+    if (rows_rn > nsb) nsb = rows_rn;
+  }
   return (size_t)(nsb * (mfg_num_features(d) + 3) * 8) + MFG_WS_CONTROL_BYTES + value_buffer_bytes(N, d);
 }
 
@@ -2466,8 +2532,11 @@ int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, 
   const int precision = (flags & MFG_ROLLOUT_F64) ? MFG_PRECISION_F64 : MFG_PRECISION_MIXED;
   const bool deferred = td && defer_values(d, B, T, pi_traj, workspace, workspace_bytes);
   if (deferred) a.w = nullptr;  // the kernel then leaves delta alone; values + delta follow on the matrix cores
+  const bool sums_in_core = td && G && core_sums_ok(d, B, T, reward_kind, workspace, workspace_bytes);
+  if (sums_in_core) a.part_rows = reinterpret_cast<double*>((char*)workspace + MFG_WS_CONTROL_BYTES);
   int rc = launch_core(a, true, td, precision, S(stream));
   if (rc != MFG_OK || !td) return rc;
+  if (sums_in_core) return reduce_core_sums(d, B, G, accumulate, workspace, nullptr, S(stream));
   if (deferred) {
     rc = launch_values_and_delta(pi_traj, B, T, d, w, reward, gamma, a.discount_pow, delta, workspace, workspace_bytes, S(stream));
     if (rc != MFG_OK) return rc;
@@ -2596,11 +2665,18 @@ int mfg_train_episode(float* pi_io, float* pi_scratch, int64_t B, int d, int T, 
     a.reward_out = reward;
     a.delta = delta;
     a.g = g;
+    const bool sums_in_core = core_sums_ok(d, B, 1, reward_kind, workspace, workspace_bytes);
+    if (sums_in_core) a.part_rows = reinterpret_cast<double*>((char*)workspace + MFG_WS_CONTROL_BYTES);
     int rc = launch_core(a, true, true, precision, st);
     if (rc != MFG_OK) return rc;
     const ApplyArgs ap{lr_critic, lr_actor, w, theta, reward_acc};
     bool applied = false;
-    rc = launch_grad(cur, d, delta, g, reward, B, 1, d, G, 0, workspace, workspace_bytes, st, &ap, &applied);
+    if (sums_in_core) {
+      rc = reduce_core_sums(d, B, G, 0, workspace, &ap, st);
+      applied = true;
+    } else {
+      rc = launch_grad(cur, d, delta, g, reward, B, 1, d, G, 0, workspace, workspace_bytes, st, &ap, &applied);
+    }
     if (rc != MFG_OK) return rc;
     if (!applied) {
       const int64_t F = mfg_num_features(d);
@@ -2652,13 +2728,34 @@ int mfg_train_episode_irl(float* pi_io, float* pi_scratch, int64_t B, int d, int
     int rc = launch_core(a, true, true, precision, st);
     if (rc != MFG_OK) return rc;
     const uint64_t key = rn_seed ^ ((rn_call0 + (uint64_t)s + 1ull) * 0x9E3779B97F4A7C15ull);
-    rc = mfg_reward_net_forward(cur, P, B, d, net->k1, net->f2, net->k2, net->n3, net->n4, net->conv1_w, net->conv1_b,
-                                net->conv2_w, net->conv2_b, net->fc3_w, net->fc3_b, net->fc4_w, net->fc4_b, net->out_w,
-                                net->out_b, net->keep_prob, key, rn_sample_offset, reward, stream);
+    // reward network; at the packed sizes the same launch folds delta = delta0 + r and leaves the partial rows of the batch
+    // sums (one per block of eight samples), so the update is a row reduction instead of a gradient kernel
+    const int64_t FO = mfg_num_features(d) + 3;
+    const int64_t room = workspace_bytes > MFG_WS_CONTROL_BYTES ? (int64_t)((workspace_bytes - MFG_WS_CONTROL_BYTES) / (size_t)(FO * 8)) : 0;
+    const RnSums sm{delta, g, delta, reinterpret_cast<double*>((char*)workspace + MFG_WS_CONTROL_BYTES), room};
+    int rows = 0;
+    rc = reward_net_forward_sums(cur, P, B, d, net->k1, net->f2, net->k2, net->n3, net->n4, net->conv1_w, net->conv1_b,
+                                 net->conv2_w, net->conv2_b, net->fc3_w, net->fc3_b, net->fc4_w, net->fc4_b, net->out_w,
+                                 net->out_b, net->keep_prob, key, rn_sample_offset, reward, &sm, &rows, stream);
     if (rc != MFG_OK) return rc;
     const ApplyArgs ap{lr_critic, lr_actor, w, theta, reward_acc};
     bool applied = false;
-    rc = launch_grad(cur, d, delta, g, reward, B, 1, d, G, 0, workspace, workspace_bytes, st, &ap, &applied, true);
+    if (rows > 0) {
+      ReduceApply rap{};
+      rap.on = 1;
+      rap.lr_c = lr_critic;
+      rap.lr_a = lr_actor;
+      rap.count = (double)B;
+      rap.w = w;
+      rap.theta = theta;
+      rap.reward_acc = reward_acc;
+      hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((FO + RP_OUT - 1) / RP_OUT)), dim3(RP_SLICES * RP_OUT), 0, st,
+                         (const double*)sm.part_rows, (int64_t)rows, FO, 0, G, rap);
+      applied = true;
+      rc = check_launch("irl_sums");
+    } else {
+      rc = launch_grad(cur, d, delta, g, reward, B, 1, d, G, 0, workspace, workspace_bytes, st, &ap, &applied, true);
+    }
     if (rc != MFG_OK) return rc;
     if (!applied) {
       const int64_t F = mfg_num_features(d);

@@ -30,6 +30,12 @@ struct RewardNetArgs {
   uint64_t seed, sample_offset;
   float* reward;  // [B]
   int w3_in_lds;
+  // SUMS variant (IRL step with per-step updates, ac_irl.py:683-708): delta_b = delta0_b + r_b is written to delta_out and
+  // the block leaves one partial row [sum delta phi(state) | sum delta g | sum r | count] of ITS samples in part_rows
+  const double* delta0;
+  const double* gsc;
+  double* delta_out;
+  double* part_rows;  // [gridDim.x][F+3]
 };
 
 #ifndef MFG_RN_WAVES
@@ -255,7 +261,12 @@ struct RunsGeom {
   }
 };
 
-template <int D, int RUN, int RPR, int P1, int P2>
+// SUMS: the IRL env step needs, right after the rewards, the batch sums of the TD update (a6 / a8) over the same samples.
+// Here every wave folds its samples into FO = F + 3 running sums spread over its lanes (entry k = lane + 64 q: one
+// fp64 fma per entry and sample, operands from a (D + 1)-float LDS line [state | 1]); the block's eight waves are added
+// up in wave order at the end and leave ONE partial row.  The separate gradient kernel of the step (a launch, a re-read
+// of the states, a fence-and-last-block finish: 10.6 us at B = 4 096) shrinks to the row reduction.
+template <int D, int RUN, int RPR, int P1, int P2, bool SUMS = false>
 __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
   using Gm = RunsGeom<D, RUN, RPR, P1, P2>;
   constexpr int K1 = Gm::K1, K2 = Gm::K2, F2 = Gm::F2, H1 = Gm::H1, H2 = Gm::H2, DD = Gm::DD, PP = Gm::PP;
@@ -346,22 +357,63 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
   }
   const int64_t nw = (int64_t)gridDim.x * RN_WAVES;
   int64_t b = (int64_t)blockIdx.x * RN_WAVES + wv;
+  // SUMS: this lane's entries k = lane + 64 q of the row: coefficient kind (0 delta, 1 delta g, 2 r, 3 one, -1 none) and
+  // the two factors' positions in the line [state (D) | 1]
+  constexpr int Qs = D * (D + 1) / 2, Fs = Qs + D + 1, FO = Fs + 3, NPL = (FO + WAVE - 1) / WAVE;
+  float* xs = smem + off + RN_WAVES * (Gm::T1 + Gm::T2) + wv * 32;  // (only allocated for SUMS launches)
+  int e_ia[NPL], e_ib[NPL], e_cm[NPL];
+  double e_acc[NPL];
+  if constexpr (SUMS) {
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+      const int k = lane + q * WAVE;
+      e_acc[q] = 0.0;
+      e_ia[q] = e_ib[q] = D;
+      e_cm[q] = -1;
+      if (k < Qs) {
+        int i = 0;
+        while (i + 1 < D && feat_idx(i + 1, i + 1, D) <= k) ++i;  // row of the upper triangle that holds entry k
+        e_ia[q] = i;
+        e_ib[q] = i + (k - feat_idx(i, i, D));
+        e_cm[q] = 0;
+      } else if (k < Qs + D) {
+        e_ia[q] = k - Qs;
+        e_cm[q] = 0;
+      } else if (k == Qs + D) {
+        e_cm[q] = 0;
+      } else if (k < FO) {
+        e_cm[q] = k - Fs + 1;  // F: delta g, F + 1: r, F + 2: count
+      }
+    }
+    if (lane == 0) xs[D] = 1.0f;
+  }
   // software prefetch: the next sample's action (and state entry) is in flight while this one is evaluated
   float av[PP], st_mine = 0.0f;
+  double d0_next = 0.0, g_next = 0.0;
 #pragma unroll
   for (int q = 0; q < PP; ++q) av[q] = (b < a.B && lane + q * WAVE < DD) ? a.action[b * DD + lane + q * WAVE] : 0.0f;
   if (b < a.B && lane >= n3 && lane < nin) st_mine = a.state[b * D + (lane - n3)];
+  if (SUMS && b < a.B) {
+    d0_next = a.delta0[b];
+    g_next = a.gsc[b];
+  }
   for (; b < a.B; b += nw) {
     // 1. action -> padded LDS tile (coalesced global read, pixel p = lane + 64 q)
 #pragma unroll
     for (int q = 0; q < PP; ++q)
       if (lane + q * WAVE < DD) tin[o1[q]] = av[q];
     const float st_cur = st_mine;
+    const double d0_cur = d0_next, g_cur = g_next;
+    if (SUMS && lane >= n3 && lane < nin) xs[lane - n3] = st_cur;
     {
       const int64_t bn = b + nw;
 #pragma unroll
       for (int q = 0; q < PP; ++q) av[q] = (bn < a.B && lane + q * WAVE < DD) ? a.action[bn * DD + lane + q * WAVE] : 0.0f;
       if (bn < a.B && lane >= n3 && lane < nin) st_mine = a.state[bn * D + (lane - n3)];
+      if (SUMS && bn < a.B) {
+        d0_next = a.delta0[bn];
+        g_next = a.gsc[bn];
+      }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -451,8 +503,37 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
       if (drop) h4 = (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(u_drop), 32 + o)) <= a.keep_prob) ? h4 * inv_keep : 0.0f;
       z = fmaf(h4, s_wo[o], z);
     }
-    if (lane == 0) a.reward[b] = tanhf(z);
+    const float rwd = tanhf(z);
+    if (lane == 0) a.reward[b] = rwd;
+    if constexpr (SUMS) {
+      const double rr = (double)rwd, de = d0_cur + rr;  // delta = r + discount V(pi') - V(pi)   (ac_irl.py:691)
+      if (lane == 0) a.delta_out[b] = de;
+      const double dgc = de * g_cur;
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) {
+        const double x = (double)xs[e_ia[q]] * (double)xs[e_ib[q]];
+        const double coef = e_cm[q] == 0 ? de : (e_cm[q] == 1 ? dgc : (e_cm[q] == 2 ? rr : (e_cm[q] == 3 ? 1.0 : 0.0)));
+        e_acc[q] = fma(coef, x, e_acc[q]);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+  }
+  if constexpr (SUMS) {
+    __syncthreads();  // every wave is done with its tiles: they now hold the waves' rows
+    double* rows = reinterpret_cast<double*>(smem + off);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+      const int k = lane + q * WAVE;
+      if (k < FO) rows[wv * FO + k] = e_acc[q];
+    }
+    __syncthreads();
+    for (int k = tid; k < FO; k += RN_BLOCK) {
+      double t = rows[k];
+#pragma unroll
+      for (int w_ = 1; w_ < RN_WAVES; ++w_) t += rows[w_ * FO + k];
+      a.part_rows[(int64_t)blockIdx.x * FO + k] = t;
+    }
   }
 }
 
@@ -460,11 +541,15 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
 
 using namespace mfg;
 
-extern "C" int mfg_reward_net_forward(const float* state, const float* action, int64_t B, int d, int k1, int f2, int k2,
-                                      int n3, int n4, const float* conv1_w, const float* conv1_b, const float* conv2_w,
-                                      const float* conv2_b, const float* fc3_w, const float* fc3_b, const float* fc4_w,
-                                      const float* fc4_b, const float* out_w, const float* out_b, float keep_prob,
-                                      uint64_t seed, uint64_t sample_offset, float* reward, mfg_stream_t stream) {
+namespace mfg {
+// sums != NULL: ask for the SUMS variant; *rows_out = partial rows written (0: this shape has no SUMS kernel -- the plain
+// forward ran and the caller takes the separate gradient kernel)
+int reward_net_forward_sums(const float* state, const float* action, int64_t B, int d, int k1, int f2, int k2, int n3, int n4,
+                            const float* conv1_w, const float* conv1_b, const float* conv2_w, const float* conv2_b,
+                            const float* fc3_w, const float* fc3_b, const float* fc4_w, const float* fc4_b,
+                            const float* out_w, const float* out_b, float keep_prob, uint64_t seed, uint64_t sample_offset,
+                            float* reward, const RnSums* sums, int* rows_out, mfg_stream_t stream) {
+  if (rows_out) *rows_out = 0;
   if (B < 0 || d < 1 || !state || !action || !reward || !conv1_w || !conv1_b || !conv2_w || !conv2_b || !fc3_w ||
       !fc3_b || !fc4_w || !fc4_b || !out_w || !out_b)
     return set_error(MFG_EINVAL, "reward_net: null pointer / bad shape");
@@ -474,7 +559,13 @@ extern "C" int mfg_reward_net_forward(const float* state, const float* action, i
     return set_error(MFG_EUNSUPPORTED, "reward_net: supported d <= 32, f2 <= 2, n_fc <= 32, odd kernels <= 7");
   if (B == 0) return MFG_OK;
   RewardNetArgs a{state, action, B, d, k1, f2, k2, n3, n4, conv1_w, conv1_b, conv2_w, conv2_b, fc3_w, fc3_b,
-                  fc4_w, fc4_b, out_w, out_b, keep_prob, seed, sample_offset, reward, 0};
+                  fc4_w, fc4_b, out_w, out_b, keep_prob, seed, sample_offset, reward, 0, nullptr, nullptr, nullptr, nullptr};
+  if (sums) {
+    a.delta0 = sums->delta0;
+    a.gsc = sums->g;
+    a.delta_out = sums->delta_out;
+    a.part_rows = sums->part_rows;
+  }
   const int dd = d * d;
   const int W1 = d + 2 * (k1 / 2), W2 = d + 2 * (k2 / 2);
   size_t fl = (size_t)(k1 * k1 + 1) + (size_t)(f2 * k2 * k2 + f2) + (size_t)(n4 * (n3 + d) + 2 * n4 + 1 + n3);
@@ -498,17 +589,40 @@ extern "C" int mfg_reward_net_forward(const float* state, const float* action, i
   else hipLaunchKernelGGL((k_reward_net<PP, 0, 0, 0, 0>), dim3((unsigned)grid), dim3(RN_BLOCK), lds, st, a);
   // w3 rows are read as float2 at even offsets: needs an 8-byte aligned fc3_w when it is not staged in LDS
   const bool runs_ok = ref_geom && (a.w3_in_lds || (((uintptr_t)fc3_w & 7) == 0));
+  const bool want_sums = sums && sums->delta0 && sums->g && sums->delta_out && sums->part_rows && grid <= sums->max_rows;
   if (runs_ok && d == 21) {
     using Gm = RunsGeom<21, 7, 3, MFG_RN_P21, MFG_RN_P21>;
-    hipLaunchKernelGGL((k_reward_net_runs<21, 7, 3, MFG_RN_P21, MFG_RN_P21>), dim3((unsigned)grid), dim3(RN_BLOCK),
-                       Gm::lds_floats(n3, n4, a.w3_in_lds != 0) * 4, st, a);
+    if (want_sums) {
+      hipLaunchKernelGGL((k_reward_net_runs<21, 7, 3, MFG_RN_P21, MFG_RN_P21, true>), dim3((unsigned)grid), dim3(RN_BLOCK),
+                         (Gm::lds_floats(n3, n4, a.w3_in_lds != 0) + RN_WAVES * 32) * 4, st, a);
+      *rows_out = (int)grid;
+    } else {
+      hipLaunchKernelGGL((k_reward_net_runs<21, 7, 3, MFG_RN_P21, MFG_RN_P21>), dim3((unsigned)grid), dim3(RN_BLOCK),
+                         Gm::lds_floats(n3, n4, a.w3_in_lds != 0) * 4, st, a);
+    }
   } else if (runs_ok && d == 15) {
     using Gm = RunsGeom<15, 5, 3, MFG_RN_P15, MFG_RN_P15>;
-    hipLaunchKernelGGL((k_reward_net_runs<15, 5, 3, MFG_RN_P15, MFG_RN_P15>), dim3((unsigned)grid), dim3(RN_BLOCK),
-                       Gm::lds_floats(n3, n4, a.w3_in_lds != 0) * 4, st, a);
+    if (want_sums) {
+      hipLaunchKernelGGL((k_reward_net_runs<15, 5, 3, MFG_RN_P15, MFG_RN_P15, true>), dim3((unsigned)grid), dim3(RN_BLOCK),
+                         (Gm::lds_floats(n3, n4, a.w3_in_lds != 0) + RN_WAVES * 32) * 4, st, a);
+      *rows_out = (int)grid;
+    } else {
+      hipLaunchKernelGGL((k_reward_net_runs<15, 5, 3, MFG_RN_P15, MFG_RN_P15>), dim3((unsigned)grid), dim3(RN_BLOCK),
+                         Gm::lds_floats(n3, n4, a.w3_in_lds != 0) * 4, st, a);
+    }
   } else if (pp <= 4) { RN_LAUNCH(4) }
   else if (pp <= 7) { RN_LAUNCH(7) }
   else { RN_LAUNCH(16) }
 #undef RN_LAUNCH
   return hipGetLastError() == hipSuccess ? MFG_OK : set_error(MFG_ELAUNCH, "reward_net: launch failed");
+}
+}  // namespace mfg
+
+extern "C" int mfg_reward_net_forward(const float* state, const float* action, int64_t B, int d, int k1, int f2, int k2,
+                                      int n3, int n4, const float* conv1_w, const float* conv1_b, const float* conv2_w,
+                                      const float* conv2_b, const float* fc3_w, const float* fc3_b, const float* fc4_w,
+                                      const float* fc4_b, const float* out_w, const float* out_b, float keep_prob,
+                                      uint64_t seed, uint64_t sample_offset, float* reward, mfg_stream_t stream) {
+  return mfg::reward_net_forward_sums(state, action, B, d, k1, f2, k2, n3, n4, conv1_w, conv1_b, conv2_w, conv2_b, fc3_w, fc3_b,
+                                      fc4_w, fc4_b, out_w, out_b, keep_prob, seed, sample_offset, reward, nullptr, nullptr, stream);
 }
