@@ -464,8 +464,13 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
         pis[tlc * d + i] = pi_i;
         if (SAMPLE) pis64[tlc * d + i] = (double)pi_i;
         if (sep) {
+#ifdef MFG_ABL_STAGE
+          pex[tlc * d + i] = pi_i;
+          Fi = pi_i + 1.0f;
+#else
           pex[tlc * d + i] = exp_f64arg(theta * ((double)pi_i - SEP_CENTRE));
           Fi = exp_f64arg(-theta * ((double)pi_i + (a.shift - SEP_CENTRE)));
+#endif
         }
       }
       if (!SAMPLE) {
@@ -554,7 +559,9 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
           // element, within 1.5 ulp of the strict value; rows still sum to 1 within a few 1e-7)
           if (FAST) {
             const float inv32 = fast_rcp_f32_of_f64(Ssum);
+#ifndef MFG_ABL_NORM
             for (int j = 0; j < d; ++j) trow[j] *= inv32;
+#endif
 #ifndef MFG_ABL_EPI
             if (TD) gacc -= fast_log_f64(Ssum) * D_;
 #endif
@@ -580,8 +587,12 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
         double acc = 0.0, s1 = 0.0, s2 = 0.0;
         const float* tcol = tile + tlc * d * dp + i;
         const double* q64 = pis64 + tlc * d;
+#ifdef MFG_ABL_COLT
+        for (int k = 0; k < 0; ++k) {
+#else
 #pragma unroll 3
         for (int k = 0; k < d; ++k) {
+#endif
           const double p = (double)tcol[k * dp];
           const double u = p * q64[k];
           acc += u;
@@ -676,7 +687,11 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
       }
       tile_sync();
       const int gl = d > 1 ? 1 : 0;  // lane of the trajectory that sums the score
+#ifdef MFG_ABL_TSUM
+      if (false) {
+#else
       if (valid && i == 0) {
+#endif
         double r0 = 0.0, r1 = 0.0, v0 = 0.0, v1 = 0.0;
         if (ext) {
           r0 = a.reward_in ? (double)a.reward_in[b * T + s] : 0.0;
@@ -712,7 +727,11 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
           discount *= a.gamma;
         }
       }
+#ifdef MFG_ABL_TSUM
+      if (false) {
+#else
       if (TD && valid && i == gl && a.g) {
+#endif
         double g0 = 0.0, g1 = 0.0;
         int k = 0;
 #pragma unroll

@@ -664,6 +664,38 @@ def test_grad_accumulate_all_kernels(dev, d, B, T, add_reward):
     assert float((G[:Q] - 2 * ref[:Q]).abs().max()) <= 1e-12 * max(scale, 1e-300)
 
 
+@pytest.mark.parametrize('d,B', [(21, 1), (21, 12), (21, 13), (21, 4096), (21, 6144), (21, 6145), (15, 16), (15, 5000)])
+@pytest.mark.parametrize('precision', ['mixed', 'f64'])
+def test_step_kernel_fused_batch_sums(dev, d, B, precision):
+    """Per-step updates (T = 1) at the packed sizes: the step kernel itself leaves the batch sums of its tile
+    (k_core_small<..., SUMS>, fp64 MFMA on the augmented vectors) and a row reduction finishes them; above 512 tiles the
+    two-kernel path takes over.  G must equal the sums formed by the stand-alone gradient kernel over the SAME outputs
+    (re-associated fp64 sums: 1e-12), both paths must produce identical per-trajectory outputs, and `accumulate` must
+    add onto G."""
+    o_ = ops()
+    rs = np.random.RandomState(d + B)
+    pi0 = t32(rs.dirichlet(np.ones(d), size=B), dev)
+    F = o_.num_features(d)
+    w = t64(rs.rand(F), dev)
+    th = t64([8.86349], dev)
+    ws = o_.workspace(B, d, dev)
+    out = o_.rollout(pi0, 1, th, 0.16, 12000.0, w=w, gamma=0.9, seed=3, first_step=7, td=True, ws=ws, precision=precision)
+    G = out['G'].clone()
+    ref = torch.zeros_like(G)
+    o_.grad_accumulate(out['pi_traj'], out['delta'].view(-1).clone(), out['g'].view(-1), out['reward'].view(-1), ref,
+                       o_.workspace(B, d, dev), T=1)
+    scale = float(ref[:F].abs().max())
+    assert float((G[:F] - ref[:F]).abs().max()) <= 1e-12 * max(scale, 1e-300)
+    assert float((G[F:] - ref[F:]).abs().max()) <= 1e-11 * max(1.0, float(ref[F:].abs().max()))
+    assert float(G[F + 2]) == B
+    # the same launch without batch sums (no G): identical per-trajectory outputs
+    out2 = o_.rollout(pi0, 1, th, 0.16, 12000.0, w=w, gamma=0.9, seed=3, first_step=7, td=True, reward_kind=2, precision=precision)
+    assert torch.equal(out2['pi_traj'], out['pi_traj']) and torch.equal(out2['g'], out['g'])
+    o_.rollout(pi0, 1, th, 0.16, 12000.0, w=w, gamma=0.9, seed=3, first_step=7, td=True, ws=ws, G=G, accumulate=True,
+               precision=precision)
+    assert float((G[:F] - 2 * ref[:F]).abs().max()) <= 1e-12 * max(scale, 1e-300) and float(G[F + 2]) == 2 * B
+
+
 def test_mixed_sampler_range_of_the_separable_exponential(dev):
     """Mixed precision forms e^{theta (pi_j - pi_i - shift)} as E_j F_i, fp32 factors centred on pi = 1/2.  Inside the
     documented range, |theta| (1/2 + |shift|) <= 86, the sampler is still exact (KS on Beta marginals at theta = 40 and,

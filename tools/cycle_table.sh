@@ -16,7 +16,7 @@ run() {  # $1 = out dir, $2 = counters, $3 = library ('' = shipped)
 }
 run /tmp/ct1 "$P1" ""; run /tmp/ct2 "$P2" ""; run /tmp/ct3 "$P3" ""
 ABL=""
-for a in PHILOX BM SETUP TRY HTAB LNY EPI COLREW V; do
+for a in PHILOX BM SETUP TRY HTAB LNY EPI COLREW COLT NORM STAGE TSUM V; do
   if [ -f $V/libabl_$a.so ]; then run /tmp/cta_$a "$P1" $V/libabl_$a.so; ABL="$ABL $a"; fi
 done
 python3 - "$SH" $ABL <<'PY'
@@ -45,28 +45,33 @@ COST = collections.OrderedDict([('FMA_F32', 2.2), ('ADD_F32', 2.2), ('MUL_F32', 
 W = m.get('SQ_WAVES', 1.0)
 tot_i = m.get('SQ_INSTS_VALU', 0.0); act = 4.0 * m.get('SQ_ACTIVE_INST_VALU', 0.0)
 elems = (d * T) if d <= 64 else ((d * d // 64) * T)   # matrix elements per lane per launch
+GHZ, NSIMD = 2.4, 1024
+dur = min(x for x in durs if x > 0)
+budget = dur * 1e-6 * GHZ * 1e9 * NSIMD / W              # SIMD cycles available per wave over the kernel's duration
 print('shape d,T,B = %s   kernel time under PMC %.1f / %.1f / %.1f us   waves %.0f   matrix elements per lane per launch %d' % (shape, *durs, W, elems))
-print('VALU instructions per wave %.0f (%.1f per element)   VALU-active cycles per wave %.0f (%.1f per element)   => %.2f cycles per instruction'
-      % (tot_i / W, tot_i / W / elems, act / W, act / W / elems, act / max(tot_i, 1)))
+print('VALU instructions per wave %.0f (%.1f per element)' % (tot_i / W, tot_i / W / elems))
 print('%-34s %12s %10s %8s %12s %8s' % ('class (SQ_INSTS_VALU_*)', 'instr/wave', 'per elem', 'cost', 'cycles/wave', 'share'))
-rows = []; known_i = 0.0; known_c = 0.0
+rows = []; known_i = 0.0
 for k, c in COST.items():
     v = m.get('SQ_INSTS_VALU_' + k, 0.0)
-    rows.append((k, v, c)); known_i += v; known_c += v * c
+    rows.append((k, v, c)); known_i += v
 rest = tot_i - known_i
-rest_cost = (act - known_c) / rest if rest > 0 else 0.0
+rows.append(('not in a class counter (logic, moves, selects, compares, DPP, readlane: plain 32-bit)', rest, 2.2))
+priced = sum(v * c for _, v, c in rows)
 for k, v, c in rows:
-    print('%-34s %12.0f %10.2f %8.1f %12.0f %7.1f%%' % (k, v / W, v / W / elems, c, v * c / W, 100 * v * c / max(act, 1)))
-print('%-34s %12.0f %10.2f %8.2f %12.0f %7.1f%%   (moves, selects, compares, DPP, bit-field ops, readlane: cost = what is left of the measured cycles)'
-      % ('not in a class counter', rest / W, rest / W / elems, rest_cost, (act - known_c) / W, 100 * (act - known_c) / max(act, 1)))
-print('%-34s %12.0f %10.2f %8s %12.0f %7.1f%%' % ('TOTAL (measured)', tot_i / W, tot_i / W / elems, '', act / W, 100.0))
-if 'SQ_WAVE_CYCLES' in m:
-    wc = 4.0 * m['SQ_WAVE_CYCLES']
-    print('wave cycles per wave %.0f: VALU-active %.1f %%, waiting on s_waitcnt/barrier %.1f %%, issue stalls %.1f %%; LDS instr/wave %.0f, SALU instr/wave %.0f'
-          % (wc / W, 100 * act / wc, 100 * 4 * m.get('SQ_WAIT_ANY', 0) / wc, 100 * 4 * m.get('SQ_WAIT_INST_ANY', 0) / wc, m.get('SQ_INSTS_LDS', 0) / W, m.get('SQ_INSTS_SALU', 0) / W))
+    print('%-34s %12.0f %10.2f %8.1f %12.0f %7.1f%%' % (k[:34], v / W, v / W / elems, c, v * c / W, 100 * v * c / priced))
+    if len(k) > 34: print('    (%s)' % k)
+print('%-34s %12.0f %10.2f %8.2f %12.0f %7.1f%%' % ('TOTAL priced with measured costs', tot_i / W, tot_i / W / elems, priced / tot_i, priced / W, 100.0))
+print('SIMD cycles available per wave (kernel time x %.1f GHz x %d SIMDs / waves): %.0f  =>  the priced VALU issue work fills %.0f %% of them'
+      % (GHZ, NSIMD, budget, 100 * priced / W / budget))
+trans = m.get('SQ_INSTS_VALU_TRANS_F32', 0.0) + m.get('SQ_INSTS_VALU_TRANS_F64', 0.0)
+print('SQ_ACTIVE_INST_VALU x 4 = %.0f per wave = %.2f per instruction.  NOT an execution time: the counter books one quad-cycle (4 cycles) per '
+      'VALU instruction issued and two per transcendental, whatever the pipe does afterwards -- 4 + 4 x (transcendental share %.4f) = %.2f; '
+      'the pieces below that contain no transcendental (fp32-only HTAB, fp64-only COLREW / V, Philox with its 6.4-cycle v_mad_u64_u32) all '
+      'come out at exactly 4.00.' % (act / W, act / max(tot_i, 1), trans / max(tot_i, 1), 4 + 4 * trans / max(tot_i, 1)))
 if abl:
     print('\nby piece (shipped build minus the build with that piece replaced by a 1-4 instruction stand-in, tools/ablate.sh):')
-    print('%-10s %14s %14s %10s %12s' % ('piece', 'instr/elem', 'cycles/elem', 'cyc/instr', 'share of cyc'))
+    print('%-10s %14s %14s %10s %12s' % ('piece', 'instr/elem', 'counter/elem', 'ctr/instr', 'share of instr'))
     ti = tc = 0.0
     for a in abl:
         c, _ = load('/tmp/cta_' + a)
@@ -74,7 +79,7 @@ if abl:
         di = (tot_i - c.get('SQ_INSTS_VALU', 0.0) * W / max(c.get('SQ_WAVES', W), 1)) / W / elems
         dc = (act - 4.0 * c.get('SQ_ACTIVE_INST_VALU', 0.0) * W / max(c.get('SQ_WAVES', W), 1)) / W / elems
         ti += di; tc += dc
-        print('%-10s %14.2f %14.1f %10.2f %11.1f%%' % (a, di, dc, dc / di if di else 0.0, 100 * dc * W * elems / max(act, 1)))
+        print('%-10s %14.2f %14.1f %10.2f %11.1f%%' % (a, di, dc, dc / di if di else 0.0, 100 * di * W * elems / max(tot_i, 1)))
     print('%-10s %14.2f %14.1f %10.2f %11.1f%%' % ('the rest', tot_i / W / elems - ti, act / W / elems - tc,
-                                                 (act / W / elems - tc) / max(tot_i / W / elems - ti, 1e-9), 100 * (1 - tc * W * elems / max(act, 1))))
+                                                 (act / W / elems - tc) / max(tot_i / W / elems - ti, 1e-9), 100 * (1 - ti * W * elems / max(tot_i, 1))))
 PY

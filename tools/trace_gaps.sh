@@ -6,7 +6,7 @@ f=$(find /tmp/tg -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r['Start_Timestamp']))
-rows = rows[-60:-10]
+rows = rows[-int(__import__("os").environ.get("TG_ROWS", "60")):-10]
 prev_end = None
 for r in rows:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
