@@ -343,13 +343,15 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
   const int pnw = CIRC ? 2 * d : d;  // floats per trajectory in pin
   double* wl = reinterpret_cast<double*>(smem_raw);
   double* pis64 = wl + (want_v ? F : 0);  // SAMPLE: the states as fp64 (column pass: transition + reward sums)
-  double* red = pis64 + (SAMPLE ? TB * d : 0);  // [TB][3][d]: per-lane terms of reward / score / value, summed by lane 0 / 1
-  float* tile = reinterpret_cast<float*>(red + 3 * TB * d);
+  double* red = pis64 + (SAMPLE ? TB * d : 0);  // [TB][4][d]: per-lane terms of reward / score / V(next) / V(start), summed by lane 0 / 1
+  float* tile = reinterpret_cast<float*>(red + 4 * TB * d);
   float* pis = tile + TB * d * dp;
   float* pin = pis + TB * d;       // [TB][pnw]
   float* pal = pin + TB * 2 * d;
   float* pex = pal + TB * d;       // SAMPLE, mixed: E_j = e^{theta pi_j} (separable exponential, mfg_device.h)
   double* scal = reinterpret_cast<double*>(pex + TB * d + ((TB * d) & 1));  // SUMS: (delta, g, r) per trajectory of the tile
+  float* pst = reinterpret_cast<float*>(scal + TB * 3);  // [TB][pnw]: the rollout's START state (doubled for CIRC): its value is
+                                                         // evaluated inside step 0, next to V of the next state
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
   const int t = lane / d, i = lane - t * d;
   const double theta = *a.theta;
@@ -428,33 +430,14 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
     const bool valid = (t < G) && (tl < nb);
     const int tlc = valid ? tl : 0;
     const int64_t b = b0 + tlc;
-    double* redq = red + (size_t)tlc * 3 * d;
+    double* redq = red + (size_t)tlc * 4 * d;
     float* pnv = pin + tlc * pnw;
     float pi_i = tileid == blockIdx.x ? pi_first : a.pi0[(a.start_idx ? start_row(a.start_idx[b], a.num_start) : b) * d + i];
     if (valid && a.pi_traj) a.pi_traj[b * (int64_t)(T + 1) * d + i] = pi_i;
     double v_cur = 0.0, discount = 1.0;  // meaningful on lane i == 0 only
-    if (want_v && SAMPLE) {
-      // V of the start state (GIVEN mode evaluates it inside its single step, below)
-      tile_sync();
-      if (valid) {
-        pnv[i] = pi_i;
-        if (CIRC) pnv[d + i] = pi_i;
-      }
-      tile_sync();
-      if (valid) redq[2 * d + i] = value_term(pnv, pi_i);
-      tile_sync();
-      if (i == 0) {
-        double v0 = 0.0, v1 = 0.0;
-        int k = 0;
-#pragma unroll 2
-        for (; k + 1 < d; k += 2) {
-          v0 += redq[2 * d + k];
-          v1 += redq[2 * d + k + 1];
-        }
-        if (k < d) v0 += redq[2 * d + k];
-        v_cur = (v0 + v1) + wl[Q + d];
-      }
-    }
+    // (V of the start state: evaluated inside step 0 next to V of the next state -- as a prologue it cost three barriers,
+    //  two LDS round trips and a serial sum BEFORE any sampling could start: 3 500 of the 20 000 cycles of a T = 1 launch.
+    //  GIVEN mode evaluates it inside its single step as before.)
     MFG_STAMP0(10)
     for (int s = 0; s < T; ++s) {
       MFG_STAMP(0)
@@ -462,6 +445,10 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
       float Fi = 0.0f;
       if (valid) {
         pis[tlc * d + i] = pi_i;
+        if (SAMPLE && want_v && s == 0) {
+          pst[tlc * pnw + i] = pi_i;
+          if (CIRC) pst[tlc * pnw + d + i] = pi_i;
+        }
         if (SAMPLE) pis64[tlc * d + i] = (double)pi_i;
         if (sep) {
 #ifdef MFG_ABL_STAGE
@@ -559,7 +546,9 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
           // element, within 1.5 ulp of the strict value; rows still sum to 1 within a few 1e-7)
           if (FAST) {
             const float inv32 = fast_rcp_f32_of_f64(Ssum);
-#ifndef MFG_ABL_NORM
+#ifdef MFG_ABL_NORM  // timing ablation: no read / multiply (magnitudes stay sane: rows sum to d / S instead of 1)
+            for (int j = 0; j < d; ++j) trow[j] = inv32;
+#else
             for (int j = 0; j < d; ++j) trow[j] *= inv32;
 #endif
 #ifndef MFG_ABL_EPI
@@ -684,6 +673,7 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
           tile_sync();
         }
         if (valid) redq[2 * d + i] = value_term(pnv, pi_n);
+        if (SAMPLE && s == 0 && valid) redq[3 * d + i] = value_term(pst + tlc * pnw, pi_i);  // (pi_i: still the start state)
       }
       tile_sync();
       const int gl = d > 1 ? 1 : 0;  // lane of the trajectory that sums the score
@@ -716,6 +706,17 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
           }
           if (k < d) v0 += redq[2 * d + k];
           const double v_next = (v0 + v1) + wl[Q + d];
+          if (SAMPLE && s == 0) {  // V of the start state: the same even / odd sums as for every other state
+            double u0 = 0.0, u1 = 0.0;
+            int kk = 0;
+#pragma unroll
+            for (; kk + 1 < d; kk += 2) {
+              u0 += redq[3 * d + kk];
+              u1 += redq[3 * d + kk + 1];
+            }
+            if (kk < d) u0 += redq[3 * d + kk];
+            v_cur = (u0 + u1) + wl[Q + d];
+          }
           const double gd = a.discount_pow ? discount : a.gamma;
           const double del = r + gd * v_next - v_cur;
           if (a.delta) a.delta[b * T + s] = del;
@@ -819,8 +820,8 @@ inline size_t core_small_lds(int d, bool want_v, bool sample) {
   const int G = WAVE / d, TB = WAVES * G, dp = d | 1;
   const size_t F = (size_t)d * (d + 1) / 2 + d + 1;
   const size_t fl = (size_t)TB * d * dp + 5 * (size_t)TB * d;  // floats: tile, pis, pin (doubled), pal, pex
-  return (want_v ? F * 8 : 0) + (sample ? (size_t)TB * d * 8 : 0) + (size_t)3 * TB * d * 8 + (fl + (fl & 1)) * 4 +
-         (size_t)TB * 3 * 8;  // + SUMS scalars
+  return (want_v ? F * 8 : 0) + (sample ? (size_t)TB * d * 8 : 0) + (size_t)4 * TB * d * 8 + (fl + (fl & 1)) * 4 +
+         (size_t)TB * 3 * 8 + (size_t)TB * 2 * d * 4;  // + SUMS scalars + start state
 }
 
 // ---------------------------------------------------------------------------------------------

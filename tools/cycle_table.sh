@@ -15,8 +15,19 @@ run() {  # $1 = out dir, $2 = counters, $3 = library ('' = shipped)
   rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $1 -o p -- python3 $R/tools/pmc_rollout.py $SH > $1.log 2>&1
 }
 run /tmp/ct1 "$P1" ""; run /tmp/ct2 "$P2" ""; run /tmp/ct3 "$P3" ""
+# the kernel's duration WITHOUT counters (PMC passes run 15-20 % slower): a kernel-trace-only pass
+rm -rf /tmp/ct0; unset MFG_HIP_LIB
+rocprofv3 --kernel-trace --output-format csv -d /tmp/ct0 -o p -- python3 $R/tools/pmc_rollout.py $SH > /tmp/ct0.log 2>&1
+DUR0=$(python3 - <<'PY'
+import csv, glob
+f = glob.glob('/tmp/ct0/**/*kernel_trace.csv', recursive=True)
+d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in csv.DictReader(open(f[0])) if 'k_core_' in r['Kernel_Name']] if f else []
+print(min(d) if d else 0.0)
+PY
+)
+export CT_DUR0=$DUR0
 ABL=""
-for a in PHILOX BM SETUP TRY HTAB LNY EPI COLREW COLT NORM STAGE TSUM V; do
+for a in PHILOX BM SETUP TRY HTAB LNY EPI COLT NORM TSUM V; do
   if [ -f $V/libabl_$a.so ]; then run /tmp/cta_$a "$P1" $V/libabl_$a.so; ABL="$ABL $a"; fi
 done
 python3 - "$SH" $ABL <<'PY'
@@ -46,9 +57,10 @@ W = m.get('SQ_WAVES', 1.0)
 tot_i = m.get('SQ_INSTS_VALU', 0.0); act = 4.0 * m.get('SQ_ACTIVE_INST_VALU', 0.0)
 elems = (d * T) if d <= 64 else ((d * d // 64) * T)   # matrix elements per lane per launch
 GHZ, NSIMD = 2.4, 1024
-dur = min(x for x in durs if x > 0)
+import os
+dur = float(os.environ.get('CT_DUR0', '0')) or min(x for x in durs if x > 0)
 budget = dur * 1e-6 * GHZ * 1e9 * NSIMD / W              # SIMD cycles available per wave over the kernel's duration
-print('shape d,T,B = %s   kernel time under PMC %.1f / %.1f / %.1f us   waves %.0f   matrix elements per lane per launch %d' % (shape, *durs, W, elems))
+print('shape d,T,B = %s   kernel time %.1f us without counters (%.1f / %.1f / %.1f us in the PMC passes)   waves %.0f   matrix elements per lane per launch %d' % (shape, dur, *durs, W, elems))
 print('VALU instructions per wave %.0f (%.1f per element)' % (tot_i / W, tot_i / W / elems))
 print('%-34s %12s %10s %8s %12s %8s' % ('class (SQ_INSTS_VALU_*)', 'instr/wave', 'per elem', 'cost', 'cycles/wave', 'share'))
 rows = []; known_i = 0.0
