@@ -15,9 +15,10 @@ run() {  # $1 = out dir, $2 = counters, $3 = library ('' = shipped)
   rocprofv3 --pmc $2 --kernel-trace --output-format csv -d $1 -o p -- python3 $R/tools/pmc_rollout.py $SH > $1.log 2>&1
 }
 run /tmp/ct1 "$P1" ""; run /tmp/ct2 "$P2" ""; run /tmp/ct3 "$P3" ""
-# the kernel's duration WITHOUT counters (PMC passes run 15-20 % slower): a kernel-trace-only pass
+# the kernel's WARM duration (the three launches of a PMC pass run on a device that is still ramping its clock, ~20 % slower):
+# a kernel-trace-only pass with enough launches, fastest launch
 rm -rf /tmp/ct0; unset MFG_HIP_LIB
-rocprofv3 --kernel-trace --output-format csv -d /tmp/ct0 -o p -- python3 $R/tools/pmc_rollout.py $SH > /tmp/ct0.log 2>&1
+PMC_LAUNCHES=$([ "${SH%%,*}" -le 64 ] && echo 40 || echo 4) rocprofv3 --kernel-trace --output-format csv -d /tmp/ct0 -o p -- python3 $R/tools/pmc_rollout.py $SH > /tmp/ct0.log 2>&1
 DUR0=$(python3 - <<'PY'
 import csv, glob
 f = glob.glob('/tmp/ct0/**/*kernel_trace.csv', recursive=True)

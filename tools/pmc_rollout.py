@@ -12,6 +12,6 @@ rs = np.random.RandomState(0)
 pi0 = torch.as_tensor(rs.dirichlet(np.ones(d), size=B).astype(np.float32), device=dev)
 w = torch.as_tensor(rs.rand(ops.num_features(d)), device=dev)
 td = 'env' not in sys.argv[2:]
-for _ in range(3):
+for _ in range(int(os.environ.get('PMC_LAUNCHES', '3'))):
     ops.rollout(pi0, T, th, 0.16, 12000.0, w=w if td else None, seed=7, td=td)
 torch.cuda.synchronize()
