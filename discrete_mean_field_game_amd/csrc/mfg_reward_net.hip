@@ -13,7 +13,6 @@
 
 #include "../../include/mfg_hip.h"
 #include "mfg_core.h"
-#include "mfg_reward_net_dev.h"
 
 namespace mfg {
 
@@ -236,8 +235,32 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
 // The run's 2*RUN FC3 inputs are contiguous in the NHWC-flattened weight rows (8-byte reads), the FC3 reductions run on
 // the DPP path instead of ds_bpermute, and the conv weights sit in scalar registers.
 // ---------------------------------------------------------------------------------------------
-// (the evaluator itself -- RunsGeom, RnRunsEval, wave_sum_f32_dpp -- lives in mfg_reward_net_dev.h: the IRL step kernel of
-// mfg_core.h evaluates the network with the same code on the action tile it holds in LDS)
+// (dpp_mov_f32 lives in mfg_device.h)
+__device__ __forceinline__ float wave_sum_f32_dpp(float v) {
+  v += dpp_mov_f32<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov_f32<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov_f32<0x141, 0xF>(v);  // row_half_mirror
+  v += dpp_mov_f32<0x140, 0xF>(v);  // row_mirror
+  v += dpp_mov_f32<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_mov_f32<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <int D, int RUN, int RPR, int P1, int P2>
+struct RunsGeom {
+  static_assert(RUN * RPR == D && D * RPR <= WAVE, "runs must tile a row exactly and fit one wavefront");
+  static constexpr int K1 = 5, K2 = 3, F2 = 2, H1 = 2, H2 = 1, DD = D * D;
+  static constexpr int T1 = (D + 2 * H1) * P1, T2 = (D + 2 * H2) * P2;  // floats per padded tile (pitches P1, P2)
+  static constexpr int PP = (DD + WAVE - 1) / WAVE;
+  static size_t lds_floats(int n3, int n4, bool w3_in_lds) {
+    size_t fl = (size_t)(n4 * (n3 + D) + 2 * n4 + 1 + n3);
+    fl = (fl + 3) & ~(size_t)3;
+    if (w3_in_lds) fl += (size_t)n3 * F2 * DD;
+    fl = (fl + 3) & ~(size_t)3;
+    return fl + (size_t)RN_WAVES * (T1 + T2);
+  }
+};
+
 // SUMS: the IRL env step needs, right after the rewards, the batch sums of the TD update (a6 / a8) over the same samples.
 // Here every wave folds its samples into FO = F + 3 running sums spread over its lanes (entry k = lane + 64 q: one
 // fp64 fma per entry and sample, operands from a (D + 1)-float LDS line [state | 1]); the block's eight waves are added
@@ -245,17 +268,93 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
 // of the states, a fence-and-last-block finish: 10.6 us at B = 4 096) shrinks to the row reduction.
 template <int D, int RUN, int RPR, int P1, int P2, bool SUMS = false>
 __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
-  using Ev = RnRunsEval<D, RUN, RPR, P1, P2>;
-  using Gm = typename Ev::Gm;
-  constexpr int DD = Gm::DD, PP = Gm::PP;
+  using Gm = RunsGeom<D, RUN, RPR, P1, P2>;
+  constexpr int K1 = Gm::K1, K2 = Gm::K2, F2 = Gm::F2, H1 = Gm::H1, H2 = Gm::H2, DD = Gm::DD, PP = Gm::PP;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n3 = a.n3, nin = n3 + D;  // FC4 input = [h3 (n3), state (D)], nin <= 64
+  const int n3 = a.n3, n4 = a.n4, nin = n3 + D;  // FC4 input = [h3 (n3), state (D)], nin <= 64
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-  const RnWeights w{a.n3, a.n4, a.c1w, a.c1b, a.c2w, a.c2b, a.w3, a.b3, a.w4, a.b4, a.wo, a.bo, a.keep_prob, a.seed, a.sample_offset};
-  Ev ev;
-  const int off = ev.stage_shared(w, smem, tid, RN_BLOCK, a.w3_in_lds != 0);
-  ev.init_wave(w, smem + off + wv * (Gm::T1 + Gm::T2), lane);
+  float* s_w4 = smem;              // [n4][nin]
+  float* s_b4 = s_w4 + n4 * nin;
+  float* s_wo = s_b4 + n4;
+  float* s_bo = s_wo + n4;
+  float* s_b3 = s_bo + 1;
+  int off = n4 * nin + 2 * n4 + 1 + n3;
+  off = (off + 3) & ~3;
+  float* s3 = smem + off;
+  if (a.w3_in_lds) off += n3 * F2 * DD;
+  off = (off + 3) & ~3;
+  float* tin = smem + off + wv * (Gm::T1 + Gm::T2);
+  float* tc1 = tin + Gm::T1;
+  for (int k = tid; k < n4 * nin; k += RN_BLOCK) s_w4[k] = a.w4[k];
+  for (int k = tid; k < n4; k += RN_BLOCK) {
+    s_b4[k] = a.b4[k];
+    s_wo[k] = a.wo[k];
+  }
+  if (tid == 0) s_bo[0] = a.bo[0];
+  for (int k = tid; k < n3; k += RN_BLOCK) s_b3[k] = a.b3[k];
+  if (a.w3_in_lds) {
+    const int nq = (n3 * F2 * DD) >> 2;
+    const float4* src4 = reinterpret_cast<const float4*>(a.w3);
+    float4* dst4 = reinterpret_cast<float4*>(s3);
+    for (int k0 = 0; k0 < nq; k0 += 4 * RN_BLOCK) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * RN_BLOCK + tid;
+        v[u] = (k < nq) ? src4[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * RN_BLOCK + tid;
+        if (k < nq) dst4[k] = v[u];
+      }
+    }
+    for (int k = (nq << 2) + tid; k < n3 * F2 * DD; k += RN_BLOCK) s3[k] = a.w3[k];
+  }
+  for (int k = lane; k < Gm::T1 + Gm::T2; k += WAVE) tin[k] = 0.0f;  // zero halos (interiors are rewritten)
+  // conv weights and biases: ONE gather per wave (lane t holds entry t of [c1w | c1b | c2w | c2b], 46 values), then
+  // v_readlane into scalar registers.  Plain `a.c1w[k]` reads are re-issued as vector loads for every sample (the
+  // compiler cannot prove that the reward store does not alias them) and sat on the critical path.
+  constexpr int NW1 = K1 * K1, NW2 = F2 * K2 * K2;
+  static_assert(NW1 + 1 + NW2 + F2 <= WAVE, "conv parameters must fit one wavefront");
+  float wtab;
+  {
+    const float* src = lane < NW1 ? a.c1w + lane
+                     : lane == NW1 ? a.c1b
+                     : lane < NW1 + 1 + NW2 ? a.c2w + (lane - NW1 - 1)
+                     : a.c2b + (lane < NW1 + 1 + NW2 + F2 ? lane - NW1 - 1 - NW2 : 0);
+    wtab = *src;
+  }
+  float w1[NW1], w2[F2][K2 * K2];
+#pragma unroll
+  for (int k = 0; k < NW1; ++k) w1[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), k));
+  const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1));
+#pragma unroll
+  for (int c = 0; c < F2; ++c)
+#pragma unroll
+    for (int k = 0; k < K2 * K2; ++k)
+      w2[c][k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 1 + c * K2 * K2 + k));
+  const float b20 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 1 + NW2));
+  const float b21 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 2 + NW2));
   __syncthreads();
+  const float* w3g = a.w3;
+  const bool w3_lds = a.w3_in_lds != 0;
+  const float inv_keep = 1.0f / a.keep_prob;
+  const bool drop = a.keep_prob < 1.0f;
+  // this lane's run: row y, columns x0 .. x0+RUN-1
+  const bool active = lane < D * RPR;
+  const int y = active ? lane / RPR : 0, x0 = active ? (lane - y * RPR) * RUN : 0;
+  const float* win1 = tin + y * P1 + x0;                // top-left of the conv1 window in the padded input tile
+  float* out1 = tc1 + (y + H2) * P2 + x0 + H2;          // this run inside the padded conv1 map
+  const float* win2 = tc1 + y * P2 + x0;                // top-left of the conv2 window
+  const int w3off = (y * D + x0) * F2;                  // the run's 2*RUN inputs inside an FC3 weight row
+  int o1[PP];
+#pragma unroll
+  for (int q = 0; q < PP; ++q) {
+    const int p = lane + q * WAVE;
+    const int pc = p < DD ? p : 0;
+    o1[q] = (pc / D + H1) * P1 + pc % D + H1;
+  }
   const int64_t nw = (int64_t)gridDim.x * RN_WAVES;
   int64_t b = (int64_t)blockIdx.x * RN_WAVES + wv;
   // SUMS: this lane's entries k = lane + 64 q of the row: coefficient kind (0 delta, 1 delta g, 2 r, 3 one, -1 none) and
@@ -299,9 +398,10 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
     g_next = a.gsc[b];
   }
   for (; b < a.B; b += nw) {
-    float cur[PP];
+    // 1. action -> padded LDS tile (coalesced global read, pixel p = lane + 64 q)
 #pragma unroll
-    for (int q = 0; q < PP; ++q) cur[q] = av[q];
+    for (int q = 0; q < PP; ++q)
+      if (lane + q * WAVE < DD) tin[o1[q]] = av[q];
     const float st_cur = st_mine;
     const double d0_cur = d0_next, g_cur = g_next;
     if (SUMS && lane >= n3 && lane < nin) xs[lane - n3] = st_cur;
@@ -315,7 +415,95 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
         g_next = a.gsc[bn];
       }
     }
-    const float rwd = ev.eval(w, cur, st_cur, a.sample_offset + (uint64_t)b, lane);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // 2. conv1 5x5 (cross-correlation, SAME) + ReLU over the run
+    float c1[RUN];
+#pragma unroll
+    for (int k = 0; k < RUN; ++k) c1[k] = b1;
+#pragma unroll
+    for (int dy = 0; dy < K1; ++dy) {
+      float row[RUN + K1 - 1];
+#pragma unroll
+      for (int t = 0; t < RUN + K1 - 1; ++t) row[t] = win1[dy * P1 + t];
+#pragma unroll
+      for (int k = 0; k < RUN; ++k)
+#pragma unroll
+        for (int dx = 0; dx < K1; ++dx) c1[k] = fmaf(row[k + dx], w1[dy * K1 + dx], c1[k]);
+    }
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < RUN; ++k) out1[k] = fmaxf(c1[k], 0.0f);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // 3. conv2 3x3, two filters + ReLU
+    float a2[RUN][F2];
+#pragma unroll
+    for (int k = 0; k < RUN; ++k) {
+      a2[k][0] = b20;
+      a2[k][1] = b21;
+    }
+#pragma unroll
+    for (int dy = 0; dy < K2; ++dy) {
+      float row[RUN + K2 - 1];
+#pragma unroll
+      for (int t = 0; t < RUN + K2 - 1; ++t) row[t] = win2[dy * P2 + t];
+#pragma unroll
+      for (int k = 0; k < RUN; ++k)
+#pragma unroll
+        for (int dx = 0; dx < K2; ++dx) {
+          a2[k][0] = fmaf(row[k + dx], w2[0][dy * K2 + dx], a2[k][0]);
+          a2[k][1] = fmaf(row[k + dx], w2[1][dy * K2 + dx], a2[k][1]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RUN; ++k) {
+      a2[k][0] = active ? fmaxf(a2[k][0], 0.0f) : 0.0f;
+      a2[k][1] = active ? fmaxf(a2[k][1], 0.0f) : 0.0f;
+    }
+    // dropout uniforms of this sample (lane o < 32: FC3 unit o, lane 32+o: FC4 unit o)
+    float u_drop = 0.0f;
+    if (drop) {
+      const u32x4 r = philox_elem(a.seed, (uint32_t)(lane & 31), lane < 32 ? 3u : 4u, a.sample_offset + (uint64_t)b, 0);
+      u_drop = u01(r.x);
+    }
+    // 4. FC3 + ReLU (+ dropout); lane o < n3 keeps unit o, lanes n3 .. n3+D-1 hold the state: `x4` is FC4's input
+    float x4 = (lane >= n3 && lane < nin) ? st_cur : 0.0f;
+#pragma unroll 2
+    for (int o = 0; o < n3; ++o) {
+      float s = 0.0f;
+      if (w3_lds) {
+        const float2* wr = reinterpret_cast<const float2*>(s3 + o * F2 * DD + w3off);
+#pragma unroll
+        for (int k = 0; k < RUN; ++k) {
+          const float2 wv2 = wr[k];
+          s = fmaf(a2[k][0], wv2.x, s);
+          s = fmaf(a2[k][1], wv2.y, s);
+        }
+      } else {
+        const float2* wr = reinterpret_cast<const float2*>(w3g + (int64_t)o * F2 * DD + w3off);
+#pragma unroll
+        for (int k = 0; k < RUN; ++k) {
+          const float2 wv2 = wr[k];
+          s = fmaf(a2[k][0], wv2.x, s);
+          s = fmaf(a2[k][1], wv2.y, s);
+        }
+      }
+      s = wave_sum_f32_dpp(s);
+      float h = fmaxf(s + s_b3[o], 0.0f);
+      if (drop) h = (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(u_drop), o)) <= a.keep_prob) ? h * inv_keep : 0.0f;
+      if (lane == o) x4 = h;
+    }
+    // 5. FC4 over [h3, state] + ReLU (+ dropout), 6. output unit: lane-parallel products, one DPP sum per unit
+    float z = s_bo[0];
+    for (int o = 0; o < n4; ++o) {
+      const float wgt = lane < nin ? s_w4[o * nin + lane] : 0.0f;
+      float h4 = fmaxf(wave_sum_f32_dpp(x4 * wgt) + s_b4[o], 0.0f);
+      if (drop) h4 = (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(u_drop), 32 + o)) <= a.keep_prob) ? h4 * inv_keep : 0.0f;
+      z = fmaf(h4, s_wo[o], z);
+    }
+    const float rwd = tanhf(z);
     if (lane == 0) a.reward[b] = rwd;
     if constexpr (SUMS) {
       const double rr = (double)rwd, de = d0_cur + rr;  // delta = r + discount V(pi') - V(pi)   (ac_irl.py:691)
@@ -406,21 +594,21 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
     using Gm = RunsGeom<21, 7, 3, MFG_RN_P21, MFG_RN_P21>;
     if (want_sums) {
       hipLaunchKernelGGL((k_reward_net_runs<21, 7, 3, MFG_RN_P21, MFG_RN_P21, true>), dim3((unsigned)grid), dim3(RN_BLOCK),
-                         (Gm::lds_floats(n3, n4, a.w3_in_lds != 0, RN_WAVES) + RN_WAVES * 32) * 4, st, a);
+                         (Gm::lds_floats(n3, n4, a.w3_in_lds != 0) + RN_WAVES * 32) * 4, st, a);
       *rows_out = (int)grid;
     } else {
       hipLaunchKernelGGL((k_reward_net_runs<21, 7, 3, MFG_RN_P21, MFG_RN_P21>), dim3((unsigned)grid), dim3(RN_BLOCK),
-                         Gm::lds_floats(n3, n4, a.w3_in_lds != 0, RN_WAVES) * 4, st, a);
+                         Gm::lds_floats(n3, n4, a.w3_in_lds != 0) * 4, st, a);
     }
   } else if (runs_ok && d == 15) {
     using Gm = RunsGeom<15, 5, 3, MFG_RN_P15, MFG_RN_P15>;
     if (want_sums) {
       hipLaunchKernelGGL((k_reward_net_runs<15, 5, 3, MFG_RN_P15, MFG_RN_P15, true>), dim3((unsigned)grid), dim3(RN_BLOCK),
-                         (Gm::lds_floats(n3, n4, a.w3_in_lds != 0, RN_WAVES) + RN_WAVES * 32) * 4, st, a);
+                         (Gm::lds_floats(n3, n4, a.w3_in_lds != 0) + RN_WAVES * 32) * 4, st, a);
       *rows_out = (int)grid;
     } else {
       hipLaunchKernelGGL((k_reward_net_runs<15, 5, 3, MFG_RN_P15, MFG_RN_P15>), dim3((unsigned)grid), dim3(RN_BLOCK),
-                         Gm::lds_floats(n3, n4, a.w3_in_lds != 0, RN_WAVES) * 4, st, a);
+                         Gm::lds_floats(n3, n4, a.w3_in_lds != 0) * 4, st, a);
     }
   } else if (pp <= 4) { RN_LAUNCH(4) }
   else if (pp <= 7) { RN_LAUNCH(7) }
