@@ -474,10 +474,14 @@ class AC_IRL(actor_critic):
             print('----- Exiting reward_iteration at iter %d -----' % it)
 
     def outerloop(self, num_iterations=20, num_gen_from_policy=5, max_reward_iterations=100,
-                  max_forward_episodes=200, gamma=1, constant=False, lr_critic=0.1, lr_actor=0.001, *, first_iteration=0):
+                  max_forward_episodes=200, gamma=1, constant=False, lr_critic=0.1, lr_actor=0.001, *, first_iteration=0,
+                  final_training=True):
         """Alternate reward updates and forward solves (ac_irl.py:900-954); returns the final theta.
-        first_iteration > 0 resumes after load_state_dict: D_samp (list_generated), the reward-update counter and the CSV
-        log of the checkpointed run are kept and the loop continues at that iteration (the reference cannot resume)."""
+        Checkpoint / resume (the reference cannot): `final_training=False` stops after iteration `num_iterations - 1`
+        without the closing 2000-episode forward solve, so that `state_dict()` can be saved there; after
+        `load_state_dict`, `first_iteration=k` continues at iteration k -- D_samp (list_generated), the reward-update counter
+        and the CSV log of the checkpointed run are kept.  outerloop(n) == outerloop(k, final_training=False) ->
+        save / load -> outerloop(n, first_iteration=k), bit for bit."""
         write = 1 if os.path.isdir('results') else 0
         if first_iteration == 0:
             self.list_generated = self.generate_trajectories(num_gen_from_policy * self.num_policies)
@@ -495,6 +499,8 @@ class AC_IRL(actor_critic):
             self.theta = self.theta_initial
             self.train(max_forward_episodes, -1, gamma, constant, lr_critic, lr_actor, consecutive=100,
                        write_file=write, write_all=0)
+        if not final_training:
+            return self.theta
         if os.path.isdir('log'):
             torch.save(self.reward_net.state_dict(), 'log/model_%s_%d_%d.ckpt' % (self.reg, self.n_fc3, self.n_fc4))
         if self.verbose:

@@ -669,6 +669,58 @@ def test_ac_irl_checkpoint_resume_is_bit_identical(dev, mode, tmp_path):
     assert [float(np.ravel(t)[0]) for t in a.list_policies] == [float(np.ravel(t)[0]) for t in c.list_policies]
 
 
+def test_ac_irl_outerloop_resume_is_bit_identical(dev, tmp_path):
+    """outerloop (ac_irl.py:900-954) stopped after iteration 1 (`final_training=False`), saved, loaded into a fresh object
+    and continued with `first_iteration=1` equals the uninterrupted 3-iteration run bit for bit: D_samp, the reward net and
+    its optimiser, the policy FIFO, the dropout-mask counter and the host RNG streams all travel in the checkpoint."""
+    import random
+    d, B = 15, 16
+    rs = np.random.RandomState(4)
+    mat = rs.dirichlet(np.ones(d), size=5)
+    demos = [[(rs.dirichlet(np.ones(d)), rs.dirichlet(np.ones(d), size=d)) for _ in range(15)] for _ in range(6)]
+    kw = dict(num_gen_from_policy=2, max_reward_iterations=3, max_forward_episodes=2)
+
+    def fresh(seed):
+        np.random.seed(3); torch.manual_seed(3); random.seed(3)
+        return IRL(d=d, pi0=mat, demonstrations=demos, batch=B, num_policies=2, seed=seed, verbose=0)
+
+    a = fresh(4)
+    a.outerloop(num_iterations=3, final_training=False, **kw)
+    b = fresh(4)
+    b.outerloop(num_iterations=1, final_training=False, **kw)
+    torch.save(b.state_dict(), str(tmp_path / 'outer.pt'))
+    np.random.seed(999); torch.manual_seed(999); random.seed(999)
+    torch.rand(5, device=dev)
+    c = IRL(d=d, pi0=mat, demonstrations=demos, batch=B, num_policies=2, seed=77, verbose=0)
+    c.load_state_dict(torch.load(str(tmp_path / 'outer.pt'), weights_only=True))
+    assert len(c.list_eval_gen_transitions) == len(b.list_eval_gen_transitions) > 0      # rebuilt on load
+    c.outerloop(num_iterations=3, first_iteration=1, final_training=False, **kw)
+    assert np.array_equal(np.ravel(a.theta), np.ravel(c.theta)) and np.array_equal(a.w, c.w)
+    for pa, pc in zip(a.reward_net.parameters(), c.reward_net.parameters()):
+        assert torch.equal(pa, pc)
+    assert a.reward_update_count == c.reward_update_count
+    assert [float(np.ravel(t)[0]) for t in a.list_policies] == [float(np.ravel(t)[0]) for t in c.list_policies]
+
+
+def test_start_table_setter_keeps_the_draw_range_and_indices_are_clamped(dev):
+    """ADVICE (round 2): assigning `mat_pi0` must move `num_start_samples` with it (mfg_synthetic.train re-reads the table,
+    mfg_synthetic.py:438-440), and a stale index can never read outside the table: the kernels clamp it."""
+    from discrete_mean_field_game_amd import ops
+    d = 21
+    rs = np.random.RandomState(0)
+    ac = AC(d=d, pi0=rs.dirichlet(np.ones(d), size=9), batch=64, seed=1, update_every='rollout', verbose=0)
+    assert ac.num_start_samples == 9
+    ac.mat_pi0 = rs.dirichlet(np.ones(d), size=3)
+    assert ac.num_start_samples == 3
+    np.random.seed(1)
+    ac.train(num_episodes=2)                                   # draws stay inside the 3-row table
+    tab = torch.as_tensor(ac.mat_pi0.astype(np.float32), device=dev)
+    idx = torch.tensor([0, 2, 3, 1000, -5], dtype=torch.int32, device=dev)
+    got = ops.gather_start(tab, idx).cpu().numpy()
+    want = ac.mat_pi0.astype(np.float32)[[0, 2, 2, 2, 0]]
+    assert np.array_equal(got, want)
+
+
 # ---- f2 / f4 pinned to the unmodified reference (tests/golden/host_io_mfg_ac2.npz) ---------------------------------------
 def _eval_setup(z, tmp_path, monkeypatch):
     """Recreate the test files the reference evaluated and make os.listdir return them in the order the reference's
