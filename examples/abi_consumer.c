@@ -88,6 +88,11 @@ int main(int argc, char** argv) {
     MFG_OK_(mfg_apply_update(G, d, 0.1 / (episode + 1), 0.001 / (episode + 1), w, theta, racc, st));
   }
   HIP_OK(hipStreamSynchronize(st));
+  { /* numeric sanitiser of the boundary: a launch that met theta outside the mixed-precision range would have reported it */
+    unsigned status_bits = 1u;
+    MFG_OK_(mfg_status(&status_bits));
+    if (status_bits != 0u) return 3;
+  }
 
   double racc_h = 0.0, count = 0.0;
   HIP_OK(hipMemcpy(&theta_h, theta, sizeof(double), hipMemcpyDeviceToHost));

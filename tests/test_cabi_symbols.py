@@ -63,3 +63,22 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), f
                 assert 'mfg_oracle' not in src, f
+
+
+def test_reward_net_struct_layout_matches_the_header(lib, tmp_path):
+    """mfg_reward_net_t crosses the boundary by pointer: the ctypes mirror (_lib.RewardNetStruct) must have the C
+    compiler's size and field offsets.  A three-line C program prints them from include/mfg_hip.h."""
+    import ctypes as C
+    import subprocess
+    fields = [n for n, _ in lib.RewardNetStruct._fields_]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "mfg_hip.h"\nint main(void){printf("%zu", sizeof(mfg_reward_net_t));\n'
+    for f in fields:
+        src += 'printf(" %%zu", offsetof(mfg_reward_net_t, %s));\n' % f
+    src += 'return 0;}\n'
+    c = tmp_path / 'layout.c'
+    c.write_text(src)
+    exe = str(tmp_path / 'layout')
+    subprocess.run(['gcc', '-std=c99', '-I', os.path.join(ROOT, 'include'), str(c), '-o', exe], check=True)
+    out = [int(x) for x in subprocess.run([exe], check=True, stdout=subprocess.PIPE).stdout.decode().split()]
+    assert out[0] == C.sizeof(lib.RewardNetStruct)
+    assert out[1:] == [getattr(lib.RewardNetStruct, f).offset for f in fields]
