@@ -50,6 +50,9 @@ struct RewardNetArgs {
 #ifndef MFG_RN_BPC
 #define MFG_RN_BPC 2
 #endif
+#ifndef MFG_RN_LDS_MIN
+#define MFG_RN_LDS_MIN 16  // samples per block from which the FC3 weights are staged in LDS
+#endif
 // 8 waves share one LDS copy of the FC3 weights (28 KB at d = 21, n3 = 8): 76 KB per block, 2 blocks per CU.
 constexpr int RN_WAVES = MFG_RN_WAVES, RN_BLOCK = RN_WAVES * WAVE, RN_MAXF2 = 2, RN_MAXN = 32;
 
@@ -576,7 +579,7 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
   // stage the FC3 weights in LDS only when a block amortises the copy over enough samples (and the pointer is
   // 16-byte aligned); otherwise they are read straight from L2 (coalesced, 28 KB at d = 21)
   const int64_t samples_per_block = (B + grid - 1) / grid;
-  a.w3_in_lds = (w3fl * 4 <= 64 * 1024 && samples_per_block >= 16 && (((uintptr_t)fc3_w & 15) == 0)) ? 1 : 0;
+  a.w3_in_lds = (w3fl * 4 <= 64 * 1024 && samples_per_block >= MFG_RN_LDS_MIN && (((uintptr_t)fc3_w & 15) == 0)) ? 1 : 0;
   if (a.w3_in_lds) fl += w3fl;
   fl = (fl + 3) & ~(size_t)3;
   fl += (size_t)RN_WAVES * (W1 * W1 + W2 * W2);
