@@ -837,6 +837,48 @@ inline size_t core_small_lds(int d, bool want_v, bool sample) {
 #ifndef MFG_CORE_LARGE_WAVES
 #define MFG_CORE_LARGE_WAVES(R) (((R) <= 2 || (R) == 4) ? 3 : 2)
 #endif
+// Rows per batch of the mixed-mode sampling loop (transposed row sums): sized so that the stash (KB x 64 R floats per
+// wave) keeps three blocks per CU at R <= 4 and two above.
+__host__ __device__ constexpr int large_row_batch(int R) { return R <= 2 ? 8 : (R <= 4 ? 4 : 2); }
+// dynamic LDS of k_core_large: 4 state vectors per wave, the per-row (A, D, S), the stash
+inline size_t core_large_lds(int d, bool sample, bool fast, bool td) {
+  const int R = (d + WAVE - 1) / WAVE;
+  if (sample && fast) return (size_t)WAVES * ((td ? 7 : 4) * d + large_row_batch(R) * WAVE * R) * 4;  // no (A, D, S) without TD
+  return (size_t)WAVES * 4 * d * 4 + (size_t)WAVES * 3 * d * 8;
+}
+// a lane's R variates of one row to / from its stash slot (R consecutive floats, 4 R bytes aligned)
+template <int R>
+__device__ __forceinline__ void stash_store(float* p, const float* y) {
+  if constexpr (R % 4 == 0) {
+#pragma unroll
+    for (int m = 0; m < R; m += 4) *reinterpret_cast<float4*>(p + m) = make_float4(y[m], y[m + 1], y[m + 2], y[m + 3]);
+  } else if constexpr (R % 2 == 0) {
+#pragma unroll
+    for (int m = 0; m < R; m += 2) *reinterpret_cast<float2*>(p + m) = make_float2(y[m], y[m + 1]);
+  } else {
+#pragma unroll
+    for (int m = 0; m < R; ++m) p[m] = y[m];
+  }
+}
+template <int R>
+__device__ __forceinline__ void stash_load(float* y, const float* p) {
+  if constexpr (R % 4 == 0) {
+#pragma unroll
+    for (int m = 0; m < R; m += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(p + m);
+      y[m] = v.x, y[m + 1] = v.y, y[m + 2] = v.z, y[m + 3] = v.w;
+    }
+  } else if constexpr (R % 2 == 0) {
+#pragma unroll
+    for (int m = 0; m < R; m += 2) {
+      const float2 v = *reinterpret_cast<const float2*>(p + m);
+      y[m] = v.x, y[m + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < R; ++m) y[m] = p[m];
+  }
+}
 // FULL: d == 64 R (every lane owns R live columns, d even): the validity masks of the quads fold away (d = 128, 256, ...).
 template <int R, bool SAMPLE, bool TD, bool FAST, bool FULL>
 __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(CoreArgs a) {
@@ -851,7 +893,11 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
   // per-row (A_i, D_i, S_i) of this wave's trajectory: psi(A_i) D_i and ln(S_i) D_i are evaluated AFTER the row
   // loop, one row per lane, instead of once per row by the whole wave (a fp64 digamma + log per row amortised
   // over only d/64 elements per lane dominated the TD kernels at d = 128)
-  double* rowq = reinterpret_cast<double*>(smem + WAVES * 4 * d) + wv * 3 * d;
+  // (mixed-mode sampling: fp32 -- the sums are fp32 sums there -- followed by the lane-private stash of a row batch's variates)
+  constexpr bool batched = SAMPLE && FAST;
+  using RQ = typename std::conditional<batched, float, double>::type;
+  RQ* rowq = reinterpret_cast<RQ*>(smem + WAVES * 4 * d) + wv * 3 * d;
+  float* ystash = smem + WAVES * (TD ? 7 : 4) * d + wv * (large_row_batch(R) * WAVE * R);
   const bool want_v = TD && a.w != nullptr;
   const double theta = *a.theta;
   const ThetaSplit ts = theta_split(theta, a.shift);
@@ -909,8 +955,9 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
         // rows per iteration: R a multiple of 4 -> a row's elements of this lane fill whole quads; otherwise two rows
         // per iteration and quads {(i, m), (i, m+1), (i+1, m), (i+1, m+1)} (odd R: last column {(i, m), (i+1, m)})
         constexpr int NR = (R % 4 == 0) ? 1 : 2;
-        for (int i = 0; i < d; i += NR) {
-          const bool row1 = NR == 2 && (FULL || i + 1 < d);
+        // sample rows i (and i + 1 when NR == 2): gamma variates y, per-lane partial row sums, score terms
+        auto sample_rows = [&](int i, bool row1, float (&y)[NR][R], TT (&ysum)[2], TT (&asum)[2], TT (&dsum)[2], TT& gsum)
+                               __attribute__((always_inline)) {
           const int i1 = row1 ? i + 1 : i;
           const float pr[2] = {pis[i], pis[i1]};
           const float prs[2] = {sep ? pr[0] + ts.sh : pr[0], sep ? pr[1] + ts.sh : pr[1]};  // the sampler's row operands
@@ -919,8 +966,6 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
             fr[0] = pfs[i];
             fr[1] = pfs[i1];
           }
-          float y[NR][R];
-          TT ysum[2] = {0, 0}, asum[2] = {0, 0}, dsum[2] = {0, 0}, gsum = 0;
           if constexpr (NR == 1) {
 #pragma unroll
             for (int m = 0; m < R; m += 4) {
@@ -1003,35 +1048,109 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
               }
             }
           }
-          if (TD) gacc += (double)gsum;
-          double Sr[2] = {1.0, 1.0}, Ar[2] = {0.0, 0.0}, Dr[2] = {0.0, 0.0};
-          if constexpr (FAST) {
-            if (TD) {
-              float x6[3 * NR];
+        };
+        // one normalised row into the column sums (transition, both reward sums)
+        //   (wp = whether P is written out: decided once per batch, not per element -- a wave-uniform branch around every
+        //   store is a TAKEN branch per element in the common no-output case)
+        auto fold_row = [&](auto wp, int ir, float pi_row, const float* yr, float inv32, double invS) __attribute__((always_inline)) {
+          const double pii = (double)pi_row;
 #pragma unroll
-              for (int rr = 0; rr < NR; ++rr) {
-                x6[3 * rr] = ysum[rr];
-                x6[3 * rr + 1] = asum[rr];
-                x6[3 * rr + 2] = dsum[rr];
-              }
-#ifndef MFG_ABL_ROWSUM
-              wave_sums_f32_dpp<3 * NR>(x6);
-#endif
-#pragma unroll
-              for (int rr = 0; rr < NR; ++rr) {
-                Sr[rr] = (double)x6[3 * rr];
-                Ar[rr] = (double)x6[3 * rr + 1];
-                Dr[rr] = (double)x6[3 * rr + 2];
-              }
-            } else {
-              float x2[NR];
-#pragma unroll
-              for (int rr = 0; rr < NR; ++rr) x2[rr] = ysum[rr];
-              wave_sums_f32_dpp<NR>(x2);
-#pragma unroll
-              for (int rr = 0; rr < NR; ++rr) Sr[rr] = (double)x2[rr];
+          for (int m = 0; m < R; ++m) {
+            if (okc[m]) {
+              const float p32 = FAST ? yr[m] * inv32 : (float)((double)yr[m] * invS);
+              const double p = (double)p32;
+              if constexpr (decltype(wp)::value) Po[(int64_t)ir * d + lane + m * WAVE] = p32;
+              const double u = p * pii;
+              acc[m] += u;
+              s1[m] = fma(u, p, s1[m]);  // both reward sums unconditionally (2 FMAs): a run-time kind test per element
+              s2 = fma(u, u, s2);        // compiles to selects around them (4 v_cndmask per element)
             }
-          } else {
+          }
+        };
+        if constexpr (FAST) {
+          // Mixed mode: rows go in batches of KB.  Phase 1 samples the batch pair by pair -- the variates wait in a lane-private
+          // LDS stash, the per-lane partials of the row sums (S and, TD, A, D) are packed TRANSPOSED (row_pair_merge ...,
+          // mfg_device.h) so that the batch shares its butterfly steps; phase 2 normalises and folds the rows into the column
+          // sums, the reciprocal of a row's sum coming from the lane that owns it through one read-lane.
+          constexpr int KB = large_row_batch(R), NQ = TD ? 3 : 1;
+          float* yst = ystash + (int64_t)lane * R;
+          for (int i0 = 0; i0 < d; i0 += KB) {
+            float x[NQ];
+            float park[NQ];  // NR == 1: the even row of a pair waits here for the odd one
+#pragma unroll 1
+            for (int k = 0; k < KB; k += NR) {  // rolled: the sampling body is large
+              const int i = i0 + k;
+              if (!FULL && i >= d && (NR == 2 || (k & 1) == 0)) break;  // (an odd last row still merges with zeros)
+              float xr[2][NQ] = {};
+              if (FULL || i < d) {
+                const bool row1 = NR == 2 && (FULL || i + 1 < d);
+                float y[NR][R];
+                TT ysum[2] = {0, 0}, asum[2] = {0, 0}, dsum[2] = {0, 0}, gsum = 0;
+                sample_rows(i, row1, y, ysum, asum, dsum, gsum);
+                if (TD) gacc += (double)gsum;
+#pragma unroll
+                for (int rr = 0; rr < NR; ++rr) {
+                  stash_store<R>(yst + (k + rr) * (WAVE * R), y[rr]);
+                  xr[rr][0] = ysum[rr];
+                  if (TD) {
+                    xr[rr][NQ > 1 ? 1 : 0] = asum[rr];
+                    xr[rr][NQ > 2 ? 2 : 0] = dsum[rr];
+                  }
+                }
+              }
+              if (NR == 1 && (k & 1) == 0) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) park[q] = xr[0][q];
+                continue;
+              }
+              float m[NQ];
+              row_pair_merge<NQ>(NR == 2 ? xr[0] : park, NR == 2 ? xr[1] : xr[0], m);
+              if constexpr (KB == 2) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) x[q] = m[q];
+              } else {
+                row_pair_deposit<NQ>(x, m, row_pair_mask<KB>(k >> 1));
+              }
+            }
+            row_batch_finish<NQ>(x);  // lane l: totals of row i0 + row_batch_row<KB>(l)
+            float inv = __builtin_amdgcn_rcpf(x[0]);
+            inv = fmaf(fmaf(-x[0], inv, 1.0f), inv, inv);
+            if (TD) {
+              const int ir = i0 + row_batch_row<KB>(lane);
+              if (row_batch_owner<KB>(lane) && (FULL || ir < d)) {
+                rowq[3 * ir] = x[NQ > 1 ? 1 : 0];
+                rowq[3 * ir + 1] = x[NQ > 2 ? 2 : 0];
+                rowq[3 * ir + 2] = x[0];
+              }
+            }
+            auto fold_batch = [&](auto wp) __attribute__((always_inline)) {
+              float yr[KB][R], pb[KB];  // the whole batch is requested up front: one LDS round trip per batch, not per row
+#pragma unroll
+              for (int k = 0; k < KB; ++k) {
+                const int ir = (FULL || i0 + k < d) ? i0 + k : i0;
+                stash_load<R>(yr[k], yst + k * (WAVE * R));
+                pb[k] = pis[ir];
+              }
+#pragma unroll
+              for (int k = 0; k < KB; ++k) {
+                const int ir = i0 + k;
+                if (!FULL && ir >= d) break;
+                const float inv_k = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv), row_batch_lane(k)));
+                fold_row(wp, ir, pb[k], yr[k], inv_k, 0.0);
+              }
+            };
+            if (Po) fold_batch(std::true_type{});
+            else fold_batch(std::false_type{});
+          }
+        } else {
+          for (int i = 0; i < d; i += NR) {
+            const bool row1 = NR == 2 && (FULL || i + 1 < d);
+            const int i1 = row1 ? i + 1 : i;
+            float y[NR][R];
+            TT ysum[2] = {0, 0}, asum[2] = {0, 0}, dsum[2] = {0, 0}, gsum = 0;
+            sample_rows(i, row1, y, ysum, asum, dsum, gsum);
+            if (TD) gacc += (double)gsum;
+            double Sr[2] = {1.0, 1.0}, Ar[2] = {0.0, 0.0}, Dr[2] = {0.0, 0.0};
 #pragma unroll
             for (int rr = 0; rr < NR; ++rr) {
               Sr[rr] = ysum[rr];
@@ -1043,38 +1162,23 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
                 Sr[rr] = wave_sum_dpp(Sr[rr]);
               }
             }
-          }
-          if (NR == 2 && !row1) Sr[1] = 1.0;
-          if (TD && lane == 0) {
-            rowq[3 * i] = Ar[0];
-            rowq[3 * i + 1] = Dr[0];
-            rowq[3 * i + 2] = Sr[0];
-            if (row1) {
-              rowq[3 * i1] = Ar[1];
-              rowq[3 * i1 + 1] = Dr[1];
-              rowq[3 * i1 + 2] = Sr[1];
-            }
-          }
-#pragma unroll
-          for (int rr = 0; rr < NR; ++rr) {
-            if (rr == 1 && !row1) break;
-            const int ir = rr ? i1 : i;
-            const double pii = (double)pr[rr];
-            float inv32 = 0.0f;
-            double invS = 0.0;
-            if (FAST) inv32 = fast_rcp_f32_of_f64(Sr[rr]);
-            else invS = 1.0 / Sr[rr];
-#pragma unroll
-            for (int m = 0; m < R; ++m) {
-              if (okc[m]) {
-                const float p32 = FAST ? y[rr][m] * inv32 : (float)((double)y[rr][m] * invS);
-                const double p = (double)p32;
-                if (Po) Po[(int64_t)ir * d + lane + m * WAVE] = p32;
-                const double u = p * pii;
-                acc[m] += u;
-                s1[m] = fma(u, p, s1[m]);  // both reward sums unconditionally (2 FMAs): a run-time kind test per element
-                s2 = fma(u, u, s2);        // compiles to selects around them (4 v_cndmask per element)
+            if (NR == 2 && !row1) Sr[1] = 1.0;
+            if (TD && lane == 0) {
+              rowq[3 * i] = Ar[0];
+              rowq[3 * i + 1] = Dr[0];
+              rowq[3 * i + 2] = Sr[0];
+              if (row1) {
+                rowq[3 * i1] = Ar[1];
+                rowq[3 * i1 + 1] = Dr[1];
+                rowq[3 * i1 + 2] = Sr[1];
               }
+            }
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+              if (rr == 1 && !row1) break;
+              const int ir = rr ? i1 : i;
+              if (Po) fold_row(std::true_type{}, ir, pis[ir], y[rr], 0.0f, 1.0 / Sr[rr]);
+              else fold_row(std::false_type{}, ir, pis[ir], y[rr], 0.0f, 1.0 / Sr[rr]);
             }
           }
         }
@@ -1146,10 +1250,10 @@ __global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(C
 #else
         for (int rw = lane; rw < d; rw += WAVE) {
 #endif
-          const double Dr = rowq[3 * rw + 1];
+          const double Dr = (double)rowq[3 * rw + 1];
           if (SAMPLE && FAST) {
-            guni = fma(digamma_pos_mixed(rowq[3 * rw]), Dr, guni);
-            guni -= fast_log_f64(rowq[3 * rw + 2]) * Dr;
+            guni = fma(digamma_pos_mixed((double)rowq[3 * rw]), Dr, guni);
+            guni -= fast_log_f64((double)rowq[3 * rw + 2]) * Dr;
           } else {
             guni = fma(digamma_pos(rowq[3 * rw]), Dr, guni);
             if (SAMPLE) guni -= log(rowq[3 * rw + 2]) * Dr;
@@ -1205,7 +1309,7 @@ template <bool FAST>
 inline int launch_core_large_impl(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st) {
   const int d = a.d;
   const int R = (d + WAVE - 1) / WAVE;
-  const size_t lds = (size_t)WAVES * 4 * d * 4 + (size_t)WAVES * 3 * d * 8;
+  const size_t lds = core_large_lds(d, sample, FAST, td);
   const int grid = core_grid(a.B, WAVES, 8 * MFG_CORE_OVERSUBSCRIBE, num_cus);
 #define MFG_CORE_LARGE_GO(RR, SS, TT, FF) \
   hipLaunchKernelGGL((k_core_large<RR, SS, TT, FAST, FF>), dim3(grid), dim3(BLOCK), lds, st, a)

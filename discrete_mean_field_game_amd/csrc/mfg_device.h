@@ -541,6 +541,69 @@ __device__ __forceinline__ void wave_sums_f32_dpp(float* x) {
   for (int q = 0; q < NS; ++q) x[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[q]), 63));
 }
 
+// ---------------------------------------------------------------------------
+// Transposed row sums (round 3; mixed mode of the wave-per-trajectory kernels).  The 64 lanes of a wave each hold a
+// partial sum of KB different matrix rows (KB = 2, 4, 8; rows arrive in pairs).  Reducing every row on its own costs
+// 6 DPP adds + a read-lane per sum; here the rows of a batch end up PACKED in one register and share the last steps:
+//   * pair merge on lane bit 3 (row_pair_merge): lanes with the bit clear take a + ror8(a), the others b + ror8(b) -- the
+//     second add is bank-masked, so two rows cost two instructions and leave one register;
+//   * two plain butterfly steps (lane bits 2 and 0), then ONE select deposits the pair into the lanes whose bits (2, 0)
+//     spell the pair's index in the batch (row_pair_deposit, mask in an SGPR pair);
+//   * once per batch (row_batch_finish): lane bit 1, and bits 4 / 5 through v_permlane16_swap / v_permlane32_swap (gfx950).
+// Afterwards lane l holds the total of the batch's row  bit3(l) + 2 bit0(l) + 4 bit2(l)  (masked to KB - 1).
+// 5 instructions per sum per row pair + ~9 per batch, against 14 per pair.
+// ---------------------------------------------------------------------------
+template <int NS>
+__device__ __forceinline__ void row_pair_merge(const float* a, const float* b, float* m) {
+#pragma unroll
+  for (int q = 0; q < NS; ++q) m[q] = a[q] + dpp_mov_f32<0x128, 0xF>(a[q]);  // row_ror:8
+#pragma unroll
+  for (int q = 0; q < NS; ++q)  // (the s_nop covers the VALU-write -> DPP-read distance the compiler cannot see into)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(m[q]) : "v"(b[q]));
+#pragma unroll
+  for (int q = 0; q < NS; ++q) m[q] += dpp_mov_f32<0x141, 0xF>(m[q]);  // row_half_mirror: lane bit 2 (and 0 <-> 1 swapped)
+#pragma unroll
+  for (int q = 0; q < NS; ++q) m[q] += dpp_mov_f32<0xB1, 0xF>(m[q]);   // quad_perm [1,0,3,2]: lane bit 0
+}
+// lanes of pair p (of KB / 2): bits (2, 0) of the lane index == p
+template <int KB>
+__device__ __forceinline__ uint64_t row_pair_mask(int p) {
+  if constexpr (KB == 8) return 0x0505050505050505ull << ((p & 1) + ((p >> 1) & 1) * 4);
+  else if constexpr (KB == 4) return 0x5555555555555555ull << (p & 1);
+  else return ~0ull;
+}
+template <int NS>
+__device__ __forceinline__ void row_pair_deposit(float* acc, const float* m, uint64_t mask) {
+#pragma unroll
+  for (int q = 0; q < NS; ++q) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(acc[q]) : "v"(m[q]), "s"(mask));
+}
+template <int NS>
+__device__ __forceinline__ void row_batch_finish(float* x) {
+#pragma unroll
+  for (int q = 0; q < NS; ++q) x[q] += dpp_mov_f32<0x4E, 0xF>(x[q]);  // quad_perm [2,3,0,1]: lane bit 1
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x[q]), __float_as_uint(x[q]), false, false);
+    x[q] = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // lane bit 4
+  }
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x[q]), __float_as_uint(x[q]), false, false);
+    x[q] = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // lane bit 5
+  }
+}
+// in-batch row index k -> the first lane that holds its total after row_batch_finish, and a lane's row
+__device__ __forceinline__ int row_batch_lane(int k) { return ((k & 1) << 3) | ((k >> 1) & 1) | (((k >> 2) & 1) << 2); }
+template <int KB>
+__device__ __forceinline__ int row_batch_row(int lane) {
+  return (((lane >> 3) & 1) | ((lane & 1) << 1) | (((lane >> 2) & 1) << 2)) & (KB - 1);
+}
+// the one lane per row that publishes its totals: replica bits (1, 4, 5) and the index bits the batch does not use clear
+template <int KB>
+__device__ __forceinline__ bool row_batch_owner(int lane) {
+  return (lane & (KB == 8 ? 0x32 : (KB == 4 ? 0x36 : 0x37))) == 0;
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
