@@ -1389,7 +1389,10 @@ __global__ __launch_bounds__(BLOCK) void k_grad_mfma_small(GradArgs a) {
 // row per x, tiles split over grid.y; the linear / scalar sums ride on the y = 0 blocks.  Deterministic.
 // ---------------------------------------------------------------------------------------------
 constexpr int GM_KC = 32;    // samples staged per chunk
-constexpr int GM_TPW = 8;    // max tiles per wave
+#ifndef MFG_GM_TPW
+#define MFG_GM_TPW 8
+#endif
+constexpr int GM_TPW = MFG_GM_TPW;    // max tiles per wave
 
 // NPF > 0 (float4 staging, NPF = d / 32 sixteen-byte loads per thread and chunk): the NEXT chunk's rows and deltas are
 // fetched into registers before this chunk's matrix instructions and committed to LDS after them, so the staging
@@ -1562,6 +1565,215 @@ __global__ __launch_bounds__(BLOCK) void k_grad_mfma(GradArgs a, int tpw) {
       const int c = tid + u * BLOCK;
       if (c < d) out[Q + c] = lin[u];
     }
+    __syncthreads();
+    red[tid] = s_d;
+    red[BLOCK + tid] = s_dg;
+    red[2 * BLOCK + tid] = s_r;
+    red[3 * BLOCK + tid] = s_n;
+    __syncthreads();
+    if (tid < 4) {
+      double t = 0.0;
+      for (int q = 0; q < GM_KC; ++q) t += red[tid * BLOCK + q];  // only threads < KC hold scalar partials
+      out[Q + d + tid] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 3: register-blocked form of k_grad_mfma for d = 128 / 256 (C3, C5).  k_grad_mfma gives a wave an arbitrary run of
+// tiles, fetches BOTH operands of every matrix instruction from LDS and tests `i < nmine` (a scalar branch, i.e. a basic
+// block boundary) in front of each: nothing overlaps, 190-220 cycles per instruction against the ~70 the matrix core needs,
+// whatever the tile count per wave or the number of sample slices (variants measured: no better).  Here a wave owns
+// RECTANGLES of tiles given at compile time as (rows NA, columns NB, tile mask) -- one K step of 4 samples fetches NA + NB
+// operands for up to NA NB instructions, no branch in the K loop, and the fetches of a step issue under the matrix
+// instructions of the step before.  The upper triangle is cut so that EVERY wave has the same number of tiles (the
+// instruction stream of a SIMD is the bound; 64 x 64 "super tiles" s = 0 .. d/64-1 on the diagonal, (r, c) off it):
+//   d = 256, 136 tiles = 8 waves x 17 (grid.y = 2 blocks of 4 waves):
+//     y = 0: (0,1) + one tile of diagonal 1 | (0,2) + one | (0,3) + one | diagonal 0 (10 tiles) + the first two rows of diagonal 1 (7)
+//     y = 1: (1,2) + one tile of diagonal 3 | (1,3) + one | (2,3) + one | diagonal 2 + the first two rows of diagonal 3
+//   d = 128, 36 tiles = 4 waves x 9: half of (0,1) (2 x 4 tiles) + tile (3,3) of a diagonal | ... | diagonal 0 less (3,3) | diagonal 1 less (3,3)
+// Staging, split-K over grid.x, partial rows, side sums and the row reduction are those of k_grad_mfma.
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned GM2_RECT44 = 0xFFFFu, GM2_DIAG44 = 0x8CEFu, GM2_DIAG44M = 0x0CEFu, GM2_TRAP24 = 0xEFu, GM2_RECT24 = 0xFFu,
+                   GM2_ONE = 1u;
+__host__ __device__ constexpr int gm2_count(unsigned m) { return m == 0 ? 0 : (int)(m & 1u) + gm2_count(m >> 1); }
+
+// one rectangle over one staged chunk
+template <int D, int NA, int NB, unsigned MASK>
+__device__ __forceinline__ void gm2_step(const float* __restrict__ abase, const float* __restrict__ bbase, int off, double dk,
+                                         v4d_t* acc) {
+  double av[NA], bv[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) av[i] = dk * (double)abase[off + (i << 4)];  // A[row li][k] = delta_k pi_k[16 (ra + i) + li]
+#pragma unroll
+  for (int j = 0; j < NB; ++j) bv[j] = (double)bbase[off + (j << 4)];       // B[k][col li] = pi_k[16 (cb + j) + li]
+  int t = 0;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if ((MASK >> (i * NB + j)) & 1u) {
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bv[j], acc[t], 0, 0, 0);
+        ++t;
+      }
+    }
+  }
+}
+template <int D, int NA0, int NB0, unsigned M0, int NA1, int NB1, unsigned M1>
+__device__ __forceinline__ void gm2_chunk(const float* __restrict__ sp, const double* __restrict__ dl, int lk, int li,
+                                          const int* ra, const int* cb, v4d_t* acc) {
+  constexpr int pitch = D + 16;
+  const float* lb = sp + lk * pitch + li;
+  const float *a0 = lb + (ra[0] << 4), *b0 = lb + (cb[0] << 4), *a1 = lb + (ra[1] << 4), *b1 = lb + (cb[1] << 4);
+#pragma unroll 2
+  for (int ks = 0; ks < GM_KC / 4; ++ks) {  // (fully unrolled the compiler hoists all 8 steps' operands: 444 spilled registers)
+    const double dk = dl[ks * 4 + lk];
+    gm2_step<D, NA0, NB0, M0>(a0, b0, ks * 4 * pitch, dk, acc);
+    if constexpr (M1 != 0) gm2_step<D, NA1, NB1, M1>(a1, b1, ks * 4 * pitch, dk, acc + gm2_count(M0));
+  }
+}
+template <int D, int NA, int NB, unsigned MASK>
+__device__ __forceinline__ void gm2_store(double* __restrict__ out, int lk, int li, int ra, int cb, const v4d_t* acc) {
+  int t = 0;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if ((MASK >> (i * NB + j)) & 1u) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {  // D[i][j] of a tile: lane holds rows 4 v + lane / 16, column lane % 16
+          const int gi = ((ra + i) << 4) + 4 * v + lk, gj = ((cb + j) << 4) + li;
+          if (gi <= gj) out[feat_idx(gi, gj, D)] = acc[t][v];
+        }
+        ++t;
+      }
+    }
+  }
+}
+
+template <int D>
+struct Gm2Geom {
+  static constexpr int NY = D == 256 ? 2 : 1, ACCN = D == 256 ? 17 : 9;
+};
+template <int NA_, int NB_, unsigned MASK_>
+struct Gm2Rect {
+  static constexpr int NA = NA_, NB = NB_;
+  static constexpr unsigned MASK = MASK_;
+};
+template <int D>
+__global__ __launch_bounds__(BLOCK, 2) void k_grad_mfma2(GradArgs a) {
+  static_assert(D == 128 || D == 256, "tile maps exist for d = 128 and 256");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int d = D, pitch = D + 16;
+  constexpr int Q = d * (d + 1) / 2, F = Q + d + 1, FO = F + 3;
+  constexpr int ACCN = Gm2Geom<D>::ACCN;
+  double* dl = reinterpret_cast<double*>(smem_raw);       // [KC] delta
+  double* red = dl + GM_KC;                               // [4][BLOCK] scalar reduction scratch
+  float* sp = reinterpret_cast<float*>(red + 4 * BLOCK);  // [KC][pitch] pi rows
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE), y = (int)blockIdx.y;
+  // this wave's two rectangles (tile coordinates of their corners); the last wave of a block owns the diagonal pieces
+  const bool diag = D == 256 ? wv == 3 : wv >= 2;
+  int ra[2] = {0, 0}, cb[2] = {0, 0};
+  if (D == 256) {
+    const int sd = 2 * y;  // this block's diagonal super tiles: sd (whole), sd + 1 (split)
+    if (diag) {
+      ra[0] = cb[0] = 4 * sd;
+      ra[1] = cb[1] = 4 * sd + 4;
+    } else {
+      const int sr = y == 0 ? 0 : (wv == 2 ? 2 : 1), sc = y == 0 ? wv + 1 : (wv == 0 ? 2 : 3);
+      ra[0] = 4 * sr;
+      cb[0] = 4 * sc;
+      ra[1] = 4 * sd + 4 + (wv == 2 ? 3 : 2);  // tiles (2,2) (2,3) (3,3) of super tile sd + 1
+      cb[1] = 4 * sd + 4 + (wv == 0 ? 2 : 3);
+    }
+  } else {
+    if (diag) ra[0] = cb[0] = 4 * (wv - 2);
+    else {
+      ra[0] = 2 * wv;
+      cb[0] = 4;
+      ra[1] = cb[1] = 4 * wv + 3;  // tile (3,3) of diagonal super tile wv
+    }
+  }
+  const bool side = blockIdx.y == 0;  // also owns the linear and scalar sums
+  double lin = 0.0, s_d = 0.0, s_dg = 0.0, s_r = 0.0, s_n = 0.0;  // (d <= BLOCK: one linear column per thread)
+  const int li = lane & 15, lk = lane >> 4;
+  const double invT = 1.0 / (double)a.T;
+  // register prefetch of a chunk: thread -> (row q0 + rpp u, float4 column c4)
+  constexpr int dq = d >> 2, rpp = BLOCK / dq, NPF = GM_KC / rpp;
+  static_assert(BLOCK % dq == 0 && GM_KC % rpp == 0, "whole rows per staging pass");
+  const int q0 = tid / dq, c4 = tid - q0 * dq;
+  double* out = a.partial + (int64_t)blockIdx.x * FO;
+  // The whole sample loop is instantiated once per ROLE and the role is chosen outside it: with the role test inside the
+  // loop the two instantiations' accumulators are merged at every iteration (two full sets live: 254 spilled registers
+  // at d = 256).  Both instantiations execute the same barriers.
+  auto run = [&](auto r0, auto r1) __attribute__((always_inline)) {
+    using R0 = decltype(r0);
+    using R1 = decltype(r1);
+    v4d_t acc[ACCN];
+#pragma unroll
+    for (int i = 0; i < ACCN; ++i) acc[i] = (v4d_t)(0.0);
+    float4 pf[NPF];
+    double pf_de = 0.0, pf_dg = 0.0, pf_rr = 0.0;
+    bool pf_on = false;
+    auto fetch = [&](int64_t n0_) __attribute__((always_inline)) {
+      const int cn_ = (int)((a.N - n0_) < GM_KC ? (a.N - n0_) : GM_KC);
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) {
+        const int q = q0 + u * rpp;
+        pf[u] = make_float4(0.f, 0.f, 0.f, 0.f);  // rows past the end are zero: they add nothing
+        if (q < cn_) {
+          const int64_t n = n0_ + q;
+          const int64_t b = (int64_t)(((double)n + 0.5) * invT);
+          pf[u] = *reinterpret_cast<const float4*>(a.pi + b * a.stride_b + (n - b * a.T) * d + 4 * c4);
+        }
+      }
+      pf_de = 0.0, pf_dg = 0.0, pf_rr = 0.0, pf_on = false;
+      if (tid < cn_) {
+        const int64_t n = n0_ + tid;
+        pf_de = a.delta[n];
+        pf_rr = a.reward ? (double)a.reward[n] : 0.0;
+        if (a.g) pf_dg = a.g[n];
+        pf_on = true;
+      }
+    };
+    if ((int64_t)blockIdx.x * GM_KC < a.N) fetch((int64_t)blockIdx.x * GM_KC);
+    for (int64_t n0 = (int64_t)blockIdx.x * GM_KC; n0 < a.N; n0 += (int64_t)gridDim.x * GM_KC) {
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < NPF; ++u) *reinterpret_cast<float4*>(sp + (q0 + u * rpp) * pitch + 4 * c4) = pf[u];
+      if (tid < GM_KC) {
+        if (side && pf_on) {
+          s_d += pf_de;
+          if (a.g) s_dg = fma(pf_de, pf_dg, s_dg);
+          s_r += pf_rr;
+          s_n += 1.0;
+        }
+        dl[tid] = pf_de;
+      }
+      __syncthreads();
+      const int64_t nn = n0 + (int64_t)gridDim.x * GM_KC;
+      if (nn < a.N) fetch(nn);
+      gm2_chunk<D, R0::NA, R0::NB, R0::MASK, R1::NA, R1::NB, R1::MASK>(sp, dl, lk, li, ra, cb, acc);
+      if (side && tid < d) {
+        double t = lin;
+#pragma unroll 8
+        for (int q = 0; q < GM_KC; ++q) t = fma(dl[q], (double)sp[q * pitch + tid], t);
+        lin = t;
+      }
+    }
+    gm2_store<D, R0::NA, R0::NB, R0::MASK>(out, lk, li, ra[0], cb[0], acc);
+    if constexpr (R1::MASK != 0) gm2_store<D, R1::NA, R1::NB, R1::MASK>(out, lk, li, ra[1], cb[1], acc + gm2_count(R0::MASK));
+  };
+  if (D == 256) {
+    if (diag) run(Gm2Rect<4, 4, GM2_DIAG44>{}, Gm2Rect<2, 4, GM2_TRAP24>{});
+    else run(Gm2Rect<4, 4, GM2_RECT44>{}, Gm2Rect<1, 1, GM2_ONE>{});
+  } else {
+    if (diag) run(Gm2Rect<4, 4, GM2_DIAG44M>{}, Gm2Rect<1, 1, 0u>{});
+    else run(Gm2Rect<2, 4, GM2_RECT24>{}, Gm2Rect<1, 1, GM2_ONE>{});
+  }
+  if (side) {
+    if (tid < d) out[Q + tid] = lin;
     __syncthreads();
     red[tid] = s_d;
     red[BLOCK + tid] = s_dg;
@@ -1799,7 +2011,10 @@ static void grad_geometry(int64_t N, int d, int* chunk, int64_t* nsb, int* nob) 
   if (ch < 8) ch = 8;
   *chunk = ch;
   int64_t sb = (N + ch - 1) / ch;
-  int64_t cap = (int64_t)(32ll << 20) / (FO * 8);
+#ifndef MFG_GRAD_WS_MB
+#define MFG_GRAD_WS_MB 72  // partial rows of the batch sums: 256 rows at d = 256 (one per CU; 32 MB until round 3)
+#endif
+  int64_t cap = (int64_t)((long long)MFG_GRAD_WS_MB << 20) / (FO * 8);
   if (cap > 1024) cap = 1024;
   if (cap < 16) cap = 16;
   if (sb > cap) sb = cap;
@@ -1892,6 +2107,16 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
     a.chunk = (BLOCK % (d / 4) == 0 && (((uintptr_t)pi & 15) == 0) && (stride_b % 4 == 0)) ? 1 : 0;  // float4 staging
     const size_t lds_m = (size_t)GM_KC * 8 + (size_t)4 * BLOCK * 8 + (size_t)GM_KC * (d + 16) * 4;
     const int npf = a.chunk ? d / 32 : 0;
+#ifndef MFG_GRAD_MFMA_OLD
+    if (a.chunk && (d == 128 || d == 256)) {
+      // two resident blocks per CU (two waves per SIMD: the second hides the first one's staging and barriers)
+      const int64_t want = (int64_t)num_cus() * 2 / (d == 256 ? Gm2Geom<256>::NY : Gm2Geom<128>::NY);
+      if (nsb > want) nsb = want;
+      a.nsb = nsb;
+      if (d == 256) hipLaunchKernelGGL((k_grad_mfma2<256>), dim3((unsigned)nsb, (unsigned)Gm2Geom<256>::NY), dim3(BLOCK), lds_m, st, a);
+      else hipLaunchKernelGGL((k_grad_mfma2<128>), dim3((unsigned)nsb, (unsigned)Gm2Geom<128>::NY), dim3(BLOCK), lds_m, st, a);
+    } else
+#endif
     switch (npf) {
       case 2: hipLaunchKernelGGL((k_grad_mfma<2>), dim3((unsigned)nsb, (unsigned)ny), dim3(BLOCK), lds_m, st, a, tpw); break;
       case 4: hipLaunchKernelGGL((k_grad_mfma<4>), dim3((unsigned)nsb, (unsigned)ny), dim3(BLOCK), lds_m, st, a, tpw); break;
