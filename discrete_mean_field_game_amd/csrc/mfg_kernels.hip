@@ -1887,6 +1887,142 @@ __global__ __launch_bounds__(BLOCK) void k_value_mfma(const float* __restrict__ 
 #undef MFG_VM_COMMIT
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 3: GEMM-tiled form of k_value_mfma for d a multiple of 64 (C3, C5).  k_value_mfma keeps the FULL rows of a wave's
+// 16 states in LDS (66 KB per block at d = 256: one block per CU, one wave per SIMD), one accumulator tile per wave (every
+// matrix instruction waits for the one before) and a block barrier every 16 instructions: 226 cycles per instruction
+// against ~70.  Here a block owns 128 states and walks the upper triangle of U in 64 x 64 pieces (column block cb, row
+// chunk kc <= cb): a piece of U (fp64, zero below the diagonal) and the matching 128 x 64 slab of states (fp32) are staged
+// -- fetched into registers under the previous piece's matrix instructions, committed behind them -- and a wave runs
+// 2 state groups x 4 column tiles = 8 independent accumulators over the 16 K steps of the piece: 2 + 4 operand reads
+// for 8 matrix instructions, 128 instructions between barriers, two blocks per CU.  After a column block's last piece the
+// finished tiles Y = X U are folded into  v_n += sum_c (Y_nc + b_c) x_nc  (x: 32 LDS reads per lane per 64
+// columns, read back from the slab of the diagonal piece).  The all-zero tiles of a diagonal piece are skipped.
+// ---------------------------------------------------------------------------------------------
+constexpr int VM2_MB = 128, VM2_KC = 64, VM2_XP = VM2_KC + 2;  // states per block, rows per piece, pitch of the state slab
+                                                               // (2 mod 32: the 32 lanes of a half wave hit 32 banks)
+__global__ __launch_bounds__(BLOCK, 2) void k_value_mfma2(const float* __restrict__ pi, int64_t stride_b, int64_t N, int TP1, int d,
+                                                           const double* __restrict__ w, double* __restrict__ V) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* Us = reinterpret_cast<double*>(smem_raw);                   // [KC][64]
+  float* Xs = reinterpret_cast<float*>(Us + VM2_KC * 64);             // [MB][XP]
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE);
+  const int li = lane & 15, lk = lane >> 4;
+  const int ncb = d >> 6, Q = d * (d + 1) / 2;
+  const double invT = 1.0 / (double)TP1;
+  const int64_t npass = (N + VM2_MB - 1) / VM2_MB;
+  // staging roles.  U piece: thread -> row ur = tid / 4, sixteen columns from uc = 16 (tid % 4) (the row of U is contiguous in
+  // the packed weight vector); state slab: thread -> state xr + 16 u (u < 8), float4 column xc.
+  const int ur = tid >> 2, uc = (tid & 3) << 4;
+  const int xr = tid >> 4, xc = (tid & 15) << 2;
+  double ustg[16];
+  float4 xstg[8];
+  for (int64_t pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+    const int64_t n0 = pass * VM2_MB;
+    // row pointers of this thread's staged states (clamped; rows past N are never written out)
+    const float* xrow[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int64_t n = n0 + xr + 16 * u;
+      if (n >= N) n = N - 1;
+      const int64_t b = (int64_t)(((double)n + 0.5) * invT);
+      xrow[u] = pi + b * stride_b + (n - b * TP1) * (int64_t)d;
+    }
+    auto fetch = [&](int cbk, int kc) __attribute__((always_inline)) {
+      const int k = VM2_KC * kc + ur, c0 = 64 * cbk + uc;
+      const double* wr = w + ((int64_t)k * d - ((int64_t)k * (k - 1)) / 2 - k);  // U[k][c] = wr[c] for c >= k
+#pragma unroll
+      for (int q = 0; q < 16; ++q) ustg[q] = (c0 + q >= k) ? wr[c0 + q] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xstg[u] = *reinterpret_cast<const float4*>(xrow[u] + VM2_KC * kc + xc);
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < 16; q += 2) *reinterpret_cast<double2*>(Us + ur * 64 + uc + q) = make_double2(ustg[q], ustg[q + 1]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float* dst = Xs + (xr + 16 * u) * VM2_XP + xc;  // (pitch 66: 8-byte aligned only)
+        *reinterpret_cast<float2*>(dst) = make_float2(xstg[u].x, xstg[u].y);
+        *reinterpret_cast<float2*>(dst + 2) = make_float2(xstg[u].z, xstg[u].w);
+      }
+    };
+    double vs[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    fetch(0, 0);
+    for (int cbk = 0; cbk < ncb; ++cbk) {
+      v4d_t acc[2][4];
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+        for (int cg = 0; cg < 4; ++cg) acc[sg][cg] = (v4d_t)(0.0);
+      for (int kc = 0; kc <= cbk; ++kc) {
+        __syncthreads();  // the previous piece's matrix instructions are done with Us / Xs
+        commit();
+        __syncthreads();
+        // the next piece of the sweep (its loads land under this piece's matrix instructions)
+        const bool last_kc = kc == cbk;
+        if (!last_kc || cbk + 1 < ncb) fetch(last_kc ? cbk + 1 : cbk, last_kc ? 0 : kc + 1);
+        const float* xa = Xs + (wv * 32 + li) * VM2_XP + lk;
+        const double* ub = Us + lk * 64 + li;
+        if (!last_kc) {
+#pragma unroll 2
+          for (int ks = 0; ks < VM2_KC / 4; ++ks) {
+            const double a0 = (double)xa[4 * ks], a1 = (double)xa[16 * VM2_XP + 4 * ks];  // A[state li][k]
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) {
+              const double bv = ub[4 * ks * 64 + 16 * cg];  // B[k][col li]
+              acc[0][cg] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0][cg], 0, 0, 0);
+              acc[1][cg] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1][cg], 0, 0, 0);
+            }
+          }
+        } else {
+          // the piece on the diagonal: rows 16 p .. 16 p + 15 of it are zero left of column tile p -- skip those tiles
+#pragma unroll
+          for (int pq = 0; pq < 4; ++pq) {
+#pragma unroll 2
+            for (int ks = 4 * pq; ks < 4 * pq + 4; ++ks) {
+              const double a0 = (double)xa[4 * ks], a1 = (double)xa[16 * VM2_XP + 4 * ks];
+#pragma unroll
+              for (int cg = pq; cg < 4; ++cg) {
+                const double bv = ub[4 * ks * 64 + 16 * cg];
+                acc[0][cg] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0][cg], 0, 0, 0);
+                acc[1][cg] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1][cg], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+      // fold the finished 32 x 64 block of Y: D[i = 4 v + lk][j = li] of tile (sg, cg).  The state slab of the diagonal
+      // piece (still in LDS: the next commit waits behind the barrier) holds exactly the columns of this block.
+#pragma unroll
+      for (int cg = 0; cg < 4; ++cg) {
+        const double bc = w[Q + 64 * cbk + 16 * cg + li];
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const double x = (double)Xs[(wv * 32 + sg * 16 + 4 * v + lk) * VM2_XP + 16 * cg + li];
+            vs[sg][v] = fma(acc[sg][cg][v] + bc, x, vs[sg][v]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int sg = 0; sg < 2; ++sg) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        double t = vs[sg][v];
+        t += dpp_mov_f64<0xB1, 0xF>(t);
+        t += dpp_mov_f64<0x4E, 0xF>(t);
+        t += dpp_mov_f64<0x141, 0xF>(t);
+        t += dpp_mov_f64<0x140, 0xF>(t);
+        const int64_t n = n0 + wv * 32 + sg * 16 + 4 * v + lk;
+        if (li == 0 && n < N) V[n] = t + w[Q + d];
+      }
+    }
+  }
+}
+
 // delta[b, s] = r[b, s] + gd(s) V[b, s+1] - V[b, s],  gd = gamma (mfg_ac2.py:505) or the running gamma^s (ac_irl.py:691);
 // reward == NULL: the IRL form without the reward (added by the gradient kernel once the network has run).
 __global__ void k_td_delta(const double* __restrict__ V, const float* __restrict__ reward, int64_t B, int T, double gamma,
@@ -2110,7 +2246,10 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
 #ifndef MFG_GRAD_MFMA_OLD
     if (a.chunk && (d == 128 || d == 256)) {
       // two resident blocks per CU (two waves per SIMD: the second hides the first one's staging and barriers)
-      const int64_t want = (int64_t)num_cus() * 2 / (d == 256 ? Gm2Geom<256>::NY : Gm2Geom<128>::NY);
+#ifndef MFG_GM2_BPC128
+#define MFG_GM2_BPC128 3  // 166 registers: three blocks per CU fit (measured 253 -> 236 us at C3)
+#endif
+      const int64_t want = d == 256 ? (int64_t)num_cus() * 2 / Gm2Geom<256>::NY : (int64_t)num_cus() * MFG_GM2_BPC128 / Gm2Geom<128>::NY;
       if (nsb > want) nsb = want;
       a.nsb = nsb;
       if (d == 256) hipLaunchKernelGGL((k_grad_mfma2<256>), dim3((unsigned)nsb, (unsigned)Gm2Geom<256>::NY), dim3(BLOCK), lds_m, st, a);
@@ -2708,6 +2847,14 @@ static int launch_values_and_delta(const float* pi_traj, int64_t B, int T, int d
   int64_t blocks = (groups + WAVES - 1) / WAVES;
   const int64_t cap = (int64_t)num_cus() * 8;
   if (blocks > cap) blocks = cap;
+#ifndef MFG_VALUE_MFMA_OLD
+  if (d % 64 == 0) {
+    const size_t lds2 = (size_t)VM2_KC * 64 * 8 + (size_t)VM2_MB * VM2_XP * 4;
+    int64_t blocks2 = (NV + VM2_MB - 1) / VM2_MB;
+    if (blocks2 > (int64_t)num_cus() * 2) blocks2 = (int64_t)num_cus() * 2;
+    hipLaunchKernelGGL(k_value_mfma2, dim3((unsigned)blocks2), dim3(BLOCK), lds2, st, pi_traj, (int64_t)(T + 1) * d, NV, T + 1, d, w, V);
+  } else
+#endif
   hipLaunchKernelGGL(k_value_mfma, dim3((unsigned)blocks), dim3(BLOCK), lds, st, pi_traj, (int64_t)(T + 1) * d, NV, T + 1, d, w, V);
   hipLaunchKernelGGL(k_td_delta, dim3(grid_for(N, 256, 8)), dim3(256), 0, st, (const double*)V, reward, B, T, gamma, discount_pow,
                      delta);

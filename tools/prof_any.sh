@@ -7,5 +7,5 @@ f=$(find /tmp/pa -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
 for r in list(csv.DictReader(open(sys.argv[1])))[:12]:
-    print('%-72s calls %5s avg %9.1f us  %5s%%' % (r['Name'][:72], r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage'][:5]))
+    print('%-72s calls %5s avg %9.1f us  min %9.1f  max %9.1f  %5s%%' % (r['Name'][:72], r['Calls'], float(r['AverageNs']) / 1e3, float(r['MinNs']) / 1e3, float(r['MaxNs']) / 1e3, r['Percentage'][:5]))
 PY
