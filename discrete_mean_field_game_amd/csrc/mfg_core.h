@@ -235,7 +235,7 @@ __device__ __forceinline__ void sample_elems_g(const CoreArgs& a, double theta, 
         cold = cold || (valid[e] && (!sure[u] || pe[u].gs.small));
       }
     }
-    if (__builtin_amdgcn_ballot_w64(cold) != 0) {  // wave-uniform, ~1 % of the pairs at the reference policies
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(cold) != 0, 0)) {  // wave-uniform, ~1 % of the pairs at the reference policies
 #pragma unroll
       for (int u = 0; u < PW; ++u) {
         const int e = PW * h + u;
