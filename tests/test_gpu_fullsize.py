@@ -317,9 +317,11 @@ def test_config_C4_irl_train_with_reward_net_in_the_loop(dev, mode, precision, t
     assert np.max(np.abs(ac.w[:, 0] - w)) < tol
 
 
-@pytest.mark.parametrize('d,B,T', [(80, 7, 3), (128, 5, 6), (144, 33, 2), (256, 3, 5), (512, 2, 2)])
+@pytest.mark.parametrize('d,B,T', [(80, 7, 3), (128, 5, 6), (144, 33, 2), (256, 3, 5), (512, 2, 2), (128, 700, 2), (192, 301, 1),
+                                   (256, 131, 3)])
 def test_matrix_core_values_equal_in_kernel_values(dev, d, B, T):
-    """Large-d TD rollouts evaluate V of all B (T+1) states on the fp64 matrix cores after the rollout (k_value_mfma) when
+    """Large-d TD rollouts evaluate V of all B (T+1) states on the fp64 matrix cores after the rollout (k_value_mfma;
+    k_value_mfma2 when d is a multiple of 64: 128 states per block -- the larger cases span several passes per block) when
     a workspace is passed; without one (the IRL form, reward_kind EXTERNAL) the rollout kernel evaluates the same values
     itself.  Both must give the same TD errors (re-associated fp64 sums: 1e-12), for both discount forms and ragged
     state counts (B (T+1) not a multiple of the 16-state tile), and match the oracle."""

@@ -627,12 +627,14 @@ def test_sampler_marginals_are_beta_distributed(dev, d, scale, theta):
 
 
 @pytest.mark.parametrize('d,B,T', [(64, 37, 3), (80, 21, 2), (96, 50, 1), (128, 333, 2), (144, 9, 1), (256, 70, 2), (512, 5, 1),
+                                   (128, 9001, 3), (256, 4403, 2), (128, 1, 1), (256, 1, 1),
                                    (21, 1000, 4), (15, 77, 3), (47, 40, 2), (3, 50, 4), (4, 1, 1), (21, 1, 1), (21, 3, 1),
                                    (28, 33, 2), (29, 10, 2), (17, 129, 5), (21, 20000, 15), (21, 4096, 1), (15, 8192, 15)])
 @pytest.mark.parametrize('add_reward', [False, True])
 def test_grad_accumulate_all_kernels(dev, d, B, T, add_reward):
     """The batch sums on their own (a6/a8) for every gradient kernel: fp64-MFMA tiles (d multiple of 16, >= 64; d = 80
-    and 144 take its scalar staging path), the augmented-vector fp64-MFMA kernel of d <= 28 (round 3; compile-time
+    and 144 take its scalar staging path; d = 128 / 256 the register-blocked k_grad_mfma2 -- the 27 003- and 8 806-sample
+    cases give its blocks several chunks each, the one-sample cases a single ragged one), the augmented-vector fp64-MFMA kernel of d <= 28 (round 3; compile-time
     d = 21 / 15 and run-time d; one to 1 024 partial rows, in-kernel and separate finalisation), the generic one (d = 29,
     47); trajectory-major layout with stride (T+1) d, ragged sample counts, optional delta += reward."""
     o_ = ops()
