@@ -350,7 +350,8 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
   float* pal = pin + TB * 2 * d;
   float* pex = pal + TB * d;       // SAMPLE, mixed: E_j = e^{theta pi_j} (separable exponential, mfg_device.h)
   double* scal = reinterpret_cast<double*>(pex + TB * d + ((TB * d) & 1));  // SUMS: (delta, g, r) per trajectory of the tile
-  float* pst = reinterpret_cast<float*>(scal + TB * 3);  // [TB][pnw]: the rollout's START state (doubled for CIRC): its value is
+  double* tot = scal + TB * 3;                           // [TB][8]: even / odd partial sums of the per-trajectory sums
+  float* pst = reinterpret_cast<float*>(tot + TB * 8);   // [TB][pnw]: the rollout's START state (doubled for CIRC): its value is
                                                          // evaluated inside step 0, next to V of the next state
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
   const int t = lane / d, i = lane - t * d;
@@ -676,6 +677,30 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
         if (SAMPLE && s == 0 && valid) redq[3 * d + i] = value_term(pst + tlc * pnw, pi_i);  // (pi_i: still the start state)
       }
       tile_sync();
+      // d >= 8: EIGHT lanes of the trajectory share the work -- lane 2 q + p adds the terms of parity p of quantity q (0 reward,
+      // 1 V(next), 2 score, 3 V(start), the last at step 0 only) and parks its partial in `tot`; lanes 0 / gl then combine
+      // (even + odd), exactly the association of the serial form below: bit-identical results, but the wave issues 11
+      // dependent fp64 adds per step instead of 63-84 (the serial sums were 6 of the kernel's 92 instructions per element).
+      const bool par = d >= 8;
+      double* totq = tot + tlc * 8;
+      if (par) {
+        if (valid && i < 8) {
+          const int q = i >> 1, pp = i & 1;
+          const bool need = q == 0 ? !ext : (q == 1 ? want_v : (q == 2 ? (TD && a.g != nullptr) : (SAMPLE && want_v && s == 0)));
+          double x = 0.0;
+          if (need) {
+            const double* src = redq + (q == 0 ? 0 : (q == 1 ? 2 * d : (q == 2 ? d : 3 * d)));
+#pragma unroll  // (fully unrolled: all loads in flight; unroll 4 / 2 / 1 measured +1 % / +5 % / +4.5 % on the whole rollout)
+            for (int k = 0; k < (d + 1) / 2; ++k) {
+              const int kk = 2 * k + pp;
+              const double v = src[kk < d ? kk : 0];
+              x += kk < d ? v : 0.0;
+            }
+          }
+          totq[i] = x;
+        }
+        tile_sync();
+      }
       const int gl = d > 1 ? 1 : 0;  // lane of the trajectory that sums the score
 #ifdef MFG_ABL_TSUM
       if (false) {
@@ -685,6 +710,9 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
         double r0 = 0.0, r1 = 0.0, v0 = 0.0, v1 = 0.0;
         if (ext) {
           r0 = a.reward_in ? (double)a.reward_in[b * T + s] : 0.0;
+        } else if (par) {
+          r0 = totq[0];
+          r1 = totq[1];
         } else {
           int k = 0;
 #pragma unroll
@@ -698,23 +726,33 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
         if (a.reward_kind == MFG_REWARD_SYNTHETIC) r *= -0.5;
         if (a.reward_out) a.reward_out[b * T + s] = (float)r;
         if (want_v) {
-          int k = 0;
+          if (par) {
+            v0 = totq[2];
+            v1 = totq[3];
+          } else {
+            int k = 0;
 #pragma unroll
-          for (; k + 1 < d; k += 2) {
-            v0 += redq[2 * d + k];
-            v1 += redq[2 * d + k + 1];
+            for (; k + 1 < d; k += 2) {
+              v0 += redq[2 * d + k];
+              v1 += redq[2 * d + k + 1];
+            }
+            if (k < d) v0 += redq[2 * d + k];
           }
-          if (k < d) v0 += redq[2 * d + k];
           const double v_next = (v0 + v1) + wl[Q + d];
           if (SAMPLE && s == 0) {  // V of the start state: the same even / odd sums as for every other state
             double u0 = 0.0, u1 = 0.0;
-            int kk = 0;
+            if (par) {
+              u0 = totq[6];
+              u1 = totq[7];
+            } else {
+              int kk = 0;
 #pragma unroll
-            for (; kk + 1 < d; kk += 2) {
-              u0 += redq[3 * d + kk];
-              u1 += redq[3 * d + kk + 1];
+              for (; kk + 1 < d; kk += 2) {
+                u0 += redq[3 * d + kk];
+                u1 += redq[3 * d + kk + 1];
+              }
+              if (kk < d) u0 += redq[3 * d + kk];
             }
-            if (kk < d) u0 += redq[3 * d + kk];
             v_cur = (u0 + u1) + wl[Q + d];
           }
           const double gd = a.discount_pow ? discount : a.gamma;
@@ -734,13 +772,18 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
       if (TD && valid && i == gl && a.g) {
 #endif
         double g0 = 0.0, g1 = 0.0;
-        int k = 0;
+        if (par) {
+          g0 = totq[4];
+          g1 = totq[5];
+        } else {
+          int k = 0;
 #pragma unroll
-        for (; k + 1 < d; k += 2) {
-          g0 += redq[d + k];
-          g1 += redq[d + k + 1];
+          for (; k + 1 < d; k += 2) {
+            g0 += redq[d + k];
+            g1 += redq[d + k + 1];
+          }
+          if (k < d) g0 += redq[d + k];
         }
-        if (k < d) g0 += redq[d + k];
         a.g[b * T + s] = g0 + g1;
         if (SUMS) scal[tlc * 3 + 1] = g0 + g1;
       }
@@ -821,7 +864,7 @@ inline size_t core_small_lds(int d, bool want_v, bool sample) {
   const size_t F = (size_t)d * (d + 1) / 2 + d + 1;
   const size_t fl = (size_t)TB * d * dp + 5 * (size_t)TB * d;  // floats: tile, pis, pin (doubled), pal, pex
   return (want_v ? F * 8 : 0) + (sample ? (size_t)TB * d * 8 : 0) + (size_t)4 * TB * d * 8 + (fl + (fl & 1)) * 4 +
-         (size_t)TB * 3 * 8 + (size_t)TB * 2 * d * 4;  // + SUMS scalars + start state
+         (size_t)TB * 3 * 8 + (size_t)TB * 8 * 8 + (size_t)TB * 2 * d * 4;  // + SUMS scalars + partial sums + start state
 }
 
 // ---------------------------------------------------------------------------------------------
