@@ -342,8 +342,10 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
   constexpr int H = (D + 1) / 2;
   const int pnw = CIRC ? 2 * d : d;  // floats per trajectory in pin
   double* wl = reinterpret_cast<double*>(smem_raw);
-  double* pis64 = wl + (want_v ? F : 0);  // SAMPLE: the states as fp64 (column pass: transition + reward sums)
-  double* red = pis64 + (SAMPLE ? TB * d : 0);  // [TB][4][d]: per-lane terms of reward / score / V(next) / V(start), summed by lane 0 / 1
+  // SAMPLE: per state entry k a 16-byte line {pi_k as fp64, 1 / S_k of row k as fp32}: the column pass (transition + reward
+  // sums) fetches both with one broadcast read per row
+  double* pis64 = wl + (want_v ? ((F + 1) & ~1) : 0);  // (16-byte aligned)
+  double* red = pis64 + (SAMPLE ? 2 * TB * d : 0);  // [TB][4][d]: per-lane terms of reward / score / V(next) / V(start), summed by lane 0 / 1
   float* tile = reinterpret_cast<float*>(red + 4 * TB * d);
   float* pis = tile + TB * d * dp;
   float* pin = pis + TB * d;       // [TB][pnw]
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
           pst[tlc * pnw + i] = pi_i;
           if (CIRC) pst[tlc * pnw + d + i] = pi_i;
         }
-        if (SAMPLE) pis64[tlc * d + i] = (double)pi_i;
+        if (SAMPLE) pis64[2 * (tlc * d + i)] = (double)pi_i;
         if (sep) {
 #ifdef MFG_ABL_STAGE
           pex[tlc * d + i] = pi_i;
@@ -545,19 +547,25 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
         if (SAMPLE) {
           // normalise the row.  strict: P_ij = fl32(y_ij / S_i); mixed: P_ij = y_ij * fl32(1 / S_i) (one fp32 multiply per
           // element, within 1.5 ulp of the strict value; rows still sum to 1 within a few 1e-7)
+          //   Mixed mode leaves the variates in the tile and hands 1 / S_i to the column pass (one multiply per element THERE
+          //   instead of a read-multiply-write pass over the row here: 2 LDS instructions per element less); only when P is
+          //   written out is the tile itself normalised (the copy-out reads it), and the column pass multiplies by 1.
+          float* inv_slot = reinterpret_cast<float*>(pis64 + 2 * (tlc * d + i) + 1);
           if (FAST) {
             const float inv32 = fast_rcp_f32_of_f64(Ssum);
-#ifdef MFG_ABL_NORM  // timing ablation: no read / multiply (magnitudes stay sane: rows sum to d / S instead of 1)
-            for (int j = 0; j < d; ++j) trow[j] = inv32;
-#else
-            for (int j = 0; j < d; ++j) trow[j] *= inv32;
-#endif
+            if (a.P_out) {
+              for (int j = 0; j < d; ++j) trow[j] *= inv32;
+              *inv_slot = 1.0f;
+            } else {
+              *inv_slot = inv32;
+            }
 #ifndef MFG_ABL_EPI
             if (TD) gacc -= fast_log_f64(Ssum) * D_;
 #endif
           } else {
             const double invS = 1.0 / Ssum;
             for (int j = 0; j < d; ++j) trow[j] = (float)((double)trow[j] * invS);
+            *inv_slot = 1.0f;
             if (TD) gacc -= log(Ssum) * D_;
           }
         }
@@ -576,15 +584,16 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
         // (consecutive lanes -> consecutive banks; pi_k as fp64 from LDS, one broadcast read per row).
         double acc = 0.0, s1 = 0.0, s2 = 0.0;
         const float* tcol = tile + tlc * d * dp + i;
-        const double* q64 = pis64 + tlc * d;
+        const double2* q64 = reinterpret_cast<const double2*>(pis64) + tlc * d;
 #ifdef MFG_ABL_COLT
         for (int k = 0; k < 0; ++k) {
 #else
 #pragma unroll 3
         for (int k = 0; k < d; ++k) {
 #endif
-          const double p = (double)tcol[k * dp];
-          const double u = p * q64[k];
+          const double2 e = q64[k];  // {pi_k, 1 / S_k (fp32 bits in the low word of .y)}
+          const double p = (double)(tcol[k * dp] * __int_as_float(__double2loint(e.y)));
+          const double u = p * e.x;
           acc += u;
 #ifndef MFG_ABL_COLREW
           s1 = fma(u, p, s1);  // both reward sums unconditionally; the kind selects what is used below
@@ -863,7 +872,7 @@ inline size_t core_small_lds(int d, bool want_v, bool sample) {
   const int G = WAVE / d, TB = WAVES * G, dp = d | 1;
   const size_t F = (size_t)d * (d + 1) / 2 + d + 1;
   const size_t fl = (size_t)TB * d * dp + 5 * (size_t)TB * d;  // floats: tile, pis, pin (doubled), pal, pex
-  return (want_v ? F * 8 : 0) + (sample ? (size_t)TB * d * 8 : 0) + (size_t)4 * TB * d * 8 + (fl + (fl & 1)) * 4 +
+  return (want_v ? ((F + 1) & ~(size_t)1) * 8 : 0) + (sample ? (size_t)2 * TB * d * 8 : 0) + (size_t)4 * TB * d * 8 + (fl + (fl & 1)) * 4 +
          (size_t)TB * 3 * 8 + (size_t)TB * 8 * 8 + (size_t)TB * 2 * d * 4;  // + SUMS scalars + partial sums + start state
 }
 

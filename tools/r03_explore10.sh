@@ -1,3 +1,4 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-bash $R/tools/ab3.sh "ts4 ts1 ts2 tsf" $R/tools/shard_table.py 21 15 65536 4096
+python -m pytest tests -m gpu -x -q -k "parity or classes or sampler" 2>&1 | tail -3
+bash $R/tools/ab3.sh "head shipped" $R/tools/shard_table.py 21 15 65536 4096
