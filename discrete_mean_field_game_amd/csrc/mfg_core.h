@@ -454,13 +454,8 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
         }
         if (SAMPLE) pis64[2 * (tlc * d + i)] = (double)pi_i;
         if (sep) {
-#ifdef MFG_ABL_STAGE
-          pex[tlc * d + i] = pi_i;
-          Fi = pi_i + 1.0f;
-#else
           pex[tlc * d + i] = exp_f64arg(theta * ((double)pi_i - SEP_CENTRE));
           Fi = exp_f64arg(-theta * ((double)pi_i + (a.shift - SEP_CENTRE)));
-#endif
         }
       }
       if (!SAMPLE) {

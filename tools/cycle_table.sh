@@ -28,7 +28,7 @@ PY
 )
 export CT_DUR0=$DUR0
 ABL=""
-for a in PHILOX BM SETUP TRY HTAB LNY EPI COLT NORM TSUM V; do
+for a in PHILOX BM SETUP TRY HTAB LNY EPI COLT TSUM V; do
   if [ -f $V/libabl_$a.so ]; then run /tmp/cta_$a "$P1" $V/libabl_$a.so; ABL="$ABL $a"; fi
 done
 python3 - "$SH" $ABL <<'PY'
