@@ -880,9 +880,14 @@ inline size_t core_small_lds(int d, bool want_v, bool sample) {
 // two rows are six interleaved fp32 DPP wave sums (a third of the instructions of three fp64 ones, per row); the
 // transition and reward sums use the u = pi_i P form (4 fp64 operations per element).
 // registers: R <= 2 fits 168 VGPRs (3 waves / SIMD) without spilling; R >= 3 needs ~220 (2 waves / SIMD; capping it at
-// 168 spills 45 registers and measured slower)
+// 168 spills 45 registers and measured slower).  Round 3: the mixed-mode sampling kernels at R <= 2 take the 128-register
+// budget of FOUR waves per SIMD -- since the row batches their phases are short enough that the 25 spilled registers (all
+// outside the sampling loop) cost less than the fourth wave brings: C3 20.47 -> 20.18 ms.
 #ifndef MFG_CORE_LARGE_WAVES
 #define MFG_CORE_LARGE_WAVES(R) (((R) <= 2 || (R) == 4) ? 3 : 2)
+#endif
+#ifndef MFG_CORE_LARGE_WAVES_MIXED_SAMPLING
+#define MFG_CORE_LARGE_WAVES_MIXED_SAMPLING(R) ((R) <= 2 ? 4 : MFG_CORE_LARGE_WAVES(R))
 #endif
 // Rows per batch of the mixed-mode sampling loop (transposed row sums): sized so that the stash (KB x 64 R floats per
 // wave) keeps three blocks per CU at R <= 4 and two above.
@@ -928,7 +933,8 @@ __device__ __forceinline__ void stash_load(float* y, const float* p) {
 }
 // FULL: d == 64 R (every lane owns R live columns, d even): the validity masks of the quads fold away (d = 128, 256, ...).
 template <int R, bool SAMPLE, bool TD, bool FAST, bool FULL>
-__global__ __launch_bounds__(BLOCK, MFG_CORE_LARGE_WAVES(R)) void k_core_large(CoreArgs a) {
+__global__ __launch_bounds__(BLOCK, (SAMPLE && FAST) ? MFG_CORE_LARGE_WAVES_MIXED_SAMPLING(R) : MFG_CORE_LARGE_WAVES(R))
+void k_core_large(CoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int d = a.d, T = a.T;
   const int64_t dd = (int64_t)d * d;

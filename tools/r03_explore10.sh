@@ -1,4 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q -k "parity or classes or sampler" 2>&1 | tail -3
-bash $R/tools/ab3.sh "head shipped" $R/tools/shard_table.py 21 15 65536 4096
+for v in shipped max-ilp iterative-minreg shipped max-ilp iterative-minreg; do
+  if [ "$v" = shipped ]; then unset MFG_HIP_LIB; else export MFG_HIP_LIB=$R/discrete_mean_field_game_amd/csrc/variants/lib$v.so; fi
+  echo "== $v"; python $R/tools/large_probe.py 2>&1 | grep "TD"
+done
