@@ -1130,6 +1130,8 @@ void k_core_large(CoreArgs a) {
           for (int i0 = 0; i0 < d; i0 += KB) {
             float x[NQ];
             float park[NQ];  // NR == 1: the even row of a pair waits here for the odd one
+            TT gb = 0;       // score terms of the batch (fp32), folded into the fp64 sum once per batch: the score stays within
+                             // 1.9e-7 of the strict one (tools/score_error.py), a cvt + fp64 add per row pair less
 #pragma unroll 1
             for (int k = 0; k < KB; k += NR) {  // rolled: the sampling body is large
               const int i = i0 + k;
@@ -1140,7 +1142,7 @@ void k_core_large(CoreArgs a) {
                 float y[NR][R];
                 TT ysum[2] = {0, 0}, asum[2] = {0, 0}, dsum[2] = {0, 0}, gsum = 0;
                 sample_rows(i, row1, y, ysum, asum, dsum, gsum);
-                if (TD) gacc += (double)gsum;
+                if (TD) gb += gsum;
 #pragma unroll
                 for (int rr = 0; rr < NR; ++rr) {
                   stash_store<R>(yst + (k + rr) * (WAVE * R), y[rr]);
@@ -1165,6 +1167,7 @@ void k_core_large(CoreArgs a) {
                 row_pair_deposit<NQ>(x, m, row_pair_mask<KB>(k >> 1));
               }
             }
+            if (TD) gacc += (double)gb;
             row_batch_finish<NQ>(x);  // lane l: totals of row i0 + row_batch_row<KB>(l)
             float inv = __builtin_amdgcn_rcpf(x[0]);
             inv = fmaf(fmaf(-x[0], inv, 1.0f), inv, inv);
