@@ -1183,7 +1183,7 @@ struct GradChunk {
 
 // n0 = first sample of the chunk (wave uniform); (b0, s0) = its trajectory / step.  Sample n0 + j sits at trajectory
 // b0 + (s0 + j) / T, step (s0 + j) % T: small integers, so the division is an fp32 multiply (exact below 2^22).
-template <int D>
+template <int D, bool WIDE>
 __device__ __forceinline__ void grad_chunk_load(GradChunk<D>& c, const GradArgs& a, const double* gp, const float* rp, int d,
                                                 int64_t n0, int64_t b0, int s0, int lane, float invT, float inv_d) {
   const int last = (int)((a.N - 1 - n0) < (GS_CH - 1) ? (a.N - 1 - n0) : (GS_CH - 1));  // last live sample of the chunk
@@ -1193,24 +1193,47 @@ __device__ __forceinline__ void grad_chunk_load(GradChunk<D>& c, const GradArgs&
     c.dg = gp[n];
     c.rr = rp[n];
   }
+  // The chunk's [64][d] block is contiguous in memory except for the rows the layout skips between trajectories
+  // (stride_b - T d floats, the T+1-th state of pi_traj): element e of the block sits at  base + e + q extra,  q = number of
+  // trajectory boundaries in front of its sample -- 32-bit arithmetic on a wave-uniform 64-bit base (the (b, s) form cost
+  // two 64-bit multiplies and three 64-bit shifts-and-adds per load: 330 of the kernel's 790 VALU instructions per chunk,
+  // and f64 VALU work does not overlap the f64 matrix instructions).  Wide strides (WIDE, chosen by the host: skipped part
+  // >= 2^23 floats) keep the general form.
+  if constexpr (!WIDE) {
+    const float* cb = a.pi + b0 * a.stride_b + (int64_t)s0 * d;
+    const int extra = (int)(a.stride_b - (int64_t)a.T * d);
 #pragma unroll
-  for (int k = 0; k < GradChunk<D>::NL; ++k) {
-    if (!D && k * WAVE >= GS_CH * d) {                    // run-time d: loads past the chunk are not needed
-      c.pi[k] = 0.0f;
-      continue;
+    for (int k = 0; k < GradChunk<D>::NL; ++k) {
+      if (!D && k * WAVE >= GS_CH * d) {                  // run-time d: loads past the chunk are not needed
+        c.pi[k] = 0.0f;
+        continue;
+      }
+      int e = k * WAVE + lane;                            // flat element of the chunk's [64][d] block
+      int j = (int)(((float)e + 0.5f) * inv_d);           // sample of the chunk (e < 64 * 28: exact in fp32)
+      if (j > last) { j = last; e = last * d; }           // past the end of the batch / of a run-time-d chunk: any live entry
+      const int q = (int)(((float)(s0 + j) + 0.5f) * invT);
+      c.pi[k] = cb[(unsigned)(e + __mul24(q, extra))];
     }
-    const int e = k * WAVE + lane;                        // flat element of the chunk's [64][d] block
-    int j = (int)(((float)e + 0.5f) * inv_d);             // sample of the chunk (e < 64 * 28: exact in fp32)
-    int col = e - j * d;
-    if (j > last) { j = last; col = 0; }                  // past the end of the batch / of a run-time-d chunk: any live entry
-    const int sj = s0 + j;
-    const int q = (int)(((float)sj + 0.5f) * invT);
-    const int64_t off = (b0 + q) * a.stride_b + (int64_t)((sj - q * a.T) * d + col);
-    c.pi[k] = a.pi[off];
+  } else {
+#pragma unroll
+    for (int k = 0; k < GradChunk<D>::NL; ++k) {
+      if (!D && k * WAVE >= GS_CH * d) {
+        c.pi[k] = 0.0f;
+        continue;
+      }
+      const int e = k * WAVE + lane;
+      int j = (int)(((float)e + 0.5f) * inv_d);
+      int col = e - j * d;
+      if (j > last) { j = last; col = 0; }
+      const int sj = s0 + j;
+      const int q = (int)(((float)sj + 0.5f) * invT);
+      const int64_t off = (b0 + q) * a.stride_b + (int64_t)((sj - q * a.T) * d + col);
+      c.pi[k] = a.pi[off];
+    }
   }
 }
 
-template <int D>
+template <int D, bool WIDE = false>
 __global__ __launch_bounds__(BLOCK) void k_grad_mfma_small(GradArgs a) {
   const int d = D ? D : a.d;
   const int Q = d * (d + 1) / 2, F = Q + d + 1, FO = F + 3;
@@ -1249,7 +1272,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_mfma_small(GradArgs a) {
   const int64_t W = (int64_t)gridDim.x * WAVES;           // waves of the launch
   const int64_t gw = (int64_t)blockIdx.x * WAVES + wv;
   GradChunk<D> nx;
-  if (gw < NC) grad_chunk_load<D>(nx, a, gp, rp, d, gw * GS_CH, (gw * GS_CH) / a.T, (int)((gw * GS_CH) % a.T), lane, invT, inv_d);
+  if (gw < NC) grad_chunk_load<D, WIDE>(nx, a, gp, rp, d, gw * GS_CH, (gw * GS_CH) / a.T, (int)((gw * GS_CH) % a.T), lane, invT, inv_d);
   for (int64_t ch = gw; ch < NC; ch += W) {
     const int64_t n0 = ch * GS_CH;
     // park the chunk in LDS (the previous chunk's reads are complete: wave-local barrier)
@@ -1273,7 +1296,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_mfma_small(GradArgs a) {
     const int nvalid = (int)((a.N - n0) < GS_CH ? (a.N - n0) : GS_CH);  // samples of this chunk (wave uniform)
     if (ch + W < NC) {
       const int64_t n1 = (ch + W) * GS_CH;
-      grad_chunk_load<D>(nx, a, gp, rp, d, n1, n1 / a.T, (int)(n1 % a.T), lane, invT, inv_d);
+      grad_chunk_load<D, WIDE>(nx, a, gp, rp, d, n1, n1 / a.T, (int)(n1 % a.T), lane, invT, inv_d);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -1284,10 +1307,19 @@ __global__ __launch_bounds__(BLOCK) void k_grad_mfma_small(GradArgs a) {
       const double de = lsc[3 * j], dg = lsc[3 * j + 1];
       const double rr = lsc[3 * j + 2];
       const double one = j < nvalid ? 1.0 : 0.0;               // slots past the last sample hold zeros and count nothing
-      const double A_lo = fma(de, (double)(pi_lo ? plo : ad_lo), a1_lo * one);
+      double A_lo, B_lo;
+      if constexpr (D >= 16) {  // entries 0 .. 15 are all state entries: no constants, no selects
+        B_lo = (double)plo;
+        A_lo = de * B_lo;
+      } else {
+        A_lo = fma(de, (double)(pi_lo ? plo : ad_lo), a1_lo * one);
+        B_lo = fma(bg_lo, dg, fma(br_lo, rr, (double)(pi_lo ? plo : b1_lo)));
+      }
       const double A_hi = fma(de, (double)(pi_hi ? phi : ad_hi), a1_hi * one);
-      const double B_lo = fma(bg_lo, dg, fma(br_lo, rr, (double)(pi_lo ? plo : b1_lo)));
       const double B_hi = fma(bg_hi, dg, fma(br_hi, rr, (double)(pi_hi ? phi : b1_hi)));
+      // (timing ablations at the bench shape, 44 us: without these three instructions 24 us, without the chunk loads 38 us --
+      //  the matrix-core time, 20 us, ADDS to the rest whatever the occupancy (1 / 2 / 4 blocks per CU: 49 / 44 / 44 us):
+      //  the fp64 matrix instructions of this kernel do not hide behind its other work)
       c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(A_lo, B_lo, c00, 0, 0, 0);
       c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(A_lo, B_hi, c01, 0, 0, 0);
       c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A_hi, B_hi, c11, 0, 0, 0);
@@ -2227,7 +2259,9 @@ static int launch_grad(const float* pi, int64_t stride_b, const double* delta, c
         if (applied) *applied = true;
       }
     }
-    if (d == 21) hipLaunchKernelGGL((k_grad_mfma_small<21>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
+    const bool wide = stride_b - (int64_t)T * d >= (1 << 23);  // floats skipped between trajectories: 32-bit offsets inside a chunk?
+    if (wide) hipLaunchKernelGGL((k_grad_mfma_small<0, true>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
+    else if (d == 21) hipLaunchKernelGGL((k_grad_mfma_small<21>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
     else if (d == 15) hipLaunchKernelGGL((k_grad_mfma_small<15>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
     else hipLaunchKernelGGL((k_grad_mfma_small<0>), dim3((unsigned)blocks), dim3(BLOCK), 0, st, a);
     if (fuse) return check_launch("grad_mfma_small");
