@@ -31,6 +31,7 @@ ls $O; cat $O/bench.json | head -c 600
 python3 $R/tools/shard_table.py > $O/shards.txt 2>&1
 [ -x $R/tools/micro/valu_rates ] && $R/tools/micro/valu_rates > $O/valu_rates.txt 2>&1
 [ -x $R/tools/micro/mfma_f64_rate ] && $R/tools/micro/mfma_f64_rate > $O/mfma_f64_rate.txt 2>&1
+[ -x $R/tools/micro/mfma_valu_overlap ] && $R/tools/micro/mfma_valu_overlap > $O/mfma_valu_overlap.txt 2>&1
 for SH in 21,15,65536 128,40,16384 256,40,16384; do bash $R/tools/cycle_table.sh $SH > $O/cycle_table_d${SH%%,*}.txt 2>&1; done
 bash $R/tools/trace_gaps.sh $R/tools/irl_mode_probe.py 4096 > $O/irl_step_mode_trace.txt 2>&1
 python3 $R/tools/perf_train.py 4096 > $O/perf_train_4096.txt 2>&1
