@@ -271,7 +271,8 @@ def test_sampler_small_shape_regime(dev):
 # Fused rollout vs the oracle replaying the SAME sampled actions
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('d,B,T', [(3, 50, 4), (4, 37, 5), (15, 33, 6), (21, 1, 15), (21, 100, 15), (32, 10, 3), (47, 9, 4),
-                                   (64, 5, 2), (65, 3, 2), (100, 5, 3), (128, 6, 3), (256, 2, 2), (320, 2, 2), (512, 1, 1)])
+                                   (64, 5, 2), (65, 3, 2), (100, 5, 3), (128, 6, 3), (256, 2, 2), (320, 2, 2), (512, 1, 1),
+                                   (250, 2, 2), (253, 2, 2), (450, 1, 1), (66, 3, 2), (127, 2, 2)])
 @pytest.mark.parametrize('discount_pow', [False, True])
 @pytest.mark.parametrize('precision,gtol', [('f64', 1e-9), ('mixed', 1e-5)])
 def test_rollout_fused_vs_oracle(dev, d, B, T, discount_pow, precision, gtol):
