@@ -435,7 +435,18 @@ __global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) 
     const int64_t b = b0 + tlc;
     double* redq = red + (size_t)tlc * 4 * d;
     float* pnv = pin + tlc * pnw;
-    float pi_i = tileid == blockIdx.x ? pi_first : a.pi0[(a.start_idx ? start_row(a.start_idx[b], a.num_start) : b) * d + i];
+    // (pi_first: this tile's start state -- loaded ahead of the weight staging for the block's first tile, and, for every
+    //  further tile, at the start of the tile before it: a T = 1 launch at large batches runs 3-4 tiles per block and paid
+    //  the L2 / HBM latency of this load once per tile)
+    float pi_i = pi_first;
+    {
+      const int64_t tn = tileid + gridDim.x;
+      if (tn < ntiles) {
+        const int64_t b0n = tn * TB;
+        const int64_t bn = b0n + ((t < G && b0n + tl < a.B) ? tl : 0);
+        pi_first = a.pi0[(a.start_idx ? start_row(a.start_idx[bn], a.num_start) : bn) * d + i];
+      }
+    }
     if (valid && a.pi_traj) a.pi_traj[b * (int64_t)(T + 1) * d + i] = pi_i;
     double v_cur = 0.0, discount = 1.0;  // meaningful on lane i == 0 only
     // (V of the start state: evaluated inside step 0 next to V of the next state -- as a prologue it cost three barriers,
