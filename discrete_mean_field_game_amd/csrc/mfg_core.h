@@ -902,11 +902,15 @@ inline size_t core_small_lds(int d, bool want_v, bool sample) {
 #endif
 // Rows per batch of the mixed-mode sampling loop (transposed row sums): sized so that the stash (KB x 64 R floats per
 // wave) keeps three blocks per CU at R <= 4 and two above.
-__host__ __device__ constexpr int large_row_batch(int R) { return R <= 2 ? 8 : (R <= 4 ? 4 : 2); }
+// (R = 3, 4 with TD: 8 rows -- 52 KB per block at d = 256, three blocks per CU; measured 78.85 -> 77.2 ms against 4 rows.  Without
+//  TD the kernel fits four blocks per CU with a 4-row stash and keeps them.)
+__host__ __device__ constexpr int large_row_batch(int R, bool td) { return R <= 2 ? 8 : (R <= 4 ? (td ? 8 : 4) : 2); }
 // dynamic LDS of k_core_large: 4 state vectors per wave, the per-row (A, D, S), the stash
 inline size_t core_large_lds(int d, bool sample, bool fast, bool td) {
   const int R = (d + WAVE - 1) / WAVE;
-  if (sample && fast) return (size_t)WAVES * ((td ? 7 : 4) * d + large_row_batch(R) * WAVE * R) * 4;  // no (A, D, S) without TD
+  // mixed-mode sampling: state + F per wave, (A, D, S) as fp32 (TD only), the stash (the next-state vector and the unused
+  // alpha-state vector live inside it: they are written after a step's row loop, when the stash is dead)
+  if (sample && fast) return (size_t)WAVES * ((td ? 5 : 2) * d + large_row_batch(R, td) * WAVE * R) * 4;
   return (size_t)WAVES * 4 * d * 4 + (size_t)WAVES * 3 * d * 8;
 }
 // a lane's R variates of one row to / from its stash slot (R consecutive floats, 4 R bytes aligned)
@@ -950,18 +954,20 @@ void k_core_large(CoreArgs a) {
   const int d = a.d, T = a.T;
   const int64_t dd = (int64_t)d * d;
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
-  float* pis = smem + wv * 4 * d;  // current state
-  float* pin = pis + d;            // next state
-  float* pal = pin + d;            // state for alpha (GIVEN with pi_alpha)
-  float* pfs = pal + d;            // SAMPLE, mixed: F_i = e^{-theta (pi_i + shift)}
+  constexpr bool batched = SAMPLE && FAST;
+  constexpr int NSV = batched ? 2 : 4;  // state vectors per wave (batched: next state / alpha state alias the stash)
+  float* pis = smem + wv * NSV * d;  // current state
+  float* pfs = pis + d;              // SAMPLE, mixed: F_i = e^{-theta (pi_i + shift)}   (others: next state)
+  float* ystash = smem + WAVES * (NSV + (batched && TD ? 3 : 0)) * d + wv * (large_row_batch(R, TD) * WAVE * R);
+  float* pin = batched ? ystash : pis + d;      // next state
+  float* pal = batched ? ystash : pis + 2 * d;  // state for alpha (GIVEN with pi_alpha)
+  if (!batched) pfs = pis + 3 * d;
   // per-row (A_i, D_i, S_i) of this wave's trajectory: psi(A_i) D_i and ln(S_i) D_i are evaluated AFTER the row
   // loop, one row per lane, instead of once per row by the whole wave (a fp64 digamma + log per row amortised
   // over only d/64 elements per lane dominated the TD kernels at d = 128)
   // (mixed-mode sampling: fp32 -- the sums are fp32 sums there -- followed by the lane-private stash of a row batch's variates)
-  constexpr bool batched = SAMPLE && FAST;
   using RQ = typename std::conditional<batched, float, double>::type;
-  RQ* rowq = reinterpret_cast<RQ*>(smem + WAVES * 4 * d) + wv * 3 * d;
-  float* ystash = smem + WAVES * (TD ? 7 : 4) * d + wv * (large_row_batch(R) * WAVE * R);
+  RQ* rowq = reinterpret_cast<RQ*>(smem + WAVES * NSV * d) + wv * 3 * d;
   const bool want_v = TD && a.w != nullptr;
   const double theta = *a.theta;
   const ThetaSplit ts = theta_split(theta, a.shift);
@@ -1136,7 +1142,7 @@ void k_core_large(CoreArgs a) {
           // LDS stash, the per-lane partials of the row sums (S and, TD, A, D) are packed TRANSPOSED (row_pair_merge ...,
           // mfg_device.h) so that the batch shares its butterfly steps; phase 2 normalises and folds the rows into the column
           // sums, the reciprocal of a row's sum coming from the lane that owns it through one read-lane.
-          constexpr int KB = large_row_batch(R), NQ = TD ? 3 : 1;
+          constexpr int KB = large_row_batch(R, TD), NQ = TD ? 3 : 1;
           float* yst = ystash + (int64_t)lane * R;
           for (int i0 = 0; i0 < d; i0 += KB) {
             float x[NQ];
