@@ -1185,24 +1185,30 @@ void k_core_large(CoreArgs a) {
               }
             }
             if (TD) gacc += (double)gb;
-            row_batch_finish<NQ>(x);  // lane l: totals of row i0 + row_batch_row<KB>(l)
-            float inv = __builtin_amdgcn_rcpf(x[0]);
-            inv = fmaf(fmaf(-x[0], inv, 1.0f), inv, inv);
-            if (TD) {
+            float tot;  // lane l: the batch totals of row i0 + row_batch_row<KB>(l) -- S where the reciprocal is read from
+            if constexpr (TD) {
+              tot = row_batch_finish3(x);  // S, A and D in one register (mfg_device.h), published by three lanes per row
               const int ir = i0 + row_batch_row<KB>(lane);
-              if (row_batch_owner<KB>(lane) && (FULL || ir < d)) {
-                rowq[3 * ir] = x[NQ > 1 ? 1 : 0];
-                rowq[3 * ir + 1] = x[NQ > 2 ? 2 : 0];
-                rowq[3 * ir + 2] = x[0];
-              }
+              if (row_batch_owner3<KB>(lane) && (FULL || ir < d)) rowq[3 * ir + row_batch_slot3(lane)] = tot;
+            } else {
+              row_batch_finish<NQ>(x);
+              tot = x[0];
             }
+            float inv = __builtin_amdgcn_rcpf(tot);
+            inv = fmaf(fmaf(-tot, inv, 1.0f), inv, inv);
             auto fold_batch = [&](auto wp) __attribute__((always_inline)) {
               float yr[KB][R], pb[KB];  // the whole batch is requested up front: one LDS round trip per batch, not per row
 #pragma unroll
-              for (int k = 0; k < KB; ++k) {
-                const int ir = (FULL || i0 + k < d) ? i0 + k : i0;
-                stash_load<R>(yr[k], yst + k * (WAVE * R));
-                pb[k] = pis[ir];
+              for (int k = 0; k < KB; ++k) stash_load<R>(yr[k], yst + k * (WAVE * R));
+              if constexpr (FULL && KB % 4 == 0) {  // the batch's state entries: 16-byte broadcast reads (i0 and d are multiples of KB)
+#pragma unroll
+                for (int k = 0; k < KB; k += 4) {
+                  const float4 pq = *reinterpret_cast<const float4*>(pis + i0 + k);
+                  pb[k] = pq.x, pb[k + 1] = pq.y, pb[k + 2] = pq.z, pb[k + 3] = pq.w;
+                }
+              } else {
+#pragma unroll
+                for (int k = 0; k < KB; ++k) pb[k] = pis[(FULL || i0 + k < d) ? i0 + k : i0];
               }
 #pragma unroll
               for (int k = 0; k < KB; ++k) {

@@ -592,6 +592,28 @@ __device__ __forceinline__ void row_batch_finish(float* x) {
     x[q] = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // lane bit 5
   }
 }
+// The three sums of a TD batch (S, A, D) finished TOGETHER: the swaps that fold lane bits 4 and 5 take TWO registers, so
+// S and A share the bit-4 step and the pair shares the bit-5 step with D -- 10 instructions instead of 27 (the same swap
+// with both operands equal needs a copy first), and ONE register comes back: lane l holds, for its row row_batch_row(l),
+// S if bits (5, 4) are (0, 0), A if (0, 1), D if bit 5 is set.
+__device__ __forceinline__ float row_batch_finish3(const float* x) {
+  float s = x[0] + dpp_mov_f32<0x4E, 0xF>(x[0]);  // quad_perm [2,3,0,1]: lane bit 1
+  float a = x[1] + dpp_mov_f32<0x4E, 0xF>(x[1]);
+  float d = x[2] + dpp_mov_f32<0x4E, 0xF>(x[2]);
+  const auto r4 = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(a), false, false);
+  const float sa = __uint_as_float(r4[0]) + __uint_as_float(r4[1]);  // even 16-lane rows: S over bit 4, odd rows: A
+  const auto rd = __builtin_amdgcn_permlane16_swap(__float_as_uint(d), __float_as_uint(d), false, false);
+  const float d4 = __uint_as_float(rd[0]) + __uint_as_float(rd[1]);
+  const auto r5 = __builtin_amdgcn_permlane32_swap(__float_as_uint(sa), __float_as_uint(d4), false, false);
+  return __uint_as_float(r5[0]) + __uint_as_float(r5[1]);            // lower half: S / A over bit 5, upper half: D
+}
+// slot of the packed value in the per-row (A, D, S) triple, and whether this lane is the one that publishes it
+__device__ __forceinline__ int row_batch_slot3(int lane) { return (lane & 32) ? 1 : ((lane & 16) ? 0 : 2); }
+template <int KB>
+__device__ __forceinline__ bool row_batch_owner3(int lane) {
+  // bit 1 clear (one of the two copies), not the (bit 5, bit 4) = (1, 1) copy of D, index bits the batch does not use clear
+  return (lane & 2) == 0 && (lane & 0x30) != 0x30 && (lane & (KB == 8 ? 0 : (KB == 4 ? 0x04 : 0x05))) == 0;
+}
 // in-batch row index k -> the first lane that holds its total after row_batch_finish, and a lane's row
 __device__ __forceinline__ int row_batch_lane(int k) { return ((k & 1) << 3) | ((k >> 1) & 1) | (((k >> 2) & 1) << 2); }
 template <int KB>
