@@ -887,9 +887,9 @@ inline size_t core_small_lds(int d, bool want_v, bool sample) {
 // ---------------------------------------------------------------------------------------------
 // SAMPLE mode (round 2): rows are processed TWO at a time so that one Philox block feeds a quad
 // {(i, c), (i, c+64), (i+1, c), (i+1, c+64)} of the lane's columns (sample_elems_g); e^z is separable (E_c lives in the
-// registers of the lane that owns column c, F_i of the row comes from LDS); in mixed mode the per-row sums S, A, D of the
-// two rows are six interleaved fp32 DPP wave sums (a third of the instructions of three fp64 ones, per row); the
-// transition and reward sums use the u = pi_i P form (4 fp64 operations per element).
+// registers of the lane that owns column c, F_i of the row comes from LDS); in mixed mode the per-row sums S, A, D are fp32
+// and reduced TRANSPOSED over batches of rows (round 3, see the sampling loop); the transition and reward sums use the
+// u = pi_i P form (4 fp64 operations per element).
 // registers: R <= 2 fits 168 VGPRs (3 waves / SIMD) without spilling; R >= 3 needs ~220 (2 waves / SIMD; capping it at
 // 168 spills 45 registers and measured slower).  Round 3: the mixed-mode sampling kernels at R <= 2 take the 128-register
 // budget of FOUR waves per SIMD -- since the row batches their phases are short enough that the 25 spilled registers (all

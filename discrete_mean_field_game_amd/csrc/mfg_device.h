@@ -480,9 +480,8 @@ __device__ __forceinline__ void wave_sum3_dpp(double& a, double& b, double& c) {
   c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c), 63), __builtin_amdgcn_readlane(__double2loint(c), 63));
 }
 
-// fp32 wave sums on the DPP path, NS independent values step-interleaved (mixed mode of the wave-per-trajectory kernels:
-// the per-row S, A, D of two rows = six sums; each step is ONE v_add_f32 with a DPP operand, against two moves and an
-// fp64 add for a double).  A tree sum of 64 fp32 terms: ~1e-7 relative, of the order of the terms' own rounding.
+// fp32 DPP move (building block of the fp32 row / wave sums: each butterfly step is ONE v_add_f32 with a DPP operand,
+// against two moves and an fp64 add for a double).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_mov_f32(float v) {
   const int x = __float_as_int(v);
@@ -490,57 +489,6 @@ __device__ __forceinline__ float dpp_mov_f32(float v) {
                                   : __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xF, false);
   return __int_as_float(r);
 }
-// The two cross-row steps are written as ONE instruction per sum: v_add_f32_dpp with row_bcast and a row mask, destination
-// tied to the second source, so that the rows outside the mask simply keep their value (the compiler expands the
-// update_dpp form into zero-initialised move + DPP move + add: 3 instructions per sum per step, a quarter of the d = 128
-// kernel's row-sum cost).  The s_nop covers the VALU-write -> DPP-read hazard, which the compiler cannot see through
-// inline assembly.
-// One asm statement per step for all NS sums: the NS independent chains cover each other's hazard distance, so ONE
-// s_nop per step suffices (NS >= 3: none needed at all, kept for safety).
-template <int NS>
-__device__ __forceinline__ void dpp_add_row_bcast(float* x, bool second) {
-  static_assert(NS == 1 || NS == 2 || NS == 3 || NS == 6, "row-sum group sizes used by the kernels");
-#define MFG_BC(OP, MASK)                                                                                              \
-  if constexpr (NS == 1) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " OP " row_mask:" MASK " bank_mask:0xf" : "+v"(x[0])); \
-  else if constexpr (NS == 2) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " OP " row_mask:" MASK " bank_mask:0xf\n\t"      \
-                                           "v_add_f32_dpp %1, %1, %1 " OP " row_mask:" MASK " bank_mask:0xf" : "+v"(x[0]), "+v"(x[1])); \
-  else if constexpr (NS == 3) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " OP " row_mask:" MASK " bank_mask:0xf\n\t"      \
-                                           "v_add_f32_dpp %1, %1, %1 " OP " row_mask:" MASK " bank_mask:0xf\n\t"                  \
-                                           "v_add_f32_dpp %2, %2, %2 " OP " row_mask:" MASK " bank_mask:0xf"                       \
-                                           : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));                                                 \
-  else asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " OP " row_mask:" MASK " bank_mask:0xf\n\t"                             \
-                    "v_add_f32_dpp %1, %1, %1 " OP " row_mask:" MASK " bank_mask:0xf\n\t"                                         \
-                    "v_add_f32_dpp %2, %2, %2 " OP " row_mask:" MASK " bank_mask:0xf\n\t"                                         \
-                    "v_add_f32_dpp %3, %3, %3 " OP " row_mask:" MASK " bank_mask:0xf\n\t"                                         \
-                    "v_add_f32_dpp %4, %4, %4 " OP " row_mask:" MASK " bank_mask:0xf\n\t"                                         \
-                    "v_add_f32_dpp %5, %5, %5 " OP " row_mask:" MASK " bank_mask:0xf"                                              \
-                    : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]));
-  if (!second) {
-    MFG_BC("row_bcast:15", "0xa")
-  } else {
-    MFG_BC("row_bcast:31", "0xc")
-  }
-#undef MFG_BC
-}
-template <int NS>
-__device__ __forceinline__ void wave_sums_f32_dpp(float* x) {
-#define MFG_SUMF_STEP(CTRL, MASK)                                          \
-  {                                                                        \
-    float t[NS];                                                           \
-    _Pragma("unroll") for (int q = 0; q < NS; ++q) t[q] = dpp_mov_f32<CTRL, MASK>(x[q]); \
-    _Pragma("unroll") for (int q = 0; q < NS; ++q) x[q] += t[q];           \
-  }
-  MFG_SUMF_STEP(0xB1, 0xF)
-  MFG_SUMF_STEP(0x4E, 0xF)
-  MFG_SUMF_STEP(0x141, 0xF)
-  MFG_SUMF_STEP(0x140, 0xF)
-#undef MFG_SUMF_STEP
-  dpp_add_row_bcast<NS>(x, false);
-  dpp_add_row_bcast<NS>(x, true);
-#pragma unroll
-  for (int q = 0; q < NS; ++q) x[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x[q]), 63));
-}
-
 // ---------------------------------------------------------------------------
 // Transposed row sums (round 3; mixed mode of the wave-per-trajectory kernels).  The 64 lanes of a wave each hold a
 // partial sum of KB different matrix rows (KB = 2, 4, 8; rows arrive in pairs).  Reducing every row on its own costs
@@ -619,11 +567,6 @@ __device__ __forceinline__ int row_batch_lane(int k) { return ((k & 1) << 3) | (
 template <int KB>
 __device__ __forceinline__ int row_batch_row(int lane) {
   return (((lane >> 3) & 1) | ((lane & 1) << 1) | (((lane >> 2) & 1) << 2)) & (KB - 1);
-}
-// the one lane per row that publishes its totals: replica bits (1, 4, 5) and the index bits the batch does not use clear
-template <int KB>
-__device__ __forceinline__ bool row_batch_owner(int lane) {
-  return (lane & (KB == 8 ? 0x32 : (KB == 4 ? 0x36 : 0x37))) == 0;
 }
 
 template <typename T>

@@ -1,5 +1,4 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q -k "large or sampler or 128 or 256 or 130 or 192 or 320 or 250 or 253 or 450 or fullsize or sweep or oracle" 2>&1 | tail -2
-python $R/tools/large_probe.py 2>&1 | grep "d="
-python $R/tools/large_probe.py 2>&1 | grep "TD"
+python -m pytest tests -m gpu -x -q -k "parity or classes or sampler" 2>&1 | tail -2
+bash $R/tools/ab3.sh "head shipped" $R/tools/shard_table.py 21 15 65536 8192 4096 | grep "==\|d="
