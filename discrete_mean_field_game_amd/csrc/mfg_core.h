@@ -324,7 +324,10 @@ __device__ __forceinline__ double value_wave(const float* pis, const double* __r
 // fence-and-last-block finish: 10.6 us per env step at B = 4 096) shrinks to the row reduction.  Register budget of two
 // waves per SIMD (the three-wave cap spills 31 registers here); used while all tiles are resident at that occupancy.
 template <bool SAMPLE, bool TD, bool FAST, int D, bool SUMS = false>
-__global__ __launch_bounds__(BLOCK, (FAST && !SUMS) ? MFG_CORE_SMALL_WAVES : 2) void k_core_small(CoreArgs a) {
+#ifndef MFG_CORE_SMALL_WAVES_F64
+#define MFG_CORE_SMALL_WAVES_F64 3  // strict precision: 227 registers wanted; at 168 the third wave still pays (5.95 -> 5.80 ms at the bench shape)
+#endif
+__global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MFG_CORE_SMALL_WAVES_F64)) void k_core_small(CoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   MFG_STAMP0(8)
   const int d = D ? D : a.d;
