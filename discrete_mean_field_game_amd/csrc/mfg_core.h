@@ -902,8 +902,9 @@ inline size_t core_small_lds(int d, bool want_v, bool sample) {
 #endif
 #ifndef MFG_CORE_LARGE_WAVES_MIXED_SAMPLING
 // R = 3: 176 registers wanted, 8 spilled at 168: d = 192 35.4 -> 31.2 ms with the third wave; R = 5, 6 (190-200 wanted): d = 320
-// 24.2 -> 22.6 ms, d = 384 32.7 -> 30.6 ms; R = 8 (228 wanted) is better off with two waves (23.7 against 24.6 ms at d = 512)
-#define MFG_CORE_LARGE_WAVES_MIXED_SAMPLING(R) ((R) <= 2 ? 4 : ((R) <= 6 ? 3 : 2))
+// 24.2 -> 22.6 ms, d = 384 32.7 -> 30.6 ms; R = 7 (208-216 wanted): d = 448 35.8 -> 32.9 ms at 6 144 trajectories (25.2 against 24.9 ms
+// at 2 048, where a SIMD holds two waves anyway); R = 8 (228 wanted) is better off with two waves (33.7 against 35.0 ms at d = 512)
+#define MFG_CORE_LARGE_WAVES_MIXED_SAMPLING(R) ((R) <= 2 ? 4 : ((R) <= 7 ? 3 : 2))
 #endif
 // Rows per batch of the mixed-mode sampling loop (transposed row sums): sized so that the stash (KB x 64 R floats per
 // wave) keeps three blocks per CU at R <= 4 and two above.
