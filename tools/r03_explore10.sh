@@ -1,4 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q -k "parity or classes or sampler" 2>&1 | tail -2
-bash $R/tools/ab3.sh "head shipped" $R/tools/shard_table.py 21 15 65536 8192 4096 | grep "==\|d="
+for v in shipped t1os1 t1os4 t1os8 shipped t1os4; do
+  if [ "$v" = shipped ]; then unset MFG_HIP_LIB; else export MFG_HIP_LIB=$R/discrete_mean_field_game_amd/csrc/variants/lib$v.so; fi
+  echo "== $v"; python $R/tools/step65k_probe.py 2>&1 | grep "step mode"; python $R/tools/step65k_probe.py 16384 2>&1 | grep "step mode"
+done
