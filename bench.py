@@ -5,11 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W    (N > 1, one rank per GPU, RCCL)
 
-One bench "step" = one full training rollout of the forward-RL actor-critic (mfg_ac2.train semantics,
-update_every='rollout') over the rank's trajectory batch, with everything resident in HBM:
-    start-state gather -> fused T-step rollout kernel (Dirichlet action sampling, pi' = P^T pi,
-    reward, value, TD error, score) -> batch gradient sums -> [one RCCL all-reduce of the fused
-    gradient buffer when N > 1] -> (theta, w) update on device.
+One bench "step" = one episode of the drop-in class, `actor_critic.train(update_every='rollout')` -- the timed region IS a
+call of the reference's train() surface (mfg_ac2.py:448) -- over the rank's trajectory batch, everything resident in HBM:
+    per-episode start-state draw (on the device, fresh every episode) -> fused T-step rollout kernel (Dirichlet
+    action sampling, pi' = P^T pi, reward, value, TD error, score) -> batch gradient sums -> [one RCCL all-reduce
+    of the fused gradient buffer when N > 1] -> (theta, w) update on device.
 value = (ranks * B * T * K) / max-over-ranks wall time between barriers.  STRONG scaling by default: the global
 batch (65536, the north-star target point d=21, T=15) is split over the N GPUs; for N > 1 the same line also carries
 the weak-scaling leg (65536 per GPU, `other_scaling`) and BASELINE config 5 (d=256, T=40, 131072 split N ways,
@@ -73,7 +73,7 @@ def cpu_baseline(d, budget_s):
     # all-cores mode: independent single-thread processes over disjoint trajectories
     try:
         import subprocess
-        procs = max(1, min(os.cpu_count() or 1, 64))
+        procs = max(1, os.cpu_count() or 1)              # one single-thread process per host core of this box
         per = int(max(150, min(rate * 4.0, 30000)) // 15 * 15)
         code = ('import sys; sys.path.insert(0, %r); from oracle import mfg_oracle as O; '
                 'n, t = O.cpu_baseline_steps(%d, %d, seed=int(sys.argv[1])); print(n, t)' % (ROOT, d, per))
@@ -188,54 +188,70 @@ def main():
 
     def start_table(d):
         # synthetic workload: 64 Dirichlet(1) start states rounded through '%.3e' text
+        return torch.as_tensor(start_table64(d).astype(np.float32), device=dev)
+
+    def start_table64(d):
         rs = np.random.RandomState(0)
         mat = rs.dirichlet(np.ones(d), size=64)
-        mat = np.array([[float('%.3e' % v) for v in row] for row in mat], dtype=np.float32)
-        return torch.as_tensor(mat, device=dev)
+        return np.array([[float('%.3e' % v) for v in row] for row in mat])
 
-    def training_leg(d, T, B, steps, warmup, precision='mixed'):
-        """`steps` timed training rollouts (mfg_ac2.train semantics, one update per rollout) of this rank's B
-        trajectories: start-state gather + fused T-step rollout + batch sums [+ ONE all-reduce when N > 1] + update.
-        Returns (max-over-ranks seconds, theta at the end, the device buffers for reuse)."""
-        F = ops.num_features(d)
-        mat_pi0 = start_table(d)
-        idx = torch.as_tensor(np.random.RandomState(1234 + rank).randint(64, size=B).astype(np.int32), device=dev)
-        w = torch.as_tensor(np.random.RandomState(1).rand(F), device=dev)    # U[0,1)^F, mfg_ac2.py:176
-        theta = torch.tensor([theta0], dtype=torch.float64, device=dev)
-        G = torch.zeros(F + 3, dtype=torch.float64, device=dev)
-        ws = ops.workspace(B * T, d, dev)
-        bufs = {'pi_traj': torch.empty(B, T + 1, d, device=dev), 'reward': torch.empty(B, T, device=dev),
-                'delta': torch.empty(B, T, dtype=torch.float64, device=dev),
-                'g': torch.empty(B, T, dtype=torch.float64, device=dev)}
-        traj_offset = rank * B
+    def make_class(d, T, B_global, mode='rollout', precision='mixed'):
+        """The drop-in class on this rank: GLOBAL batch (the class shards it over the ranks of the default process group),
+        reference hyper-parameters (mfg_ac2.py:832), synthetic start table, w ~ U[0,1)^F (mfg_ac2.py:176)."""
+        from discrete_mean_field_game_amd.mfg_ac2 import actor_critic
+        np.random.seed(1)                                                # init_w draws from np.random
+        ac = actor_critic(theta=theta0, shift=shift, alpha_scale=alpha_scale, d=d, pi0=start_table64(d), batch=B_global,
+                          rng='philox', seed=2024, update_every=mode, precision=precision, episode_steps=T, verbose=0,
+                          device=dev)
+        ac._force_collective = bool(args.force_dist)
+        return ac
 
-        def one_step(k):
-            sc = 1.0 / (k + 1)
-            sa = 1.0 / ((k + 1) * np.log(np.log(k + 20)))                # mfg_ac2.py:514,522
-            # start-state gather (in-kernel) + fused rollout + batch sums; on one GPU the update rides in the same call
-            ops.train_rollout(mat_pi0, idx, T, theta, shift, alpha_scale, w, gamma, G, ws, bufs, lr_c * sc, lr_a * sa,
-                              apply=not multi, seed=2024, first_step=k * T, traj_offset=traj_offset, precision=precision)
-            if multi:
-                all_reduce_(G)                                           # one RCCL all-reduce per update
-                ops.apply_update(G, d, lr_c * sc, lr_a * sa, w, theta)
-
-        for k in range(warmup):
-            one_step(k)
+    def training_leg(d, T, B, steps, warmup, precision='mixed', mode='rollout'):
+        """`steps` timed episodes of actor_critic.train() (one update per episode in mode 'rollout', the reference's
+        per-step updates in mode 'step') with B trajectories PER RANK.  Returns (max-over-ranks seconds, theta at the end,
+        the class instance)."""
+        ac = make_class(d, T, B * world, mode, precision)
+        ac.train(num_episodes=warmup, gamma=gamma, constant=0, lr_critic=lr_c, lr_actor=lr_a, consecutive=10 ** 9)
         sync()
         t0 = time.perf_counter()
-        for k in range(warmup, warmup + steps):
-            one_step(k)
+        ac.train(num_episodes=steps, gamma=gamma, constant=0, lr_critic=lr_c, lr_actor=lr_a, consecutive=10 ** 9,
+                 first_episode=warmup)
         sync()
         elapsed = time.perf_counter() - t0
         if multi:
             te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             all_reduce_(te, op=dist.ReduceOp.MAX)
             elapsed = float(te[0])
-        theta_end = float(theta[0])
+        theta_end = float(np.ravel(ac.theta)[0])
         if not np.isfinite(theta_end):
             sys.exit('non-finite theta after the timed region')
-        return elapsed, theta_end, dict(mat_pi0=mat_pi0, idx=idx, w=w, theta=theta, G=G, ws=ws, bufs=bufs,
-                                        traj_offset=traj_offset)
+        return elapsed, theta_end, ac
+
+    def native_leg(d, T, B, steps, warmup, precision='mixed'):
+        """The same `steps` updates issued by ONE native call (mfg_train_rollouts: no interpreter between episodes), timed with
+        events on the launch stream: the GPU time of the kernels alone.  class wall time / this = how much of the class
+        API's time the GPU is busy (1.0 = not host bound).  Single rank only."""
+        F = ops.num_features(d)
+        mat = torch.as_tensor(start_table64(d).astype(np.float32), device=dev)
+        w = torch.as_tensor(np.random.RandomState(1).rand(F), device=dev)
+        theta = torch.tensor([theta0], dtype=torch.float64, device=dev)
+        G = torch.zeros(F + 3, dtype=torch.float64, device=dev)
+        ws = ops.workspace(B * T, d, dev)
+        bufs = {'pi_traj': torch.empty(B, T + 1, d, device=dev), 'pi_last': torch.empty(B, d, device=dev),
+                'reward': torch.empty(B, T, device=dev), 'delta': torch.empty(B, T, dtype=torch.float64, device=dev),
+                'g': torch.empty(B, T, dtype=torch.float64, device=dev)}
+        racc = torch.zeros(warmup + steps, dtype=torch.float64, device=dev)
+        run = lambda k, e0: ops.train_rollouts(mat, T, k, e0, False, theta, shift, alpha_scale, w, gamma, G, ws, bufs, lr_c, lr_a,
+                                               seed=2024, first_step=e0 * T, reward_acc=racc.data_ptr() + 8 * e0,
+                                               precision=precision)
+        run(warmup, 0)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run(steps, warmup)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3
 
     def event_time(fn, n, warm=2):
         for _ in range(warm):
@@ -278,25 +294,24 @@ def main():
     d, T = args.d, args.T
     # ---- headline leg.  strong scaling (default): the GLOBAL batch --batch is split over the ranks; weak: --batch per GPU
     B = args.batch // world if args.scaling == 'strong' else args.batch
-    elapsed, theta_end, st = training_leg(d, T, B, args.steps, args.warmup)
+    elapsed, theta_end, ac = training_leg(d, T, B, args.steps, args.warmup)
     value = world * B * T * args.steps / elapsed
+    del ac
     other = None
     c5 = None
     if world > 1:
         # the other scaling mode, same run (not the headline value)
         Bo = args.batch if args.scaling == 'strong' else args.batch // world
-        del st
-        eo, _, st = training_leg(d, T, Bo, args.steps, args.warmup)
+        eo, _, ac = training_leg(d, T, Bo, args.steps, args.warmup)
         other = {'scaling': 'weak' if args.scaling == 'strong' else 'strong', 'batch_per_gpu': Bo,
                  'value': world * Bo * T * args.steps / eo, 'ms_per_step': eo / args.steps * 1e3, 'unit': 'env-steps/s'}
-        del st
+        del ac
         # BASELINE config 5: d=256, T=40, global batch 131072 sharded over the ranks
         B5 = 131072 // world
-        e5, _, st5 = training_leg(256, 40, B5, 2, 1)
+        e5, _, ac = training_leg(256, 40, B5, 2, 1)
         c5 = {'workload': 'C5 d=256 T=40 global batch 131072 split over %d GPUs' % world, 'batch_per_gpu': B5,
               'value': world * B5 * 40 * 2 / e5, 'ms_per_step': e5 / 2 * 1e3, 'unit': 'env-steps/s', 'steps': 2}
-        del st5
-        st = None
+        del ac
 
     collective = None
     if multi:
@@ -304,16 +319,25 @@ def main():
         # [G_w | G_theta | sum r | count] (fp64, F+3 entries) and the replicated parameter update that follows it, timed
         # with events on the launch stream, every rank in lock-step
         Fc = ops.num_features(d)
+        # (a zero buffer with count 1/world: the sums stay zero and the count entry stays 1 however often it is reduced)
         Gc = torch.zeros(Fc + 3, dtype=torch.float64, device=dev)
-        Gc[Fc + 2] = 1.0
         wc = torch.zeros(Fc, dtype=torch.float64, device=dev)
         tc = torch.zeros(1, dtype=torch.float64, device=dev)
+
+        def exchange(update):
+            Gc[Fc + 2:].fill_(1.0 / world)                               # reset the count entry (it is summed too)
+            all_reduce_(Gc)
+            if update:
+                ops.apply_update(Gc, d, 0.0, 0.0, wc, tc)
         sync()
-        t_ar = event_time(lambda: all_reduce_(Gc), n=50, warm=10)
+        t_fill = event_time(lambda: Gc[Fc + 2:].fill_(1.0 / world), n=50, warm=10)
         sync()
-        t_upd = event_time(lambda: (all_reduce_(Gc), ops.apply_update(Gc, d, 0.0, 0.0, wc, tc)), n=50, warm=10)
+        t_ar = event_time(lambda: exchange(False), n=50, warm=10) - t_fill
         sync()
-        collective = {'backend': ('rccl (torch.distributed nccl)' if args.backend == 'nccl' else 'gloo, host staged (debug)'),
+        t_upd = event_time(lambda: exchange(True), n=50, warm=10) - t_fill
+        sync()
+        collective = {'backend': ('rccl (torch.distributed nccl)' if args.backend == 'nccl'
+                                  else 'gloo, staged through the host: wall time of a debug path, not a device collective'),
                       'world': world, 'payload_bytes': (Fc + 3) * 8, 'all_reduce_us': t_ar * 1e6,
                       'all_reduce_plus_apply_update_us': t_upd * 1e6}
 
@@ -326,7 +350,6 @@ def main():
         if not args.no_roofline:
             # the HBM-bound kernel of the path on THIS GPU: materialised actions of one rollout of the global batch
             # (B*T transitions, a 1.7 GB slab > L3 at the default size), the same leg at every N
-            st = None
             Br = args.batch if args.scaling == 'strong' else B
             gp = given_p_leg(d, Br, T)
             traffic, traffic_src = pmc_traffic('k_step_', d, T, Br)
@@ -344,19 +367,30 @@ def main():
             roofline['box_ceiling_GBs'] = {'torch_sum_read': xx.numel() * 4 / t_rd / 1e9,
                                            'torch_copy_read_plus_write': 2 * xx.numel() * 4 / t_cp / 1e9}
             del xx, yy
-            if world == 1:                                               # (a training leg on rank 0 alone would hang the others)
-                _, _, st = training_leg(d, T, B, 1, 1)
-                pi0 = ops.gather_start(st['mat_pi0'], st['idx'])
-                t_f = event_time(lambda: ops.rollout(pi0, T, st['theta'], shift, alpha_scale, w=st['w'], gamma=gamma, seed=7,
-                                                     traj_offset=st['traj_offset'], td=True, G=st['G'], ws=st['ws'],
-                                                     out=st['bufs']), n=10, warm=3)
+            if world == 1:                                               # (a leg on rank 0 alone would hang the other ranks)
+                F = ops.num_features(d)
+                idx = torch.as_tensor(np.random.RandomState(1234).randint(64, size=B).astype(np.int32), device=dev)
+                pi0 = ops.gather_start(start_table(d), idx)
+                th = torch.tensor([theta0], dtype=torch.float64, device=dev)
+                wv = torch.as_tensor(np.random.RandomState(1).rand(F), device=dev)
+                Gf = torch.zeros(F + 3, dtype=torch.float64, device=dev)
+                wsf = ops.workspace(B * T, d, dev)
+                bf = {'pi_traj': torch.empty(B, T + 1, d, device=dev), 'pi_last': torch.empty(B, d, device=dev),
+                      'reward': torch.empty(B, T, device=dev), 'delta': torch.empty(B, T, dtype=torch.float64, device=dev),
+                      'g': torch.empty(B, T, dtype=torch.float64, device=dev)}
+                t_f = event_time(lambda: ops.rollout(pi0, T, th, shift, alpha_scale, w=wv, gamma=gamma, seed=7, td=True, G=Gf,
+                                                     ws=wsf, out=bf), n=10, warm=3)
                 fused = {'kernel': ('k_core_small' if d <= 64 else 'k_core_large') + '<SAMPLE,TD,MIXED> + k_grad + k_reduce_partials',
                          'bound': 'valu/transcendental+rng (P stays on chip)', 'avg_launch_ms': t_f * 1e3,
                          'env_steps_per_s': B * T / t_f, 'hbm_algorithmic_GBs': B * T * bytes_per_step / t_f / 1e9}
                 fused.update(pmc_sq('k_core_', d, T, B))
-                del st, pi0
+                # host-boundness of the class API: the same updates issued by one native call, GPU time from events
+                t_native = native_leg(d, T, B, args.steps, args.warmup)
+                fused['native_loop_ms_per_step'] = t_native / args.steps * 1e3
+                fused['class_api_gpu_busy_frac'] = min(1.0, t_native / elapsed)
+                del pi0, idx, th, wv, Gf, wsf, bf
             if world == 1 and not args.no_configs:
-                configs = other_configs(training_leg, given_p_leg, d, T, B, args)
+                configs = other_configs(training_leg, native_leg, given_p_leg, d, T, B, args)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(d, args.cpu_seconds)
@@ -365,7 +399,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32 (f64 accumulate)',
             'data': 'synthetic',
-            'config': {'workload': 'forward-RL actor-critic training rollouts (mfg_ac2.train, update per rollout): '
+            'config': {'workload': 'actor_critic.train(update_every="rollout") of the drop-in class (mfg_ac2.train call surface; '
+                                   'device-side start draw every episode, one update per 15-step rollout): '
                                    'd=%d topics, T=%d, global batch %d = %d trajectories per GPU x %d'
                                    % (d, T, B * world, B, world),
                        'd': d, 'T': T, 'batch_per_gpu': B, 'global_batch': B * world,
@@ -388,10 +423,11 @@ def main():
         dist.destroy_process_group()
 
 
-def other_configs(training_leg, given_p_leg, d0, T0, B0, args):
-    """BASELINE.json's other configurations on this GPU, bounded (a few seconds each): fused training rollout time and
-    the given-P kernel's HBM rate per shape, AC_IRL.train (config 4) through the drop-in class, and the headline shape
-    in strict f64 precision."""
+def other_configs(training_leg, native_leg, given_p_leg, d0, T0, B0, args):
+    """BASELINE.json's other configurations on this GPU, bounded (a few seconds each).  Every training number is a timed
+    call of the drop-in class (actor_critic.train / AC_IRL.train); `class_api_gpu_busy_frac` = GPU time of the same updates
+    issued by one native call (events) / wall time of the class call.  Plus the given-P kernel's HBM rate per shape and the
+    headline shape in strict f64 precision."""
     import time as _t
     import numpy as np
     import torch
@@ -400,14 +436,17 @@ def other_configs(training_leg, given_p_leg, d0, T0, B0, args):
                                        ('C5 (1/8 share)', 256, 40, 16384, 2, 1)):
         try:
             e, _, st = training_leg(d, T, B, steps, warm)
+            del st
+            tn = native_leg(d, T, B, steps, warm)
             gp = given_p_leg(d, B, T if d <= 64 else 1, n_launch=20, warm=10)
             bps = 4 * (d * d + 2 * d + 1)
-            out.append({'config': name, 'd': d, 'T': T, 'batch': B, 'steps': steps, 'fused_ms_per_rollout': e / steps * 1e3,
-                        'fused_env_steps_per_s': B * T * steps / e,
+            out.append({'config': name + ': actor_critic.train(update_every="rollout"), class API', 'd': d, 'T': T, 'batch': B,
+                        'steps': steps, 'fused_ms_per_rollout': e / steps * 1e3,
+                        'fused_env_steps_per_s': B * T * steps / e, 'native_loop_ms_per_rollout': tn / steps * 1e3,
+                        'class_api_gpu_busy_frac': min(1.0, tn / e),
                         'fused_frac_of_hbm_line': B * T * steps / e * bps / 1e9 / HBM_PEAK_GBS,
                         'given_P_GBs': gp['achieved_GBs'], 'given_P_frac': gp['frac'], 'given_P_slab_GB': gp['slab_GB'],
                         'given_P_avg_launch_us': gp['avg_launch_us']})
-            del st
         except Exception as exc:  # informational: never fail the headline on it
             out.append({'config': name, 'error': repr(exc)})
     # strong-scaling shards of the headline batch on THIS GPU (what each rank of an N-GPU run executes per update before
@@ -421,28 +460,19 @@ def other_configs(training_leg, given_p_leg, d0, T0, B0, args):
             e, _, st = training_leg(d0, T0, b, 40, 10)
             sh.append({'gpus': n, 'batch_per_gpu': b, 'ms_per_update': e / 40 * 1e3, 'env_steps_per_s_per_gpu': b * T0 * 40 / e})
             del st
-        out.append({'config': 'strong-scaling shards of the headline batch, one GPU each (no collective)', 'd': d0, 'T': T0,
+        out.append({'config': 'strong-scaling shards of the headline batch through actor_critic.train, one GPU each (no collective)', 'd': d0, 'T': T0,
                     'shards': sh})
     except Exception as exc:
         out.append({'config': 'shards', 'error': repr(exc)})
     # reference semantics: theta and w move after EVERY env step (mfg_ac2.py:505-522), batch-mean gradient; the 15-step
     # episode is issued natively (mfg_train_episode: 15 x [fused step kernel | batch sums + update])
     try:
-        from discrete_mean_field_game_amd.mfg_ac2 import actor_critic
-        rs = np.random.RandomState(0)
-        mat = rs.dirichlet(np.ones(21), size=64)
         for Bs, episodes in ((65536, 20), (4096, 60)):
-            np.random.seed(5)
-            ac = actor_critic(d=21, pi0=mat, batch=Bs, seed=3, update_every='step', verbose=0)
-            ac.train(num_episodes=3, consecutive=10 ** 9)
-            torch.cuda.synchronize()
-            t0 = _t.perf_counter()
-            ac.train(num_episodes=episodes, consecutive=10 ** 9, first_episode=3)
-            torch.cuda.synchronize()
-            dt = _t.perf_counter() - t0
+            e, _, st = training_leg(21, 15, Bs, episodes, 3, mode='step')
+            del st
             out.append({'config': 'mfg_ac2.train, update per env step (reference semantics), class API', 'd': 21, 'T': 15,
-                        'batch': Bs, 'episodes': episodes, 'env_steps_per_s': Bs * 15 * episodes / dt,
-                        'ms_per_episode': dt / episodes * 1e3})
+                        'batch': Bs, 'episodes': episodes, 'env_steps_per_s': Bs * 15 * episodes / e,
+                        'ms_per_episode': e / episodes * 1e3})
     except Exception as exc:
         out.append({'config': 'mfg_ac2.train step mode', 'error': repr(exc)})
     # headline shape, strict f64 policy math

@@ -49,6 +49,7 @@ SIGNATURES = {
     'mfg_num_features': (_i64, [_i32]),
     'mfg_workspace_bytes': (_sz, [_i64, _i32]),
     'mfg_gather_start': (_i32, [_p, _i64, _p, _i64, _i32, _p, _p]),
+    'mfg_draw_start': (_i32, [_p, _i64, _i64, _i32, _u64, _u32, _u64, _p, _p, _p]),
     'mfg_alpha': (_i32, [_p, _i64, _i32, _p, _f64, _p, _p, _p]),
     'mfg_dirichlet_from_gamma': (_i32, [_p, _i64, _i32, _p, _p]),
     'mfg_sample_dirichlet': (_i32, [_p, _i64, _i32, _p, _f64, _f64, _u64, _u32, _u64, _i32, _p, _p]),
@@ -69,6 +70,10 @@ SIGNATURES = {
                                  _p, _p, _p, _p, _p, _p, _sz, _p]),
     'mfg_train_rollout': (_i32, [_p, _i64, _p, _i64, _i32, _i32, _p, _f64, _f64, _p, _f64, _i32, _u64, _u32, _u64, _i32, _f64,
                                  _f64, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    'mfg_train_rollouts': (_i32, [_p, _i64, _i64, _i32, _i32, _i64, _i64, _i32, _p, _f64, _f64, _p, _f64, _i32, _u64, _u32, _u64,
+                                  _i32, _f64, _f64, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    'mfg_train_episodes': (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _i64, _i64, _i32, _p, _f64, _f64, _p, _f64, _i32, _u64, _u32,
+                                  _u64, _i32, _f64, _f64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'mfg_policy_logpdf': (_i32, [_p, _p, _i64, _i32, _p, _i32, _f64, _f64, _f64, _f64, _p, _p]),
     'mfg_backward_value': (_i32, [_p, _i64, _i32, _i32, _p, _p, _p, _p]),
     'mfg_reward_net_forward': (_i32, [_p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p,

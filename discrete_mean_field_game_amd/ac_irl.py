@@ -196,9 +196,12 @@ class AC_IRL(actor_critic):
         list_reward = []
         episode = 0
         pi = None
-        draws = self._start_draws(shard, max_episodes, lookahead=(stop_criteria == -1))
+        device_draw = self._device_draw()       # batched Philox runs: start states drawn on the device (mfg_draw_start)
         for episode in range(1 + first_episode, first_episode + max_episodes + 1):
-            pi = ops.gather_start(self._mat_pi0_dev, next(draws))
+            if device_draw:
+                _, pi = ops.draw_start(self._mat_pi0_dev, Bl, self.seed, self._rng_step, shard.traj_offset)
+            else:
+                pi = ops.gather_start(self._mat_pi0_dev, self._draw_start(shard))       # ac_irl.py:655
             discount = 1.0
             total_reward = torch.zeros(1, dtype=torch.float64, device=self.device)
             sc, sa = lr_scales(episode, constant)          # lr/(episode+1) with the 1-indexed episode (:700)

@@ -19,6 +19,8 @@ struct CoreArgs {
   const float* pi0;         // [B,d]; or, with start_idx != NULL, the start-state table [num_start,d]
   const int32_t* start_idx; // [B] rows of the table (start-state gather folded into the kernel, mfg_ac2.py:466-469)
   int64_t num_start;        // rows of the table (start_idx != NULL): indices are clamped into [0, num_start)
+  int start_draw;           // != 0: pi0 is the table and the row of trajectory b is DRAWN in the kernel (start_draw_row,
+                            // mfg_device.h: Philox keyed by seed, first_step, global trajectory id); start_idx is ignored
   const float* pi_alpha;    // GIVEN: state the concentrations are computed from (NULL -> pi0)
   const float* P_in;        // GIVEN: [B,d,d]
   const float* pi_next_in;  // GIVEN: [B,d] (may be NULL when no delta is wanted)
@@ -73,6 +75,12 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
 int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st);
 int launch_core_large_f64(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st);
 int launch_core_large_mixed(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st);
+
+// row of a.pi0 that holds the start state of local trajectory b: drawn in the kernel, gathered through start_idx, or b itself
+__device__ __forceinline__ int64_t core_src_row(const CoreArgs& a, int64_t b) {
+  if (a.start_draw) return start_draw_row(a.seed, a.first_step, a.traj_offset + (uint64_t)b, a.num_start);
+  return a.start_idx ? start_row(a.start_idx[b], a.num_start) : b;
+}
 
 __device__ __forceinline__ double reward_term(int kind, double pii, double pj, double p) {
   // contribution of element (i,j) BEFORE the factor pi_i (kind 0) / -0.5 pi_i (kind 1)
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
     const int tlf = wv * G + t;
     if (b0f < a.B) {
       const int64_t bf = b0f + ((t < G && b0f + tlf < a.B) ? tlf : 0);
-      pi_first = a.pi0[(a.start_idx ? start_row(a.start_idx[bf], a.num_start) : bf) * d + i];
+      pi_first = a.pi0[core_src_row(a, bf) * d + i];
     }
   }
   if (want_v) {
@@ -447,7 +455,7 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
       if (tn < ntiles) {
         const int64_t b0n = tn * TB;
         const int64_t bn = b0n + ((t < G && b0n + tl < a.B) ? tl : 0);
-        pi_first = a.pi0[(a.start_idx ? start_row(a.start_idx[bn], a.num_start) : bn) * d + i];
+        pi_first = a.pi0[core_src_row(a, bn) * d + i];
       }
     }
     if (valid && a.pi_traj) a.pi_traj[b * (int64_t)(T + 1) * d + i] = pi_i;
@@ -983,10 +991,11 @@ void k_core_large(CoreArgs a) {
   const int64_t nw = (int64_t)gridDim.x * WAVES;
   for (int64_t b = (int64_t)blockIdx.x * WAVES + wv; b < a.B; b += nw) {
     float pc[R];
+    const int64_t row0 = core_src_row(a, b);
 #pragma unroll
     for (int m = 0; m < R; ++m) {
       const int c = lane + m * WAVE;
-      pc[m] = c < d ? a.pi0[(a.start_idx ? start_row(a.start_idx[b], a.num_start) : b) * d + c] : 0.0f;
+      pc[m] = c < d ? a.pi0[row0 * d + c] : 0.0f;
       if (c < d && a.pi_traj) a.pi_traj[b * (int64_t)(T + 1) * d + c] = pc[m];
     }
     double v_cur = 0.0, discount = 1.0;

@@ -605,6 +605,24 @@ __host__ __device__ __forceinline__ int64_t start_row(int32_t idx, int64_t num_s
   return r < 0 ? 0 : (r >= num_start ? num_start - 1 : r);
 }
 
+// Start-state draw on the device (mfg_ac2.py:466, ac_irl.py:655: idx_row = randint(num_start_samples), one per trajectory
+// and episode).  Batched runs draw it from the same counter-based generator as the actions, so no host RNG, no index
+// upload and -- with several ranks -- no broadcast sits in front of an episode:
+//   counter = (c0 = START_DRAW_ELEM, c1 = Philox step of the episode's FIRST env step, c2 | c3 = global trajectory id, draw
+//   block 0); row = floor(x * num_start / 2^32) with x the first word of the block (Lemire's multiply-shift; the bias is
+//   below num_start / 2^32).  START_DRAW_ELEM lies outside the element ids i*d + j < 512^2 of the action draws, so the
+//   streams never collide; keyed by the GLOBAL trajectory id the draw does not depend on launch geometry or world size.
+constexpr uint32_t START_DRAW_ELEM = 0xFFFFFFFFu;
+__host__ __device__ __forceinline__ int64_t start_draw_row(uint64_t seed, uint32_t step, uint64_t traj, int64_t num_start) {
+  u32x4 c;
+  c.x = START_DRAW_ELEM;
+  c.y = step;
+  c.z = (uint32_t)traj;
+  c.w = (uint32_t)(traj >> 32) & 0xFFFFu;
+  const u32x4 r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return (int64_t)(((uint64_t)r.x * (uint64_t)num_start) >> 32);
+}
+
 // k(i,j) for i <= j: row-major upper triangle (mfg_ac2.py:333).
 __host__ __device__ __forceinline__ int feat_idx(int i, int j, int d) { return i * d - (i * (i - 1)) / 2 + (j - i); }
 

@@ -78,6 +78,19 @@ __global__ void k_gather_start(const float* __restrict__ mat, int64_t num_start,
   }
 }
 
+// a9: the start-state draw itself (start_draw_row, mfg_device.h) as a launch of its own: idx[b] and / or the gathered rows
+__global__ void k_draw_start(const float* __restrict__ mat, int64_t num_start, int64_t B, int d, uint64_t seed, uint32_t step,
+                             uint64_t traj_offset, int32_t* __restrict__ idx_out, float* __restrict__ out) {
+  const int64_t n = out ? B * d : B;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = out ? e / d : e;
+    const int j = out ? (int)(e - b * d) : 0;
+    const int64_t row = start_draw_row(seed, step, traj_offset + (uint64_t)b, num_start);
+    if (idx_out && j == 0) idx_out[b] = (int32_t)row;
+    if (out) out[e] = mat[row * d + j];
+  }
+}
+
 __global__ void k_alpha(const float* __restrict__ pi, int64_t B, int d, const double* __restrict__ theta_p,
                         double shift, double* __restrict__ alpha, double* __restrict__ deriv) {
   const double theta = *theta_p;
@@ -2449,7 +2462,7 @@ static int reduce_core_sums(int d, int64_t B, double* G, int accumulate, void* w
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 11; }
+int mfg_abi_version(void) { return 12; }
 
 int mfg_init(void) {
   if (!htab_ptr()) return fail(MFG_ELAUNCH, "%s", "mfg_init: no HIP device / table initialisation failed");
@@ -2523,6 +2536,17 @@ int mfg_gather_start(const float* mat_pi0, int64_t num_start, const int32_t* idx
   hipLaunchKernelGGL(k_gather_start, dim3(grid_for(B * d, 256, 8)), dim3(256), 0, S(stream), mat_pi0, num_start, idx, B,
                      d, pi0);
   return check_launch("gather_start");
+}
+
+int mfg_draw_start(const float* mat_pi0, int64_t num_start, int64_t B, int d, uint64_t seed, uint32_t step, uint64_t traj_offset,
+                   int32_t* idx, float* pi0, mfg_stream_t stream) {
+  CHECK_BD();
+  REQUIRE(num_start > 0 && num_start <= 0x7FFFFFFF, "empty / oversized start-state table");
+  REQUIRE(idx || pi0, "nothing to write");
+  REQUIRE(!pi0 || mat_pi0, "null start-state table");
+  hipLaunchKernelGGL(k_draw_start, dim3(grid_for(pi0 ? B * d : B, 256, 8)), dim3(256), 0, S(stream), mat_pi0, num_start, B, d,
+                     seed, step, traj_offset, idx, pi0);
+  return check_launch("draw_start");
 }
 
 int mfg_alpha(const float* pi, int64_t B, int d, const double* theta, double shift, double* alpha, double* alpha_deriv,
@@ -2953,19 +2977,31 @@ int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, 
                      workspace_bytes, S(stream));
 }
 
-int mfg_train_rollout(const float* mat_pi0, int64_t num_start, const int32_t* idx, int64_t B, int d, int T, double* theta,
-                      double shift, double alpha_scale, double* w, double gamma, int reward_kind, uint64_t seed,
-                      uint32_t first_step, uint64_t traj_offset, int flags, double lr_critic, double lr_actor,
-                      float* pi_traj, float* pi_last, float* reward, double* delta, double* g, double* G,
-                      double* reward_acc, void* workspace, size_t workspace_bytes, mfg_stream_t stream) {
-  CHECK_BD();
-  REQUIRE(T >= 1, "T < 1");
-  REQUIRE(mat_pi0 && idx && num_start > 0, "null start-state table / index");
-  REQUIRE(theta && w && pi_traj && reward && delta && g && G && workspace, "null pointer");
-  REQUIRE(reward_kind == MFG_REWARD_MFG_AC2 || reward_kind == MFG_REWARD_SYNTHETIC, "needs an in-kernel reward");
+// learning-rate multipliers of the reference schedule in episode number `episode` (mfg_ac2.py:511-522: 1/(episode+1) and
+// 1/((episode+1) ln ln(episode+20)); ac_irl.py:697-708 with its 1-indexed episode); 1, 1 when `constant`.  The same
+// double arithmetic as parallel.lr_scales of the host classes (libm log), so native and per-episode runs agree bit for bit.
+static void lr_schedule(int64_t episode, int constant, double* sc, double* sa) {
+  if (constant) {
+    *sc = 1.0;
+    *sa = 1.0;
+    return;
+  }
+  const double e1 = (double)(episode + 1);
+  *sc = 1.0 / e1;
+  *sa = 1.0 / (e1 * log(log((double)(episode + 20))));
+}
+
+// one training update per episode: [rollout kernel (start rows: drawn in the kernel when idx == NULL, else gathered) |
+// values + delta (large d) | batch sums | row reduction (+ update)]
+static int train_rollout_impl(const float* mat_pi0, int64_t num_start, const int32_t* idx, int64_t B, int d, int T, double* theta,
+                              double shift, double alpha_scale, double* w, double gamma, int reward_kind, uint64_t seed,
+                              uint32_t first_step, uint64_t traj_offset, int flags, double lr_critic, double lr_actor,
+                              float* pi_traj, float* pi_last, float* reward, double* delta, double* g, double* G,
+                              double* reward_acc, void* workspace, size_t workspace_bytes, hipStream_t st) {
   CoreArgs a{};
   a.pi0 = mat_pi0;
   a.start_idx = idx;
+  a.start_draw = idx ? 0 : 1;
   a.num_start = num_start;
   a.theta = theta;
   a.w = w;
@@ -2988,24 +3024,62 @@ int mfg_train_rollout(const float* mat_pi0, int64_t num_start, const int32_t* id
   const int precision = (flags & MFG_ROLLOUT_F64) ? MFG_PRECISION_F64 : MFG_PRECISION_MIXED;
   const bool deferred = defer_values(d, B, T, pi_traj, workspace, workspace_bytes);
   if (deferred) a.w = nullptr;
-  int rc = launch_core(a, true, true, precision, S(stream));
+  int rc = launch_core(a, true, true, precision, st);
   if (rc != MFG_OK) return rc;
   if (deferred) {
-    rc = launch_values_and_delta(pi_traj, B, T, d, w, reward, gamma, a.discount_pow, delta, workspace, workspace_bytes, S(stream));
+    rc = launch_values_and_delta(pi_traj, B, T, d, w, reward, gamma, a.discount_pow, delta, workspace, workspace_bytes, st);
     if (rc != MFG_OK) return rc;
   }
   const ApplyArgs ap{lr_critic, lr_actor, w, theta, reward_acc};
   const bool want_apply = (flags & MFG_TRAIN_APPLY) != 0;
   bool applied = false;
-  rc = launch_grad(pi_traj, (int64_t)(T + 1) * d, delta, g, reward, B * T, T, d, G, 0, workspace, workspace_bytes, S(stream),
+  rc = launch_grad(pi_traj, (int64_t)(T + 1) * d, delta, g, reward, B * T, T, d, G, 0, workspace, workspace_bytes, st,
                    want_apply ? &ap : nullptr, &applied);
   if (rc != MFG_OK) return rc;
   if (want_apply && !applied) {
     const int64_t F = mfg_num_features(d);
-    hipLaunchKernelGGL(k_apply_update, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, S(stream), G, F, lr_critic, lr_actor,
-                       w, theta, reward_acc);
+    hipLaunchKernelGGL(k_apply_update, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, G, F, lr_critic, lr_actor, w, theta,
+                       reward_acc);
   }
   return check_launch("train_rollout");
+}
+
+#define CHECK_TRAIN_ROLLOUT()                                                                                        \
+  CHECK_BD();                                                                                                        \
+  REQUIRE(T >= 1, "T < 1");                                                                                          \
+  REQUIRE(mat_pi0 && num_start > 0 && num_start <= 0x7FFFFFFF, "null / empty / oversized start-state table");        \
+  REQUIRE(theta && w && pi_traj && reward && delta && g && G && workspace, "null pointer");                          \
+  REQUIRE(reward_kind == MFG_REWARD_MFG_AC2 || reward_kind == MFG_REWARD_SYNTHETIC, "needs an in-kernel reward")
+
+int mfg_train_rollout(const float* mat_pi0, int64_t num_start, const int32_t* idx, int64_t B, int d, int T, double* theta,
+                      double shift, double alpha_scale, double* w, double gamma, int reward_kind, uint64_t seed,
+                      uint32_t first_step, uint64_t traj_offset, int flags, double lr_critic, double lr_actor,
+                      float* pi_traj, float* pi_last, float* reward, double* delta, double* g, double* G,
+                      double* reward_acc, void* workspace, size_t workspace_bytes, mfg_stream_t stream) {
+  CHECK_TRAIN_ROLLOUT();
+  return train_rollout_impl(mat_pi0, num_start, idx, B, d, T, theta, shift, alpha_scale, w, gamma, reward_kind, seed, first_step,
+                            traj_offset, flags, lr_critic, lr_actor, pi_traj, pi_last, reward, delta, g, G, reward_acc, workspace,
+                            workspace_bytes, S(stream));
+}
+
+int mfg_train_rollouts(const float* mat_pi0, int64_t num_start, int64_t B, int d, int T, int64_t episodes, int64_t first_episode,
+                       int constant, double* theta, double shift, double alpha_scale, double* w, double gamma, int reward_kind,
+                       uint64_t seed, uint32_t first_step, uint64_t traj_offset, int flags, double lr_critic, double lr_actor,
+                       float* pi_traj, float* pi_last, float* reward, double* delta, double* g, double* G, double* reward_acc,
+                       void* workspace, size_t workspace_bytes, mfg_stream_t stream) {
+  CHECK_TRAIN_ROLLOUT();
+  REQUIRE(episodes >= 0 && first_episode >= 0, "bad episode range");
+  REQUIRE((uint64_t)first_step + (uint64_t)episodes * (uint64_t)T <= 0xFFFFFFFFull, "Philox step counter would wrap");
+  for (int64_t k = 0; k < episodes; ++k) {
+    double sc, sa;
+    lr_schedule(first_episode + k, constant, &sc, &sa);
+    const int rc = train_rollout_impl(mat_pi0, num_start, nullptr, B, d, T, theta, shift, alpha_scale, w, gamma, reward_kind, seed,
+                                      first_step + (uint32_t)(k * T), traj_offset, flags | MFG_TRAIN_APPLY, lr_critic * sc,
+                                      lr_actor * sa, pi_traj, pi_last, reward, delta, g, G, reward_acc ? reward_acc + k : nullptr,
+                                      workspace, workspace_bytes, S(stream));
+    if (rc != MFG_OK) return rc;
+  }
+  return MFG_OK;
 }
 
 int mfg_grad_accumulate(const float* pi, int64_t stride_b, double* delta, const double* g, const float* reward, int64_t B,
@@ -3039,17 +3113,11 @@ int mfg_grad_apply(const float* pi, int64_t stride_b, double* delta, const doubl
   return check_launch("grad_apply");
 }
 
-int mfg_train_episode(float* pi_io, float* pi_scratch, int64_t B, int d, int T, double* theta, double shift,
-                      double alpha_scale, double* w, double gamma, int reward_kind, uint64_t seed, uint32_t first_step,
-                      uint64_t traj_offset, int precision, double lr_critic, double lr_actor, float* reward, double* delta,
-                      double* g, double* G, double* reward_acc, void* workspace, size_t workspace_bytes,
-                      mfg_stream_t stream) {
-  CHECK_BD();
-  CHECK_PRECISION();
-  REQUIRE(T >= 1, "T < 1");
-  REQUIRE(pi_io && pi_scratch && theta && w && reward && delta && g && G && workspace, "null pointer");
-  REQUIRE(reward_kind == MFG_REWARD_MFG_AC2 || reward_kind == MFG_REWARD_SYNTHETIC, "needs an in-kernel reward");
-  hipStream_t st = S(stream);
+static int train_episode_impl(float* pi_io, float* pi_scratch, int64_t B, int d, int T, double* theta, double shift,
+                              double alpha_scale, double* w, double gamma, int reward_kind, uint64_t seed, uint32_t first_step,
+                              uint64_t traj_offset, int precision, double lr_critic, double lr_actor, float* reward,
+                              double* delta, double* g, double* G, double* reward_acc, void* workspace, size_t workspace_bytes,
+                              hipStream_t st) {
   float* cur = pi_io;
   float* nxt = pi_scratch;
   for (int s = 0; s < T; ++s) {
@@ -3096,6 +3164,48 @@ int mfg_train_episode(float* pi_io, float* pi_scratch, int64_t B, int d, int T, 
   if (cur != pi_io && hipMemcpyAsync(pi_io, cur, (size_t)B * d * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
     return fail(MFG_ELAUNCH, "%s", "train_episode: final state copy failed");
   return check_launch("train_episode");
+}
+
+
+#define CHECK_TRAIN_EPISODE()                                                                                      \
+  CHECK_BD();                                                                                                      \
+  CHECK_PRECISION();                                                                                               \
+  REQUIRE(T >= 1, "T < 1");                                                                                        \
+  REQUIRE(pi_io && pi_scratch && theta && w && reward && delta && g && G && workspace, "null pointer");            \
+  REQUIRE(reward_kind == MFG_REWARD_MFG_AC2 || reward_kind == MFG_REWARD_SYNTHETIC, "needs an in-kernel reward")
+
+int mfg_train_episode(float* pi_io, float* pi_scratch, int64_t B, int d, int T, double* theta, double shift,
+                      double alpha_scale, double* w, double gamma, int reward_kind, uint64_t seed, uint32_t first_step,
+                      uint64_t traj_offset, int precision, double lr_critic, double lr_actor, float* reward, double* delta,
+                      double* g, double* G, double* reward_acc, void* workspace, size_t workspace_bytes,
+                      mfg_stream_t stream) {
+  CHECK_TRAIN_EPISODE();
+  return train_episode_impl(pi_io, pi_scratch, B, d, T, theta, shift, alpha_scale, w, gamma, reward_kind, seed, first_step,
+                            traj_offset, precision, lr_critic, lr_actor, reward, delta, g, G, reward_acc, workspace,
+                            workspace_bytes, S(stream));
+}
+
+int mfg_train_episodes(const float* mat_pi0, int64_t num_start, float* pi_io, float* pi_scratch, int64_t B, int d, int T,
+                       int64_t episodes, int64_t first_episode, int constant, double* theta, double shift, double alpha_scale,
+                       double* w, double gamma, int reward_kind, uint64_t seed, uint32_t first_step, uint64_t traj_offset,
+                       int precision, double lr_critic, double lr_actor, float* reward, double* delta, double* g, double* G,
+                       double* reward_acc, void* workspace, size_t workspace_bytes, mfg_stream_t stream) {
+  CHECK_TRAIN_EPISODE();
+  REQUIRE(mat_pi0 && num_start > 0 && num_start <= 0x7FFFFFFF, "null / empty / oversized start-state table");
+  REQUIRE(episodes >= 0 && first_episode >= 0, "bad episode range");
+  REQUIRE((uint64_t)first_step + (uint64_t)episodes * (uint64_t)T <= 0xFFFFFFFFull, "Philox step counter would wrap");
+  for (int64_t k = 0; k < episodes; ++k) {
+    const uint32_t step0 = first_step + (uint32_t)(k * T);
+    hipLaunchKernelGGL(k_draw_start, dim3(grid_for(B * d, 256, 8)), dim3(256), 0, S(stream), mat_pi0, num_start, B, d, seed, step0,
+                       traj_offset, (int32_t*)nullptr, pi_io);
+    double sc, sa;
+    lr_schedule(first_episode + k, constant, &sc, &sa);
+    const int rc = train_episode_impl(pi_io, pi_scratch, B, d, T, theta, shift, alpha_scale, w, gamma, reward_kind, seed, step0,
+                                      traj_offset, precision, lr_critic * sc, lr_actor * sa, reward, delta, g, G,
+                                      reward_acc ? reward_acc + k : nullptr, workspace, workspace_bytes, S(stream));
+    if (rc != MFG_OK) return rc;
+  }
+  return MFG_OK;
 }
 
 int mfg_train_episode_irl(float* pi_io, float* pi_scratch, int64_t B, int d, int T, double* theta, double shift,

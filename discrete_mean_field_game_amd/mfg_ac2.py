@@ -16,6 +16,7 @@ mat_pi0, num_start_samples, mat_alpha, mat_alpha_deriv``.  Extensions are keywor
                                 so a seeded batch-1 run retraces the reference; the math still runs on
                                 the GPU
   precision         : 'mixed' (fp32 hardware transcendentals, fp64 sums; default) or 'f64' (strict)
+  episode_steps     : env steps per episode (reference: 15, mfg_ac2.py:478)
   update_every      : 'step' (reference semantics: theta, w move after every env step; batch-mean
                       gradient) or 'rollout' (one fused T-step kernel + one update per episode)
   group             : torch.distributed process group; the batch is the GLOBAL batch and is sharded
@@ -46,7 +47,7 @@ class actor_critic:
 
     def __init__(self, theta=8.86349, shift=0.16, alpha_scale=12000, d=21, *, pi0=None, path_to_dir=None,
                  batch=1, rng='philox', seed=0, update_every='step', reward='mfg_ac2', precision='mixed', device=None,
-                 group=None, verbose=1, check_finite=False):
+                 group=None, verbose=1, check_finite=False, episode_steps=EPISODE_STEPS):
         if rng not in ('philox', 'numpy'):
             raise ValueError("rng must be 'philox' or 'numpy'")
         if update_every not in ('step', 'rollout'):
@@ -72,6 +73,13 @@ class actor_critic:
         # check_finite=True train() verifies theta, w and the states after every episode and raises FloatingPointError
         self.check_finite = bool(check_finite)
         self.batch = int(batch)
+        # env steps per episode: the reference's loop runs `while num_steps < 15` (mfg_ac2.py:478); BASELINE's synthetic
+        # configurations C3 / C5 use T = 40
+        self.episode_steps = int(episode_steps)
+        if self.episode_steps < 1:
+            raise ValueError('episode_steps must be >= 1')
+        self._train_bufs = {}      # device buffers of train(), kept between calls (keyed by shape)
+        self._force_collective = False   # debug (bench.py --force-dist): take the multi-rank update path with one rank
         self._theta = torch.zeros(1, dtype=torch.float64, device=self.device)
         self._theta_is_array = False
         self.theta = theta
@@ -331,10 +339,17 @@ class actor_critic:
             f.write('\n')
 
     # ------------------------------------------------------------------ a9: train
+    def _device_draw(self):
+        """Whether train() draws the start states on the device.  The reference draws `np.random.randint(num_start)` per
+        episode (mfg_ac2.py:466); that is kept for the runs that retrace it -- batch 1, or rng='numpy'.  Batched Philox
+        runs (no reference counterpart) draw idx_b from the action sampler's counter-based generator, keyed by (seed,
+        episode's first Philox step, GLOBAL trajectory id): no host RNG, no index upload, no broadcast between ranks."""
+        return self.rng == 'philox' and self.batch > 1
+
     def _draw_start(self, shard):
-        """Start-state indices of this rank's trajectories.  The GLOBAL index vector is drawn from the process-global
-        legacy np.random stream (one scalar draw at batch 1, the reference's :466); with several ranks, rank 0's draw
-        is broadcast, so the ranks need not share a host seed, and every rank keeps its shard of it."""
+        """Host draw of the start-state indices (batch 1 / rng='numpy'): the GLOBAL index vector comes from the
+        process-global legacy np.random stream (one scalar draw at batch 1, the reference's :466); with several ranks,
+        rank 0's draw is broadcast, so the ranks need not share a host seed, and every rank keeps its shard of it."""
         if self.batch == 1:
             idx = np.array([np.random.randint(self.num_start_samples)])      # the reference's single draw (:466)
         else:
@@ -344,25 +359,6 @@ class actor_critic:
             idx = idx[shard.traj_offset:shard.traj_offset + shard.local_batch]
         return torch.as_tensor(idx.astype(np.int32), device=self.device)
 
-    def _start_draws(self, shard, num_episodes, lookahead=True):
-        """Iterator over the per-episode start-state index vectors (device int32 [local batch]).  The np.random draws
-        are the ones _draw_start makes, in the same order; with the in-kernel sampler nothing else consumes np.random
-        inside train(), so up to 16 episodes are drawn and uploaded in one host-to-device copy (the per-episode
-        synchronous copy left the GPU idle for ~50 us per episode at small batches).  `lookahead=False` (early stopping,
-        rng='numpy', several ranks) draws episode by episode."""
-        block = 16 if (lookahead and self.rng == 'philox' and shard.world == 1 and self.batch > 1) else 1
-        done = 0
-        while done < num_episodes:
-            k = min(block, num_episodes - done)
-            if k == 1:
-                yield self._draw_start(shard)
-            else:
-                idx = np.stack([np.random.randint(self.num_start_samples, size=self.batch) for _ in range(k)])
-                dev = torch.as_tensor(idx.astype(np.int32), device=self.device)
-                for r in range(k):
-                    yield dev[r]
-            done += k
-
     def train(self, num_episodes=4000, gamma=1, constant=0, lr_critic=0.1, lr_actor=0.001, consecutive=100,
               file_theta='results/theta.csv', file_pi='results/pi.csv', file_reward='results/reward.csv',
               write_file=0, write_all=0, *, first_episode=0):
@@ -370,99 +366,91 @@ class actor_critic:
         batch=1, rng='numpy', update_every='step' retraces the reference's seeded run.
         first_episode: episode number the 1/(episode+1) learning-rate schedule starts from (resume after
         load_state_dict)."""
-        d, T = self.d, EPISODE_STEPS
+        d, T = self.d, self.episode_steps
         shard = current_shard(self.batch, self.group)
         Bl = shard.local_batch
         if shard.world > self.batch:
             raise ValueError('batch=%d is smaller than the world size %d: every rank needs a trajectory'
                              % (self.batch, shard.world))
         F = ops.num_features(d)
-        G = torch.zeros(F + 3, dtype=torch.float64, device=self.device)
-        ws = ops.workspace(Bl * T, d, self.device)
+        # device buffers: allocated (and the workspace zeroed) once per shape, reused by later train() calls -- the outer
+        # loops of the IRL class and resumed runs call train() many times
+        key = ('train', Bl, T, d, str(self.device))
+        bufs = self._train_bufs.get(key)
+        if bufs is None:
+            self._train_bufs.clear()
+            bufs = {'G': torch.zeros(F + 3, dtype=torch.float64, device=self.device),
+                    'ws': ops.workspace(Bl * T, d, self.device)}
+            self._train_bufs[key] = bufs
+        G, ws = bufs['G'], bufs['ws']
+        # mean reward per update, one entry per episode (step mode: summed over the episode's T updates = the mean episode
+        # return; rollout mode: the mean over the B*T transitions of the one update, times T below)
         ep_reward = torch.zeros(max(num_episodes, 1), dtype=torch.float64, device=self.device)
+        ep_base = ep_reward.data_ptr()
+        ret_scale = float(T) if self.update_every == 'rollout' else 1.0
         window_start = 0
         pi = None
+        device_draw = self._device_draw()
         # per-step updates on one GPU: the whole episode is issued by native code (mfg_train_episode)
         native_episode = (self.update_every == 'step' and self.rng == 'philox' and shard.world == 1
-                          and self.trace is None and not write_all)
-        ebufs = ops.episode_buffers(Bl, d, self.device) if native_episode else None
+                          and not self._force_collective and self.trace is None and not write_all)
+        ebufs = None
+        if native_episode:
+            if 'episode' not in bufs:
+                bufs['episode'] = ops.episode_buffers(Bl, d, self.device)
+            ebufs = bufs['episode']
         fused_rollout = self.update_every == 'rollout' and self.rng == 'philox'
         if fused_rollout:
-            rbufs = {'pi_traj': torch.empty(Bl, T + 1, d, dtype=torch.float32, device=self.device),
-                     'pi_last': torch.empty(Bl, d, dtype=torch.float32, device=self.device),
-                     'reward': torch.empty(Bl, T, dtype=torch.float32, device=self.device),
-                     'delta': torch.empty(Bl, T, dtype=torch.float64, device=self.device),
-                     'g': torch.empty(Bl, T, dtype=torch.float64, device=self.device)}
-        draws = self._start_draws(shard, num_episodes)
-        for episode in range(num_episodes):
-            if write_all:
-                with open('temp.csv', 'a') as f:
-                    f.write('Episode %d \n\n' % episode)
-            idx = next(draws)
-            pi = None if fused_rollout else ops.gather_start(self._mat_pi0_dev, idx)
-            sc, sa = lr_scales(episode + first_episode, constant == 1)
-            if native_episode:
-                ops.train_episode(pi, T, self._theta, self.shift, self.alpha_scale, self._w, gamma, lr_critic * sc,
-                                  lr_actor * sa, G, ws, ebufs, reward_kind=self.reward_kind, seed=self.seed,
-                                  first_step=self._rng_step, traj_offset=shard.traj_offset,
-                                  reward_acc=ep_reward[episode:episode + 1], precision=self.precision)
-                self._rng_step += T
+            if 'rollout' not in bufs:
+                bufs['rollout'] = {'pi_traj': torch.empty(Bl, T + 1, d, dtype=torch.float32, device=self.device),
+                                   'pi_last': torch.empty(Bl, d, dtype=torch.float32, device=self.device),
+                                   'reward': torch.empty(Bl, T, dtype=torch.float32, device=self.device),
+                                   'delta': torch.empty(Bl, T, dtype=torch.float64, device=self.device),
+                                   'g': torch.empty(Bl, T, dtype=torch.float64, device=self.device)}
+            rbufs = bufs['rollout']
+        # one GPU, start states drawn on the device, nothing for the host to do between two episodes: ALL episodes up to
+        # the next report are issued by one native call (mfg_train_rollouts / mfg_train_episodes: the draw, the learning-rate
+        # schedule and the episode loop itself run without the interpreter)
+        multi = shard.world > 1 or self._force_collective
+        native_loop = (device_draw and not multi and (fused_rollout or native_episode) and self.trace is None
+                       and not write_all and not self.check_finite)
+        if native_episode and device_draw:
+            if 'pi_ep' not in bufs:
+                bufs['pi_ep'] = torch.empty(Bl, d, dtype=torch.float32, device=self.device)
+            pi_ep = bufs['pi_ep']
+        episode = 0
+        while episode < num_episodes:
+            if native_loop:
+                # episodes episode .. last, `last` = the next reporting episode (episode % consecutive == 0) or the final one
+                last = episode if episode % consecutive == 0 else (episode // consecutive + 1) * consecutive
+                last = min(last, num_episodes - 1)
+                k = last - episode + 1
+                if fused_rollout:
+                    ops.train_rollouts(self._mat_pi0_dev, T, k, episode + first_episode, constant == 1, self._theta, self.shift,
+                                       self.alpha_scale, self._w, gamma, G, ws, rbufs, lr_critic, lr_actor,
+                                       reward_kind=self.reward_kind, seed=self.seed, first_step=self._rng_step,
+                                       traj_offset=shard.traj_offset, reward_acc=ep_base + 8 * episode,
+                                       precision=self.precision)
+                    pi = rbufs['pi_last']
+                else:
+                    ops.train_episodes(self._mat_pi0_dev, pi_ep, T, k, episode + first_episode, constant == 1, self._theta,
+                                       self.shift, self.alpha_scale, self._w, gamma, lr_critic, lr_actor, G, ws, ebufs,
+                                       reward_kind=self.reward_kind, seed=self.seed, first_step=self._rng_step,
+                                       traj_offset=shard.traj_offset, reward_acc=ep_base + 8 * episode,
+                                       precision=self.precision)
+                    pi = pi_ep
+                self._rng_step += k * T
                 self._theta_is_array = True
-            elif fused_rollout:
-                # start-state gather + fused T-step rollout + batch sums (+ the update itself on one GPU): 2-3 launches
-                single = shard.world == 1
-                ops.train_rollout(self._mat_pi0_dev, idx, T, self._theta, self.shift, self.alpha_scale, self._w, gamma, G,
-                                  ws, rbufs, lr_critic * sc, lr_actor * sa, apply=single, reward_kind=self.reward_kind,
-                                  seed=self.seed, first_step=self._rng_step, traj_offset=shard.traj_offset,
-                                  reward_acc=ep_reward[episode:episode + 1], precision=self.precision)
-                self._rng_step += T
-                if not single:
-                    all_reduce_gradients_(G, self.group)
-                    ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta,
-                                     ep_reward[episode:episode + 1])
-                pi = rbufs['pi_last']
-                self._theta_is_array = True
-                if self.trace is not None:
-                    self.trace.append(float(self._theta.cpu()[0]))
+                episode = last
             else:
-                for step in range(T):
-                    if self.rng == 'philox':
-                        out = ops.rollout(pi, 1, self._theta, self.shift, self.alpha_scale, w=self._w, gamma=gamma,
-                                          reward_kind=self.reward_kind, seed=self.seed, first_step=self._rng_step,
-                                          traj_offset=shard.traj_offset, td=True, G=G, ws=ws, precision=self.precision,
-                                          accumulate=(self.update_every == 'rollout' and step > 0))
-                        self._rng_step += 1
-                        pi_next = out['pi_last']
-                    else:
-                        P = self._sample(pi, shard.traj_offset, snapshot=False)
-                        if write_all:
-                            self._write_all(pi, P, step + 1)
-                        pi_next, r = ops.step_given_P(pi, P, reward_kind=self.reward_kind)
-                        ops.td_pg_accumulate(pi, pi_next, P, r, self._w, self._theta, self.shift, gamma, G=G, ws=ws,
-                                             precision=self.precision,
-                                             accumulate=(self.update_every == 'rollout' and step > 0))
-                    if self.update_every == 'step':
-                        all_reduce_gradients_(G, self.group)
-                        ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta,
-                                         ep_reward[episode:episode + 1])
-                        self._theta_is_array = True
-                        if self.trace is not None:
-                            self.trace.append(float(self._theta.cpu()[0]))
-                    pi = pi_next
-                if self.update_every == 'rollout':
-                    all_reduce_gradients_(G, self.group)
-                    ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta,
-                                     ep_reward[episode:episode + 1])
-                    self._theta_is_array = True
-                    if self.trace is not None:
-                        self.trace.append(float(self._theta.cpu()[0]))
-            if self.update_every == 'rollout':
-                ep_reward[episode] *= T            # mean over B*T transitions -> mean episode return
+                pi = self._train_one_episode(episode, shard, device_draw, native_episode, fused_rollout, G, ws, ebufs,
+                                             rbufs if fused_rollout else None, ep_base + 8 * episode, gamma, constant,
+                                             lr_critic, lr_actor, first_episode, write_all)
             if self.check_finite:
                 self._raise_if_not_finite(pi, episode)
             if episode % consecutive == 0:
                 # the reference divides the sum over the window by `consecutive` even at episode 0 (:530-534)
-                reward_avg = float(ep_reward[window_start:episode + 1].sum().cpu()) / consecutive
+                reward_avg = float(ep_reward[window_start:episode + 1].sum().cpu()) * ret_scale / consecutive
                 window_start = episode + 1
                 pi_host = pi[0].cpu().numpy().astype(np.float64)
                 if self.verbose:
@@ -474,8 +462,80 @@ class actor_critic:
                     self.train_log(pi_host, file_pi, '%.3e')
                     self.train_log(np.array([reward_avg]), file_reward, '%.3e')
                     self._train_log_extra()
+            episode += 1
         self._last_pi = pi
         self._check_status()
+
+    def _train_one_episode(self, episode, shard, device_draw, native_episode, fused_rollout, G, ws, ebufs, rbufs, reward_acc,
+                           gamma, constant, lr_critic, lr_actor, first_episode, write_all):
+        """One episode of train() issued from Python: the multi-rank path (an all-reduce sits between the batch sums and
+        the update), runs that record a trace / check finiteness / write every step, and the reference-RNG modes.
+        reward_acc: device address of this episode's entry of the return accumulator.  Returns the final states."""
+        d, T = self.d, self.episode_steps
+        Bl = shard.local_batch
+        if write_all:
+            with open('temp.csv', 'a') as f:
+                f.write('Episode %d \n\n' % episode)
+        sc, sa = lr_scales(episode + first_episode, constant == 1)
+        if fused_rollout:
+            # start states (drawn in the kernel, or gathered from the host draw) + fused T-step rollout + batch sums
+            # (+ the update itself on one GPU): 2-3 launches
+            idx = None if device_draw else self._draw_start(shard)
+            single = shard.world == 1 and not self._force_collective
+            ops.train_rollout(self._mat_pi0_dev, idx, T, self._theta, self.shift, self.alpha_scale, self._w, gamma, G,
+                              ws, rbufs, lr_critic * sc, lr_actor * sa, apply=single, reward_kind=self.reward_kind,
+                              seed=self.seed, first_step=self._rng_step, traj_offset=shard.traj_offset,
+                              reward_acc=reward_acc, precision=self.precision)
+            self._rng_step += T
+            if not single:
+                all_reduce_gradients_(G, self.group, self._force_collective)       # the ONE exchange of an update
+                ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta, reward_acc)
+            self._theta_is_array = True
+            if self.trace is not None:
+                self.trace.append(float(self._theta.cpu()[0]))
+            return rbufs['pi_last']
+        if device_draw:
+            _, pi = ops.draw_start(self._mat_pi0_dev, Bl, self.seed, self._rng_step, shard.traj_offset)
+        else:
+            pi = ops.gather_start(self._mat_pi0_dev, self._draw_start(shard))
+        if native_episode:
+            ops.train_episode(pi, T, self._theta, self.shift, self.alpha_scale, self._w, gamma, lr_critic * sc,
+                              lr_actor * sa, G, ws, ebufs, reward_kind=self.reward_kind, seed=self.seed,
+                              first_step=self._rng_step, traj_offset=shard.traj_offset,
+                              reward_acc=reward_acc, precision=self.precision)
+            self._rng_step += T
+            self._theta_is_array = True
+            return pi
+        for step in range(T):
+            if self.rng == 'philox':
+                out = ops.rollout(pi, 1, self._theta, self.shift, self.alpha_scale, w=self._w, gamma=gamma,
+                                  reward_kind=self.reward_kind, seed=self.seed, first_step=self._rng_step,
+                                  traj_offset=shard.traj_offset, td=True, G=G, ws=ws, precision=self.precision,
+                                  accumulate=(self.update_every == 'rollout' and step > 0))
+                self._rng_step += 1
+                pi_next = out['pi_last']
+            else:
+                P = self._sample(pi, shard.traj_offset, snapshot=False)
+                if write_all:
+                    self._write_all(pi, P, step + 1)
+                pi_next, r = ops.step_given_P(pi, P, reward_kind=self.reward_kind)
+                ops.td_pg_accumulate(pi, pi_next, P, r, self._w, self._theta, self.shift, gamma, G=G, ws=ws,
+                                     precision=self.precision,
+                                     accumulate=(self.update_every == 'rollout' and step > 0))
+            if self.update_every == 'step':
+                all_reduce_gradients_(G, self.group, self._force_collective)
+                ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta, reward_acc)
+                self._theta_is_array = True
+                if self.trace is not None:
+                    self.trace.append(float(self._theta.cpu()[0]))
+            pi = pi_next
+        if self.update_every == 'rollout':
+            all_reduce_gradients_(G, self.group, self._force_collective)
+            ops.apply_update(G, d, lr_critic * sc, lr_actor * sa, self._w, self._theta, reward_acc)
+            self._theta_is_array = True
+            if self.trace is not None:
+                self.trace.append(float(self._theta.cpu()[0]))
+        return pi
 
     def _check_status(self):
         """Raise MfgError if a launch of this run reported a numeric-range condition (mixed-precision sampling with

@@ -27,7 +27,11 @@ def _chk_f64(t, name):
 
 
 def _ptr(t):
-    return None if t is None else t.data_ptr()
+    """Device address of a tensor; None -> NULL; a plain int is taken as an address already (e.g. one entry of a
+    per-episode accumulator array: base.data_ptr() + 8 * k, without building a tensor view per episode)."""
+    if t is None or isinstance(t, int):
+        return t
+    return t.data_ptr()
 
 
 def init():
@@ -73,6 +77,18 @@ def gather_start(mat_pi0, idx):
     L.check(L.lib().mfg_gather_start(mat_pi0.data_ptr(), mat_pi0.shape[0], idx.data_ptr(), B, d, out.data_ptr(),
                                      _stream()), 'mfg_gather_start')
     return out
+
+
+def draw_start(mat_pi0, B, seed, step, traj_offset=0, want_idx=False, want_pi0=True):
+    """Start states of B trajectories drawn on the device (mfg_draw_start: Philox keyed by seed, the episode's first
+    step, the global trajectory id).  Returns (idx int32 [B] | None, pi0 [B,d] | None)."""
+    _chk_f32(mat_pi0, 'mat_pi0')
+    d = mat_pi0.shape[1]
+    idx = torch.empty(B, dtype=torch.int32, device=mat_pi0.device) if want_idx else None
+    pi0 = torch.empty(B, d, dtype=torch.float32, device=mat_pi0.device) if want_pi0 else None
+    L.check(L.lib().mfg_draw_start(mat_pi0.data_ptr(), mat_pi0.shape[0], int(B), d, int(seed), int(step), int(traj_offset),
+                                   _ptr(idx), _ptr(pi0), _stream()), 'mfg_draw_start')
+    return idx, pi0
 
 
 def alpha(pi, theta, shift, want_alpha=True, want_deriv=True):
@@ -228,21 +244,44 @@ def train_rollout(mat_pi0, idx, T, theta, shift, alpha_scale, w, gamma, G, ws, b
                   reward_acc=None, precision='mixed'):
     """One training update per episode: start-state gather (inside the kernel) + fused T-step TD rollout + batch sums
     [+ parameter update when apply=True (single GPU)].  bufs = dict(pi_traj [B,T+1,d], pi_last [B,d] | None,
-    reward [B,T], delta [B,T], g [B,T])."""
+    reward [B,T], delta [B,T], g [B,T]).  idx=None: the start rows are drawn inside the rollout kernel."""
     _chk_f32(mat_pi0, 'mat_pi0'); _chk_f64(theta, 'theta'); _chk_f64(w, 'w'); _chk_f64(G, 'G')
-    if idx.dtype != torch.int32 or not idx.is_cuda:
-        raise ValueError('idx must be an int32 CUDA tensor')
-    B, d = idx.numel(), mat_pi0.shape[1]
+    if idx is not None and (idx.dtype != torch.int32 or not idx.is_cuda):
+        raise ValueError('idx must be an int32 CUDA tensor (or None: start states drawn in the kernel)')
+    B, d = bufs['pi_traj'].shape[0], mat_pi0.shape[1]
+    if idx is not None and idx.numel() != B:
+        raise ValueError('idx must have one entry per trajectory of the buffers')
     flags = (L.TRAIN_APPLY if apply else 0) | (L.ROLLOUT_DISCOUNT_POW if discount_pow else 0)
     if L.PRECISIONS[precision] == L.PRECISION_F64:
         flags |= L.ROLLOUT_F64
-    L.check(L.lib().mfg_train_rollout(mat_pi0.data_ptr(), mat_pi0.shape[0], idx.data_ptr(), B, d, int(T), theta.data_ptr(),
+    L.check(L.lib().mfg_train_rollout(mat_pi0.data_ptr(), mat_pi0.shape[0], _ptr(idx), B, d, int(T), theta.data_ptr(),
                                       float(shift), float(alpha_scale), w.data_ptr(), float(gamma), int(reward_kind),
                                       int(seed), int(first_step), int(traj_offset), flags, float(lr_critic),
                                       float(lr_actor), bufs['pi_traj'].data_ptr(), _ptr(bufs.get('pi_last')),
                                       bufs['reward'].data_ptr(), bufs['delta'].data_ptr(), bufs['g'].data_ptr(),
                                       G.data_ptr(), _ptr(reward_acc), ws.data_ptr(), ws.numel() * 8, _stream()),
             'mfg_train_rollout')
+    return bufs
+
+
+def train_rollouts(mat_pi0, T, episodes, first_episode, constant, theta, shift, alpha_scale, w, gamma, G, ws, bufs, lr_critic,
+                   lr_actor, reward_kind=L.REWARD_MFG_AC2, seed=0, first_step=0, traj_offset=0, discount_pow=False,
+                   reward_acc=None, precision='mixed'):
+    """`episodes` training updates (one per episode) issued back to back by native code: start states drawn in the kernel,
+    fused T-step rollout, batch sums, update with the reference's learning-rate schedule in episode numbers
+    first_episode, first_episode + 1, ...  reward_acc: fp64 device array [episodes] (or an address), entry k += mean reward
+    of episode k's update."""
+    _chk_f32(mat_pi0, 'mat_pi0'); _chk_f64(theta, 'theta'); _chk_f64(w, 'w'); _chk_f64(G, 'G')
+    B, d = bufs['pi_traj'].shape[0], mat_pi0.shape[1]
+    flags = L.ROLLOUT_DISCOUNT_POW if discount_pow else 0
+    if L.PRECISIONS[precision] == L.PRECISION_F64:
+        flags |= L.ROLLOUT_F64
+    L.check(L.lib().mfg_train_rollouts(mat_pi0.data_ptr(), mat_pi0.shape[0], B, d, int(T), int(episodes), int(first_episode),
+                                       int(bool(constant)), theta.data_ptr(), float(shift), float(alpha_scale), w.data_ptr(),
+                                       float(gamma), int(reward_kind), int(seed), int(first_step), int(traj_offset), flags,
+                                       float(lr_critic), float(lr_actor), bufs['pi_traj'].data_ptr(), _ptr(bufs.get('pi_last')),
+                                       bufs['reward'].data_ptr(), bufs['delta'].data_ptr(), bufs['g'].data_ptr(), G.data_ptr(),
+                                       _ptr(reward_acc), ws.data_ptr(), ws.numel() * 8, _stream()), 'mfg_train_rollouts')
     return bufs
 
 
@@ -285,6 +324,23 @@ def train_episode(pi, T, theta, shift, alpha_scale, w, gamma, lr_critic, lr_acto
                                       float(lr_critic), float(lr_actor), bufs['reward'].data_ptr(),
                                       bufs['delta'].data_ptr(), bufs['g'].data_ptr(), G.data_ptr(), _ptr(reward_acc),
                                       ws.data_ptr(), ws.numel() * 8, _stream()), 'mfg_train_episode')
+    return pi
+
+
+def train_episodes(mat_pi0, pi, T, episodes, first_episode, constant, theta, shift, alpha_scale, w, gamma, lr_critic, lr_actor,
+                   G, ws, bufs, reward_kind=L.REWARD_MFG_AC2, seed=0, first_step=0, traj_offset=0, reward_acc=None,
+                   precision='mixed'):
+    """`episodes` x [start states drawn on the device into `pi` | T env steps with per-step updates], issued natively
+    (single GPU); learning rates per episode as in train_rollouts.  `pi` [B,d] holds the last episode's final states."""
+    _chk_f32(mat_pi0, 'mat_pi0'); _chk_f32(pi, 'pi'); _chk_f64(theta, 'theta'); _chk_f64(w, 'w')
+    B, d = pi.shape
+    L.check(L.lib().mfg_train_episodes(mat_pi0.data_ptr(), mat_pi0.shape[0], pi.data_ptr(), bufs['scratch'].data_ptr(), B, d,
+                                       int(T), int(episodes), int(first_episode), int(bool(constant)), theta.data_ptr(),
+                                       float(shift), float(alpha_scale), w.data_ptr(), float(gamma), int(reward_kind), int(seed),
+                                       int(first_step), int(traj_offset), L.PRECISIONS[precision], float(lr_critic),
+                                       float(lr_actor), bufs['reward'].data_ptr(), bufs['delta'].data_ptr(),
+                                       bufs['g'].data_ptr(), G.data_ptr(), _ptr(reward_acc), ws.data_ptr(), ws.numel() * 8,
+                                       _stream()), 'mfg_train_episodes')
     return pi
 
 

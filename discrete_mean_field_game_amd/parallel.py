@@ -43,10 +43,12 @@ def current_shard(global_batch: int, group=None) -> Shard:
     return shard_batch(global_batch, 0, 1)
 
 
-def all_reduce_gradients_(G: torch.Tensor, group=None) -> torch.Tensor:
+def all_reduce_gradients_(G: torch.Tensor, group=None, force: bool = False) -> torch.Tensor:
     """In-place SUM of the fused gradient buffer over all ranks (no-op for a single process).
-    The count entry G[F+2] is summed too, so dividing by it afterwards gives the global batch mean."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    The count entry G[F+2] is summed too, so dividing by it afterwards gives the global batch mean.
+    force: issue the collective also on a 1-rank communicator (bench.py --force-dist: the RCCL call of the multi-GPU
+    update executed on a 1-GPU box)."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         if G.is_cuda and dist.get_backend(group) != 'nccl':
             # gloo (CPU tests, several ranks sharing one GPU): no device collectives on this build, stage the 2 KB
             # buffer through the host; production runs use RCCL ("nccl") on the device tensor directly

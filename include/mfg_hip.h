@@ -105,6 +105,18 @@ size_t mfg_workspace_bytes(int64_t N, int d);
 int mfg_gather_start(const float* mat_pi0, int64_t num_start, const int32_t* idx, int64_t B, int d,
                      float* pi0, mfg_stream_t stream);
 
+/* a9 on the device: the per-episode start-state draw  idx_row = randint(num_start_samples)  (mfg_ac2.py:466, ac_irl.py:655)
+ * for B trajectories, from the counter-based generator of the action sampler instead of the host's np.random:
+ *   Philox4x32-10, key = seed, counter = (0xFFFFFFFF, step, low 32 bits of the global trajectory id traj_offset + b,
+ *   bits 32..47 of that id), x = first output word;  idx[b] = floor(x * num_start / 2^32)  (multiply-shift).
+ * `step` = the Philox step of the episode's first env step, so an episode's draw and its actions share one counter space
+ * (element id 0xFFFFFFFF is outside the action draws' i*d + j) and nothing but (seed, step, trajectory id) enters: the
+ * draw does not depend on launch geometry or world size, and a resumed run redraws the same states.
+ * Writes idx[B] (int32) and / or the gathered rows pi0[B,d] = mat_pi0[idx[b],:]; either may be NULL (mat_pi0 is only
+ * needed for pi0).  The training entry points below draw the same rows inside their first kernel. */
+int mfg_draw_start(const float* mat_pi0, int64_t num_start, int64_t B, int d, uint64_t seed, uint32_t step,
+                   uint64_t traj_offset, int32_t* idx, float* pi0, mfg_stream_t stream);
+
 /* a1: alpha[b,i,j] = softplus(theta (pi_j - pi_i - shift)) and its theta-derivative
  * (mfg_ac2.py:219-234; ac_irl.py:573-588).  Outputs fp64 [B,d,d]; either may be NULL. */
 int mfg_alpha(const float* pi, int64_t B, int d, const double* theta, double shift, double* alpha,
@@ -182,13 +194,29 @@ int mfg_rollout(const float* pi0, int64_t B, int d, int T, const double* theta, 
  * mfg_rollout, plus MFG_TRAIN_APPLY: also apply w += lr_critic G_w/N, theta += lr_actor G_theta/N and add the mean
  * reward to *reward_acc (if not NULL) inside the launch that finishes the sums -- a single-GPU update is then 2-3
  * launches.  Without MFG_TRAIN_APPLY G is complete on return: multi-GPU jobs all-reduce it and call mfg_apply_update.
- * Outputs as for mfg_rollout (pi_traj, reward, delta, g are required; pi_last may be NULL). */
+ * Outputs as for mfg_rollout (pi_traj, reward, delta, g are required; pi_last may be NULL).
+ * idx == NULL: the start rows are DRAWN inside the rollout kernel (mfg_draw_start with step = first_step) -- batched runs
+ * need no host RNG, no index upload and, with several ranks, no broadcast in front of an episode. */
 #define MFG_TRAIN_APPLY 16
 int mfg_train_rollout(const float* mat_pi0, int64_t num_start, const int32_t* idx, int64_t B, int d, int T, double* theta,
                       double shift, double alpha_scale, double* w, double gamma, int reward_kind, uint64_t seed,
                       uint32_t first_step, uint64_t traj_offset, int flags, double lr_critic, double lr_actor,
                       float* pi_traj, float* pi_last, float* reward, double* delta, double* g, double* G,
                       double* reward_acc, void* workspace, size_t workspace_bytes, mfg_stream_t stream);
+
+/* a9, the episode loop itself (mfg_ac2.py:460-526 with one update per episode): `episodes` training updates issued back to
+ * back from native code -- per episode k: start states drawn in the rollout kernel (Philox step first_step + k T), fused
+ * T-step TD rollout, batch sums, update with the reference's learning-rate schedule evaluated natively:
+ *   e = first_episode + k;  constant != 0: lr_critic, lr_actor;  else lr_critic / (e+1), lr_actor / ((e+1) ln ln (e+20))
+ * (mfg_ac2.py:511-522; pass the 1-indexed episode number for ac_irl.py:697-708), mean reward of the update added to
+ * reward_acc[k] (may be NULL).  flags as for mfg_train_rollout (MFG_TRAIN_APPLY implied).  Single GPU: between two
+ * episodes of a multi-GPU job sits an all-reduce, which stays with the caller (mfg_train_rollout per episode).
+ * The output buffers hold the LAST episode's values on return. */
+int mfg_train_rollouts(const float* mat_pi0, int64_t num_start, int64_t B, int d, int T, int64_t episodes, int64_t first_episode,
+                       int constant, double* theta, double shift, double alpha_scale, double* w, double gamma, int reward_kind,
+                       uint64_t seed, uint32_t first_step, uint64_t traj_offset, int flags, double lr_critic, double lr_actor,
+                       float* pi_traj, float* pi_last, float* reward, double* delta, double* g, double* G, double* reward_acc,
+                       void* workspace, size_t workspace_bytes, mfg_stream_t stream);
 
 /* f1 (IRL): reward[b] = r_net(state_b, action_b), the reward network of networks.py:46-81 evaluated for B
  * transitions in one launch (ac_irl.py:683 evaluates it with batch 1 per env step).  fp32.  Weight layouts are
@@ -239,6 +267,15 @@ int mfg_train_episode(float* pi_io, float* pi_scratch, int64_t B, int d, int T, 
                       uint64_t traj_offset, int precision, double lr_critic, double lr_actor, float* reward, double* delta,
                       double* g, double* G, double* reward_acc, void* workspace, size_t workspace_bytes,
                       mfg_stream_t stream);
+
+/* a9, the episode loop with the reference's per-step updates (mfg_ac2.py:460-526): `episodes` x [start states drawn on the
+ * device into pi_io (mfg_draw_start, step = first_step + k T) | mfg_train_episode], learning rates per episode as in
+ * mfg_train_rollouts, reward_acc[k] += mean reward of every step's update of episode k (may be NULL).  Single GPU. */
+int mfg_train_episodes(const float* mat_pi0, int64_t num_start, float* pi_io, float* pi_scratch, int64_t B, int d, int T,
+                       int64_t episodes, int64_t first_episode, int constant, double* theta, double shift, double alpha_scale,
+                       double* w, double gamma, int reward_kind, uint64_t seed, uint32_t first_step, uint64_t traj_offset,
+                       int precision, double lr_critic, double lr_actor, float* reward, double* delta, double* g, double* G,
+                       double* reward_acc, void* workspace, size_t workspace_bytes, mfg_stream_t stream);
 
 /* Weights of the reward network of networks.py:46-81 as device pointers (layouts as for mfg_reward_net_forward). */
 typedef struct mfg_reward_net {

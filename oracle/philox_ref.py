@@ -50,3 +50,15 @@ def philox_elem(seed, elem, step, traj, block):
 def u01(r):
     """(0,1] float32 from the top 24 bits (csrc/mfg_device.h::u01)."""
     return ((r >> np.uint32(8)).astype(np.float64) * 2.0 ** -24 + 2.0 ** -25).astype(np.float32)   # one fma rounding
+
+
+START_DRAW_ELEM = 0xFFFFFFFF
+
+
+def start_indices(seed, step, traj, num_start):
+    """Start-state rows of batched runs (csrc/mfg_device.h::start_draw_row, include/mfg_hip.h mfg_draw_start): the
+    reference's per-episode `idx_row = np.random.randint(num_start_samples)` (mfg_ac2.py:466, ac_irl.py:655) drawn from the
+    counter-based generator instead -- counter (0xFFFFFFFF, step of the episode's first env step, global trajectory id,
+    block 0), idx = floor(x0 * num_start / 2^32).  Integer bookkeeping: bit exact against the kernels."""
+    x0 = philox_elem(int(seed), START_DRAW_ELEM, int(step), np.asarray(traj, dtype=np.uint64), 0)[0]
+    return ((x0.astype(np.uint64) * np.uint64(int(num_start))) >> np.uint64(32)).astype(np.int64)

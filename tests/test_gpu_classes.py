@@ -144,9 +144,10 @@ def test_philox_step_mode_matches_oracle_replay(dev):
     ac.trace = []
     np.random.seed(12)
     ac.train(num_episodes=1, gamma=0.9, constant=0)
-    # replay: same start draw, same Philox counters, oracle math in fp64
-    np.random.seed(12)
-    idx = np.random.randint(5, size=B)
+    # replay: same start draw (Philox, keyed by seed / first step of the episode / trajectory id), same action counters,
+    # oracle math in fp64
+    from oracle.philox_ref import start_indices
+    idx = start_indices(77, 0, np.arange(B), 5)
     pi = mat[idx].astype(np.float32)
     w = w0.copy(); theta = theta0
     F = O().num_features(d)
@@ -541,8 +542,8 @@ def test_ac_irl_philox_train_matches_oracle_replay(dev, mode):
     np.random.seed(32)
     ac.train(max_episodes=1, stop_criteria=-1, gamma=gamma, constant=False, lr_critic=0.1, lr_actor=0.001,
              reward_fn=fake_reward_dev)
-    np.random.seed(32)
-    idx = np.random.randint(6, size=B)
+    from oracle.philox_ref import start_indices
+    idx = start_indices(13, 0, np.arange(B), 6)                     # the device-side start draw of the episode
     pi = mat[idx].astype(np.float32)
     w, theta = w0.copy(), theta0
     sc, sa = O().lr_scales(1, False)
@@ -866,6 +867,136 @@ def test_train_rollout_equals_gather_rollout_update_sequence(dev, d, B, T, apply
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
     assert float(outs[0][0]) != 8.86349 and float(outs[0][2][F + 2]) == B * T
+
+
+# ---- a9 on the device: the per-episode start-state draw (mfg_ac2.py:466) and the native episode loops -----------------------
+@pytest.mark.parametrize('num_start', [1, 3, 64, 1000])
+def test_draw_start_equals_the_oracle_bit_for_bit(dev, num_start):
+    """mfg_draw_start: indices and gathered rows against oracle/philox_ref.start_indices (integer bookkeeping: bit exact),
+    for trajectory ids beyond 2^32 and steps near the top of the counter."""
+    from discrete_mean_field_game_amd import ops
+    from oracle.philox_ref import start_indices
+    d = 21
+    mat = np.random.RandomState(num_start).dirichlet(np.ones(d), size=num_start).astype(np.float32)
+    mat_dev = torch.as_tensor(mat, device=dev)
+    for seed, step, off, B in [(0, 0, 0, 1), (2024, 45, 0, 4097), (0x9E3779B97F4A7C15, 4_000_000_000, 2 ** 33 + 5, 1000),
+                               (5, 7, 2 ** 47, 13)]:
+        idx, pi0 = ops.draw_start(mat_dev, B, seed, step, off, want_idx=True)
+        ref = start_indices(seed, step, off + np.arange(B, dtype=np.uint64), num_start)
+        assert np.array_equal(idx.cpu().numpy(), ref)
+        assert np.array_equal(pi0.cpu().numpy(), mat[ref])
+        only_idx, none = ops.draw_start(mat_dev, B, seed, step, off, want_idx=True, want_pi0=False)
+        assert none is None and torch.equal(only_idx, idx)
+
+
+@pytest.mark.parametrize('d,B,T', [(21, 1000, 15), (21, 13, 3), (15, 77, 15), (47, 30, 4), (128, 40, 5), (256, 9, 2), (448, 5, 2)])
+def test_in_kernel_start_draw_equals_the_gather_of_the_oracle_indices(dev, d, B, T):
+    """mfg_train_rollout(idx = NULL) draws the start rows inside the rollout kernel (packed and wave-per-trajectory
+    forms): every output equals, bit for bit, the run that is handed oracle/philox_ref.start_indices as `idx`."""
+    from discrete_mean_field_game_amd import ops
+    from oracle.philox_ref import start_indices
+    rs = np.random.RandomState(d)
+    mat_h = rs.dirichlet(np.ones(d), size=9).astype(np.float32)
+    mat = torch.as_tensor(mat_h, device=dev)
+    seed, first_step, off = 5, 3 * T, 2 ** 32 + 11
+    ref = start_indices(seed, first_step, off + np.arange(B, dtype=np.uint64), 9)
+    idx = torch.as_tensor(ref.astype(np.int32), device=dev)
+    F = ops.num_features(d)
+    w0 = rs.rand(F)
+    outs = []
+    for drawn in (True, False):
+        theta = torch.tensor([8.86349], dtype=torch.float64, device=dev)
+        w = torch.as_tensor(w0.copy(), device=dev)
+        G = torch.zeros(F + 3, dtype=torch.float64, device=dev)
+        ws = ops.workspace(B * T, d, dev)
+        bufs = {'pi_traj': torch.empty(B, T + 1, d, device=dev), 'pi_last': torch.empty(B, d, device=dev),
+                'reward': torch.empty(B, T, device=dev), 'delta': torch.empty(B, T, dtype=torch.float64, device=dev),
+                'g': torch.empty(B, T, dtype=torch.float64, device=dev)}
+        ops.train_rollout(mat, None if drawn else idx, T, theta, 0.16, 12000.0, w, 0.9, G, ws, bufs, 0.1, 0.001, apply=True,
+                          seed=seed, first_step=first_step, traj_offset=off)
+        torch.cuda.synchronize()
+        outs.append((theta.clone(), w.clone(), G.clone(), bufs['pi_traj'].clone(), bufs['delta'].clone(), bufs['g'].clone(),
+                     bufs['reward'].clone(), bufs['pi_last'].clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert np.array_equal(outs[0][3][:, 0].cpu().numpy(), mat_h[ref])
+
+
+@pytest.mark.parametrize('mode,d,B', [('rollout', 21, 300), ('step', 21, 300), ('rollout', 15, 64), ('rollout', 128, 12), ('step', 47, 20)])
+@pytest.mark.parametrize('constant', [0, 1])
+def test_native_multi_episode_loop_equals_the_per_episode_loop(dev, mode, d, B, constant):
+    """mfg_train_rollouts / mfg_train_episodes (ALL episodes up to the next report issued by one native call: device-side
+    start draw, learning-rate schedule evaluated in C, episode loop without the interpreter) against the per-episode
+    Python loop of the same kernels (a recorded trace forces it): theta, w, final states, the Philox counter and the
+    per-report reward averages agree bit for bit -- including the libm `log(log(episode + 20))` of the actor schedule."""
+    rs = np.random.RandomState(d)
+    mat = rs.dirichlet(np.ones(d), size=9)
+    runs = []
+    for native in (True, False):
+        np.random.seed(21)
+        ac = AC(d=d, pi0=mat, batch=B, rng='philox', seed=5, update_every=mode, verbose=0)
+        if not native:
+            ac.trace = []
+        logs = []
+        ac.train_log = lambda vector, filename, fmt, logs=logs: logs.append((filename, np.array(vector, dtype=np.float64).copy()))
+        ac.train(num_episodes=8, gamma=0.95, constant=constant, consecutive=3, write_file=1, first_episode=2)
+        runs.append((np.ravel(ac.theta).copy(), ac.w.copy(), ac._last_pi.cpu().numpy().copy(), ac._rng_step, logs))
+    assert runs[0][3] == runs[1][3] == 8 * 15
+    for k in range(3):
+        assert np.array_equal(runs[0][k], runs[1][k])
+    assert len(runs[0][4]) == len(runs[1][4]) == 9                   # reports after episodes 0, 3, 6: theta, pi, reward each
+    for (fa, va), (fb, vb) in zip(runs[0][4], runs[1][4]):
+        assert fa == fb and np.array_equal(va, vb)
+
+
+def test_batched_philox_training_uses_no_host_rng(dev):
+    """Batched runs draw their start states on the device: train() neither consumes nor depends on np.random (the
+    reference's `np.random.randint` at mfg_ac2.py:466 is kept for batch 1 and rng='numpy' only), and the states an episode
+    starts from are the rows oracle/philox_ref.start_indices names."""
+    from oracle.philox_ref import start_indices
+    d, B = 21, 200
+    mat = np.random.RandomState(0).dirichlet(np.ones(d), size=16)
+    outs = []
+    for host_seed in (1, 2):
+        np.random.seed(5)
+        ac = AC(d=d, pi0=mat, batch=B, seed=9, update_every='rollout')
+        np.random.seed(host_seed)
+        before = np.random.get_state()[1].copy()
+        ac.train(num_episodes=3)
+        assert np.array_equal(before, np.random.get_state()[1])     # the stream was not touched
+        outs.append((float(ac.theta[0]), ac.w.copy()))
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+    # per-step mode, per-episode Python path (trace): states of episode e start from start_indices(seed, 15 e, b)
+    np.random.seed(5)
+    ac = AC(d=d, pi0=mat, batch=B, seed=9, update_every='step')
+    ac.trace = []
+    from discrete_mean_field_game_amd import ops
+    seen = []
+    real = ops.draw_start
+    try:
+        ops.draw_start = lambda *a, **k: seen.append((a[2], a[3])) or real(*a, **k)
+        ac.train(num_episodes=2)
+    finally:
+        ops.draw_start = real
+    assert seen == [(9, 0), (9, 15)]
+    _, pi0 = real(ac._mat_pi0_dev, B, 9, 15, 0)
+    assert np.array_equal(pi0.cpu().numpy(), mat.astype(np.float32)[start_indices(9, 15, np.arange(B), 16)])
+
+
+def test_batch_one_and_numpy_rng_keep_the_reference_host_draw(dev):
+    """batch = 1 (and rng = 'numpy' at any batch) still take `np.random.randint(num_start_samples)` per episode, the
+    reference's draw (mfg_ac2.py:466): one scalar draw per episode at batch 1."""
+    d = 21
+    mat = np.random.RandomState(0).dirichlet(np.ones(d), size=16)
+    np.random.seed(5)
+    ac = AC(d=d, pi0=mat, batch=1, seed=9, rng='philox', update_every='step')
+    np.random.seed(77)
+    ac.train(num_episodes=4)
+    after = np.random.get_state()
+    np.random.seed(77)
+    for _ in range(4):
+        np.random.randint(16)
+    assert np.array_equal(after[1], np.random.get_state()[1]) and after[2] == np.random.get_state()[2]
 
 
 @pytest.mark.parametrize('d,B', [(21, 1), (21, 2), (21, 3), (21, 4), (21, 100), (15, 1), (15, 5), (15, 1001)])

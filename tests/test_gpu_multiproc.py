@@ -1,7 +1,8 @@
 """-m gpu: the CLASS-level multi-rank path (actor_critic.train / AC_IRL.train with a process group), executed for real:
 two FRESH child processes share GPU 0, talk over gloo, each builds the drop-in class with the GLOBAL batch and runs
-train(); the batch shards by rank, the Philox stream is keyed by the global trajectory id, gradients meet in one
-all-reduce per update and rank 0's start-state draw is broadcast (the ranks are given DIFFERENT host seeds on purpose).
+train(); the batch shards by rank, the Philox streams of the actions AND of the per-episode start-state draw are keyed by
+the global trajectory id, gradients meet in one all-reduce per update.  Nothing else is exchanged: `dist.broadcast` is
+replaced by a function that raises inside the children, and the ranks are given DIFFERENT host seeds on purpose.
 
 Checked: both ranks end with bit-identical (theta, w) (replicated update, no broadcast of parameters needed), two
 2-rank runs agree bit for bit (deterministic), and the result equals the single-process run of the same global batch up
@@ -40,7 +41,7 @@ def _run_class(kind, mode, d, B, episodes, host_seed, world):
         from discrete_mean_field_game_amd.mfg_ac2 import actor_critic
         np.random.seed(11)                                   # same critic initialisation on every rank
         ac = actor_critic(d=d, pi0=_mat(d), batch=B, rng='philox', seed=5, update_every=mode, precision='f64', verbose=0)
-        np.random.seed(host_seed)                            # start-state draws: rank 0's are broadcast
+        np.random.seed(host_seed)                            # (nothing in a batched Philox run reads the host stream)
         ac.train(num_episodes=episodes, gamma=0.9, constant=0)
     else:
         from discrete_mean_field_game_amd.ac_irl import AC_IRL
@@ -64,6 +65,10 @@ def _child(rank, world, port, kind, mode, d, B, episodes, out_dir):
     import torch.distributed as dist
     torch.cuda.set_device(0)                                 # both ranks on GPU 0
     dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    def _no_broadcast(*a, **k):
+        raise AssertionError('train() must not broadcast: start states are drawn on the device, parameters stay replicated')
+    dist.broadcast = _no_broadcast
     try:
         theta, w = _run_class(kind, mode, d, B, episodes, host_seed=100 + 17 * rank, world=world)
         np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), theta=theta, w=w)

@@ -272,7 +272,8 @@ def test_sampler_small_shape_regime(dev):
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('d,B,T', [(3, 50, 4), (4, 37, 5), (15, 33, 6), (21, 1, 15), (21, 100, 15), (32, 10, 3), (47, 9, 4),
                                    (64, 5, 2), (65, 3, 2), (100, 5, 3), (128, 6, 3), (256, 2, 2), (320, 2, 2), (512, 1, 1),
-                                   (250, 2, 2), (253, 2, 2), (450, 1, 1), (66, 3, 2), (127, 2, 2)])
+                                   (250, 2, 2), (253, 2, 2), (450, 1, 1), (66, 3, 2), (127, 2, 2),
+                                   (400, 2, 2), (448, 3, 2)])      # R = 7 (385 <= d <= 448): its register cap moved late in round 3
 @pytest.mark.parametrize('discount_pow', [False, True])
 @pytest.mark.parametrize('precision,gtol', [('f64', 1e-9), ('mixed', 1e-5)])
 def test_rollout_fused_vs_oracle(dev, d, B, T, discount_pow, precision, gtol):
@@ -317,6 +318,40 @@ def test_rollout_fused_vs_oracle(dev, d, B, T, discount_pow, precision, gtol):
     P0 = ops().sample_dirichlet(t32(pi0, dev), t64([theta], dev), shift, scale, seed=99, step=5, traj_offset=1000,
                                 precision=precision)
     assert np.array_equal(P0.cpu().numpy(), P[:, 0])
+
+
+# Every instantiation R = ceil(d / 64) = 2 .. 8 of the wave-per-trajectory kernels, at a full width (d = 64 R), one column
+# short of it and one column into it (d = 64 (R - 1) + 1): any edit of MFG_CORE_LARGE_WAVES* / large_row_batch (launch
+# bounds, i.e. register caps and spills, and the stash size are functions of R) is covered whatever R it touches.
+@pytest.mark.parametrize('R', [2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize('precision,gtol', [('f64', 1e-9), ('mixed', 1e-5)])
+def test_every_wave_per_trajectory_instantiation_vs_oracle(dev, R, precision, gtol):
+    theta, shift, scale, gamma = 8.86349, 0.16, 12000.0, 0.9
+    for d, B, T in ((64 * R, 5, 2), (64 * R - 1, 3, 2), (64 * (R - 1) + 1, 4, 1)):
+        rs = np.random.RandomState(7 * d)
+        pi0 = rs.dirichlet(np.ones(d), size=B).astype(np.float32)
+        w = rs.rand(O().num_features(d))
+        out = ops().rollout(t32(pi0, dev), T, t64([theta], dev), shift, scale, w=t64(w, dev), gamma=gamma, seed=123,
+                            first_step=2, traj_offset=77, td=True, write_P=True, precision=precision)
+        P = out['P'].cpu().numpy()
+        assert np.isfinite(P).all() and np.max(np.abs(P.astype(np.float64).sum(-1) - 1)) < 5e-7
+        pt = out['pi_traj'].cpu().numpy().astype(np.float64)
+        traj = O().batched_rollout_given_P(pi0, P, w, theta, shift, gamma=gamma)[0]
+        assert np.allclose(pt, traj, rtol=3e-7, atol=1e-12)
+        r_ref = np.stack([O().calc_reward(P[:, t].astype(np.float64), pt[:, t]) for t in range(T)], 1)
+        assert rel(out['reward'].cpu().numpy(), r_ref, 1e-30) < 1e-6
+        g_ref = np.stack([O().calc_gradient(P[:, t], pt[:, t], theta, shift) for t in range(T)], 1)
+        assert rel(out['g'].cpu().numpy(), g_ref, 1e-30) < max(gtol, 2e-7)
+        V = O().calc_features(pt).dot(w)
+        d_ref = r_ref + gamma * V[:, 1:] - V[:, :-1]
+        assert np.max(np.abs(out['delta'].cpu().numpy() - d_ref)) < 1e-11 * max(1.0, np.abs(V).max())
+        # the sampling-only instantiation (no TD: another register budget) draws the same actions
+        env = ops().rollout(t32(pi0, dev), T, t64([theta], dev), shift, scale, seed=123, first_step=2, traj_offset=77, td=False,
+                            write_P=True, precision=precision)
+        assert np.array_equal(env['P'].cpu().numpy(), P)
+        P0 = ops().sample_dirichlet(t32(pi0, dev), t64([theta], dev), shift, scale, seed=123, step=2, traj_offset=77,
+                                    precision=precision)
+        assert np.array_equal(P0.cpu().numpy(), P[:, 0])
 
 
 def test_rollout_env_only_matches_td_rollout(dev):

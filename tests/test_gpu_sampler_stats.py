@@ -61,7 +61,7 @@ REGIMES = {'policy': (8.86349, 0.16, 12000.0), 'mid': (5.0, 0.1, 40.0), 'small':
 
 @pytest.mark.parametrize('precision', ['mixed', 'f64'])
 @pytest.mark.parametrize('regime', ['policy', 'mid', 'small'])
-@pytest.mark.parametrize('d', [192, 256, 320])
+@pytest.mark.parametrize('d', [192, 256, 320, 448])
 def test_large_d_sampler_marginals(dev, d, regime, precision):
     from scipy import stats
     theta, shift, scale = REGIMES[regime]

@@ -1,7 +1,7 @@
 """Known-answer tests of the Philox4x32-10 restatement (Random123 kat_vectors)."""
 import numpy as np
 
-from oracle.philox_ref import philox4x32_10, u01
+from oracle.philox_ref import philox4x32_10, start_indices, u01
 
 
 def test_random123_known_answers():
@@ -21,3 +21,32 @@ def test_u01_never_zero():
     assert u.dtype == np.float32 and u.min() > 0 and u.max() <= 1
     assert u[0] == np.float32(2.0 ** -25) and u[2] == np.float32(0.5) and u[3] == np.float32(1.5 * 2.0 ** -24)
     assert u[1] == np.float32(1.0)
+
+
+def test_start_indices_are_the_documented_philox_words():
+    """include/mfg_hip.h mfg_draw_start: counter (0xFFFFFFFF, step, trajectory id low, trajectory id bits 32..47), key = seed,
+    idx = floor(x0 * num_start / 2^32) -- spelled out here with the raw block function (integer bookkeeping)."""
+    seed, step = 0x0123456789ABCDEF, 4500
+    traj = np.array([0, 1, 2, 65535, 2 ** 32 - 1, 2 ** 32, 5 * 2 ** 32 + 7, 2 ** 47 + 3], dtype=np.uint64)
+    for n in (1, 2, 3, 64, 1000, 2 ** 31 - 1):
+        got = start_indices(seed, step, traj, n)
+        x0 = philox4x32_10(0xFFFFFFFF, step, traj & np.uint64(0xFFFFFFFF), (traj >> np.uint64(32)) & np.uint64(0xFFFF),
+                           seed & 0xFFFFFFFF, seed >> 32)[0]
+        want = np.array([(int(x) * n) >> 32 for x in x0])
+        assert got.dtype == np.int64 and np.array_equal(got, want)
+        assert got.min() >= 0 and got.max() < n
+    # the Random123 known answer with counter word 0 = 0xFFFFFFFF: all-ones counter and key give x0 = 0x408f276d; the start
+    # draw's counter differs from it only in c3 (block 0 -> upper 16 bits zero), so it must NOT reproduce that word
+    assert int(philox4x32_10(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF)[0]) == 0x408f276d
+
+
+def test_start_indices_are_uniform_and_independent_of_the_split():
+    n, B = 64, 1 << 16
+    idx = start_indices(7, 15, np.arange(B), n)
+    counts = np.bincount(idx, minlength=n)
+    chi2 = float(((counts - B / n) ** 2 / (B / n)).sum())
+    assert chi2 < 120.0                                              # 63 degrees of freedom: mean 63, sd 11.2
+    # a rank's shard draws exactly its slice of the global vector; another episode (step) is a different vector
+    assert np.array_equal(start_indices(7, 15, np.arange(1000, 3000), n), idx[1000:3000])
+    assert not np.array_equal(start_indices(7, 30, np.arange(B), n), idx)
+    assert not np.array_equal(start_indices(8, 15, np.arange(B), n), idx)
