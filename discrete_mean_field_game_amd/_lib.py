@@ -72,6 +72,8 @@ SIGNATURES = {
                                  _f64, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'mfg_train_rollouts': (_i32, [_p, _i64, _i64, _i32, _i32, _i64, _i64, _i32, _p, _f64, _f64, _p, _f64, _i32, _u64, _u32, _u64,
                                   _i32, _f64, _f64, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    'mfg_train_rollout_deferred': (_i32, [_p, _i64, _p, _i64, _i32, _i32, _p, _p, _p, _f64, _f64, _p, _p, _p, _f64, _f64, _f64,
+                                          _i32, _u64, _u32, _u64, _i32, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'mfg_train_episodes': (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _i64, _i64, _i32, _p, _f64, _f64, _p, _f64, _i32, _u64, _u32,
                                   _u64, _i32, _f64, _f64, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'mfg_policy_logpdf': (_i32, [_p, _p, _i64, _i32, _p, _i32, _f64, _f64, _f64, _f64, _p, _p]),

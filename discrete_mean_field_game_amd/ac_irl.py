@@ -27,7 +27,7 @@ from . import _lib as L
 from . import ops
 from .mfg_ac2 import EPISODE_STEPS, actor_critic
 from .networks import RewardNet, maxent_irl_loss
-from .parallel import all_reduce_gradients_, current_shard, lr_scales
+from .parallel import all_reduce_gradients_, all_reduce_mean_flat_, broadcast_seed, current_shard, lr_scales
 
 
 class AC_IRL(actor_critic):
@@ -331,10 +331,12 @@ class AC_IRL(actor_critic):
                     pi, _r = ops.step_given_P(pi, P, want_reward=False)
                 out.append(traj)
             return out
-        idx = torch.as_tensor(np.random.randint(num, size=n).astype(np.int32), device=self.device)
-        pi0 = ops.gather_start(mat_dev, idx)
+        # start states drawn on the device like train()'s (mfg_draw_start keyed by seed / step / trajectory id): every rank of
+        # a multi-GPU job generates the identical D_samp without sharing a host RNG stream
+        off = self._gen_offset(n)
+        _, pi0 = ops.draw_start(mat_dev, n, self.seed, self._rng_step, off)
         r = ops.rollout(pi0, T, self._theta, self.shift, self.alpha_scale, seed=self.seed, first_step=self._rng_step,
-                        traj_offset=self._gen_offset(n), td=False, write_P=True, precision=self.precision)
+                        traj_offset=off, td=False, write_P=True, precision=self.precision)
         self._rng_step += T
         pis = r['pi_traj'].cpu().numpy().astype(np.float64)
         Ps = r['P'].cpu().numpy().astype(np.float64)
@@ -434,19 +436,33 @@ class AC_IRL(actor_critic):
         loss, first, second = maxent_irl_loss(r_demo, r_gen, self.num_demo_samples, len(gen_sampled), reg)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        if self.group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            # replicated reward net: identical batches on every rank -> identical grads; keep ranks in lock-step
-            for p in self.reward_net.parameters():
-                if p.grad is not None and torch.distributed.get_world_size(self.group) > 1:
-                    torch.distributed.all_reduce(p.grad, group=self.group)
-                    p.grad /= torch.distributed.get_world_size(self.group)
+        self._all_reduce_reward_grads()
         self.optimizer.step()
         self.loss_val = float(loss.detach().cpu())
         self.first_term_val = float(first.detach().cpu())
         self.second_term_val = float(second.detach().cpu())
 
+    def _all_reduce_reward_grads(self):
+        """Replicated reward network: ONE all-reduce of the flattened gradient, averaged over the ranks.  The
+        ranks train on identical batches (see _sync_host_sampler), so this only keeps them in lock-step against rounding
+        differences."""
+        all_reduce_mean_flat_([p.grad for p in self.reward_net.parameters() if p.grad is not None], self.group)
+
+    def _sync_host_sampler(self):
+        """update_reward draws its demonstration / generated trajectories with Python's `random` (ac_irl.py:814-829) and
+        the training-mode reward net draws dropout masks from torch's generator.  Several ranks must pick the SAME batches
+        and masks: rank 0 draws one value and broadcasts it, every rank re-seeds `random` and torch from it.  Once per
+        reward_iteration, not per update; a single process keeps its streams untouched."""
+        dist = torch.distributed
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return
+        s = broadcast_seed(random.getrandbits(62), self.group, self.device)
+        random.seed(s)
+        torch.manual_seed(s)
+
     def reward_iteration(self, max_iterations=500, stop_criteria=0.01, iter_check=10):
         prev_reward_demo_avg = -100
+        self._sync_host_sampler()
         if self.verbose:
             print('----- Starting reward_iteration -----')
         it = 0

@@ -42,6 +42,15 @@ struct CoreArgs {
   const float4* htab;  // h(z) cubic table (mixed precision TD), see mfg_device.h
   unsigned* status;    // device address of the host-visible status word (mfg_status), or NULL
   double* part_rows;   // SUMS variant (T == 1, one tile per block): partial rows [ntiles][F+3] of the batch sums, or NULL
+  // Deferred update (packed kernel, mfg_train_rollout_deferred): pend_G != NULL = the all-reduced batch sums [F+3] of the
+  // PREVIOUS update, not applied yet.  Every block forms the updated parameters while it stages them (theta, w above are
+  // the parameters BEFORE that update); block 0 also writes them to theta_out / w_out (other buffers than theta / w: blocks
+  // that start later still read the old values) and adds the update's mean reward to *pend_reward_acc.
+  const double* pend_G;
+  double pend_lr_c, pend_lr_a;
+  double* w_out;
+  double* theta_out;
+  double* pend_reward_acc;
 #ifdef MFG_TIMING
   unsigned long long* dbg;  // timing variant only (tools/phase_timing.py): s_memtime stamps of block 0, wave 0
 #endif
@@ -368,7 +377,11 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
                                                          // evaluated inside step 0, next to V of the next state
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
   const int t = lane / d, i = lane - t * d;
-  const double theta = *a.theta;
+  // deferred update of the previous episode (CoreArgs::pend_G): applied here, on the fly, with the arithmetic of
+  // k_apply_update (updated_param); a sum over no samples (count 0) leaves the parameters alone
+  const bool pend = a.pend_G != nullptr && a.pend_G[F + 2] > 0.0;
+  const double pinv = pend ? 1.0 / a.pend_G[F + 2] : 0.0;
+  const double theta = pend ? updated_param(*a.theta, a.pend_lr_a, a.pend_G[F], pinv) : *a.theta;
   const ThetaSplit ts = theta_split(theta, a.shift);
   const float inv_d = 1.0f / (float)d;
   // mixed sampling kernels: separable e^z = E_j F_i (mfg_device.h), in range while |theta| (1/2 + |shift|) <= 86; beyond
@@ -386,17 +399,27 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
       pi_first = a.pi0[core_src_row(a, bf) * d + i];
     }
   }
+  auto w_now = [&](int k) -> double { return pend ? updated_param(a.w[k], a.pend_lr_c, a.pend_G[k], pinv) : a.w[k]; };
   if (want_v) {
     if (CIRC) {
       for (int k = tid; k < H * d; k += BLOCK) {
         const int m = k / d, ii = k - m * d;
         int kk = ii + m;
         if (kk >= d) kk -= d;
-        wl[k] = a.w[feat_idx(ii < kk ? ii : kk, ii < kk ? kk : ii, d)];
+        wl[k] = w_now(feat_idx(ii < kk ? ii : kk, ii < kk ? kk : ii, d));
       }
-      for (int k = Q + tid; k < F; k += BLOCK) wl[k] = a.w[k];
+      for (int k = Q + tid; k < F; k += BLOCK) wl[k] = w_now(k);
     } else {
-      for (int k = tid; k < F; k += BLOCK) wl[k] = a.w[k];
+      for (int k = tid; k < F; k += BLOCK) wl[k] = w_now(k);
+    }
+  }
+  if (a.pend_G != nullptr && blockIdx.x == 0) {
+    // block 0 publishes the updated parameters (out of place) and books the update's mean reward
+    if (a.w_out && a.w)
+      for (int k = tid; k < F; k += BLOCK) a.w_out[k] = w_now(k);
+    if (tid == 0) {
+      if (a.theta_out) *a.theta_out = theta;
+      if (pend && a.pend_reward_acc) *a.pend_reward_acc += a.pend_G[F + 1] * pinv;
     }
   }
   // wl is staged block-wide but read by every wave; the per-step barriers below may be wave-local, so order the

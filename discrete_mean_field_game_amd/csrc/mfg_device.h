@@ -623,6 +623,11 @@ __host__ __device__ __forceinline__ int64_t start_draw_row(uint64_t seed, uint32
   return (int64_t)(((uint64_t)r.x * (uint64_t)num_start) >> 32);
 }
 
+// One parameter of the update  p += lr * G_k / count  (mfg_ac2.py:511-522 for the batch mean): ONE definition, used by the
+// stand-alone update kernel, the update fused into the row reduction and the update folded into the next rollout's weight
+// staging, so that every path produces the same bits.  `inv` = 1 / count.
+__host__ __device__ __forceinline__ double updated_param(double p, double lr, double gk, double inv) { return fma(lr, gk * inv, p); }
+
 // k(i,j) for i <= j: row-major upper triangle (mfg_ac2.py:333).
 __host__ __device__ __forceinline__ int feat_idx(int i, int j, int d) { return i * d - (i * (i - 1)) / 2 + (j - i); }
 

@@ -165,8 +165,22 @@ __global__ void k_apply_update(const double* __restrict__ G, int64_t F, double l
   const double inv = 1.0 / count;
   if (reward_acc && blockIdx.x == 0 && threadIdx.x == 0) *reward_acc += G[F + 1] * inv;
   for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < F; k += (int64_t)gridDim.x * blockDim.x)
-    w[k] += lr_c * (G[k] * inv);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *theta += lr_a * (G[F] * inv);
+    w[k] = updated_param(w[k], lr_c, G[k], inv);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *theta = updated_param(*theta, lr_a, G[F], inv);
+}
+
+// the same update out of place: (w_out, theta_out) = (w_in, theta_in) + lr G / count -- the large-d form of the deferred
+// update of mfg_train_rollout_deferred (at d <= 64 the rollout kernel applies it while staging its weights)
+__global__ void k_apply_update_oop(const double* __restrict__ G, int64_t F, double lr_c, double lr_a, const double* __restrict__ w_in,
+                                   const double* __restrict__ theta_in, double* __restrict__ w_out, double* __restrict__ theta_out,
+                                   double* __restrict__ reward_acc) {
+  const double count = G[F + 2];
+  const bool on = count > 0.0;
+  const double inv = on ? 1.0 / count : 0.0;
+  if (on && reward_acc && blockIdx.x == 0 && threadIdx.x == 0) *reward_acc += G[F + 1] * inv;
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < F; k += (int64_t)gridDim.x * blockDim.x)
+    w_out[k] = on ? updated_param(w_in[k], lr_c, G[k], inv) : w_in[k];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *theta_out = on ? updated_param(*theta_in, lr_a, G[F], inv) : *theta_in;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1414,10 +1428,10 @@ __global__ __launch_bounds__(BLOCK) void k_grad_mfma_small(GradArgs a) {
     const double count = fin[F + 2];
     if (count > 0.0) {
       const double inv = 1.0 / count;
-      for (int k = tid; k < F; k += BLOCK) a.w[k] += a.lr_c * (fin[k] * inv);
+      for (int k = tid; k < F; k += BLOCK) a.w[k] = updated_param(a.w[k], a.lr_c, fin[k], inv);
       if (tid == 0) {
         if (a.reward_acc) *a.reward_acc += fin[F + 1] * inv;
-        *a.theta += a.lr_a * (fin[F] * inv);
+        *a.theta = updated_param(*a.theta, a.lr_a, fin[F], inv);
       }
     }
   }
@@ -2153,8 +2167,8 @@ __global__ __launch_bounds__(RP_SLICES* RP_OUT) void k_reduce_partials(const dou
     if (ap.on) {
       const int64_t F = FO - 3;
       const double inv = 1.0 / ap.count;
-      if (k < F) ap.w[k] += ap.lr_c * (gk * inv);
-      else if (k == F) *ap.theta += ap.lr_a * (gk * inv);
+      if (k < F) ap.w[k] = updated_param(ap.w[k], ap.lr_c, gk, inv);
+      else if (k == F) *ap.theta = updated_param(*ap.theta, ap.lr_a, gk, inv);
       else if (k == F + 1 && ap.reward_acc) *ap.reward_acc += gk * inv;
     }
   }
@@ -2462,7 +2476,7 @@ static int reduce_core_sums(int d, int64_t B, double* G, int accumulate, void* w
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 12; }
+int mfg_abi_version(void) { return 13; }
 
 int mfg_init(void) {
   if (!htab_ptr()) return fail(MFG_ELAUNCH, "%s", "mfg_init: no HIP device / table initialisation failed");
@@ -2991,14 +3005,41 @@ static void lr_schedule(int64_t episode, int constant, double* sc, double* sa) {
   *sa = 1.0 / (e1 * log(log((double)(episode + 20))));
 }
 
+// the previous update of a multi-rank job, all-reduced but not applied yet (mfg_train_rollout_deferred)
+struct DeferredUpdate {
+  const double* G;
+  double lr_c, lr_a;
+  double* reward_acc;
+  double *theta_out, *w_out;
+};
+
 // one training update per episode: [rollout kernel (start rows: drawn in the kernel when idx == NULL, else gathered) |
 // values + delta (large d) | batch sums | row reduction (+ update)]
 static int train_rollout_impl(const float* mat_pi0, int64_t num_start, const int32_t* idx, int64_t B, int d, int T, double* theta,
                               double shift, double alpha_scale, double* w, double gamma, int reward_kind, uint64_t seed,
                               uint32_t first_step, uint64_t traj_offset, int flags, double lr_critic, double lr_actor,
                               float* pi_traj, float* pi_last, float* reward, double* delta, double* g, double* G,
-                              double* reward_acc, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                              double* reward_acc, void* workspace, size_t workspace_bytes, hipStream_t st,
+                              const DeferredUpdate* du = nullptr) {
   CoreArgs a{};
+  if (du) {
+    if (d <= WAVE) {
+      // packed kernel: the update rides in the weight staging of this rollout
+      a.pend_G = du->G;
+      a.pend_lr_c = du->lr_c;
+      a.pend_lr_a = du->lr_a;
+      a.pend_reward_acc = du->reward_acc;
+      a.theta_out = du->theta_out;
+      a.w_out = du->w_out;
+    } else {
+      // wave-per-trajectory kernels read the weights from memory throughout: apply the update out of place first
+      const int64_t F = mfg_num_features(d);
+      hipLaunchKernelGGL(k_apply_update_oop, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, du->G, F, du->lr_c, du->lr_a,
+                         (const double*)w, (const double*)theta, du->w_out, du->theta_out, du->reward_acc);
+      theta = du->theta_out;
+      w = du->w_out;
+    }
+  }
   a.pi0 = mat_pi0;
   a.start_idx = idx;
   a.start_draw = idx ? 0 : 1;
@@ -3080,6 +3121,21 @@ int mfg_train_rollouts(const float* mat_pi0, int64_t num_start, int64_t B, int d
     if (rc != MFG_OK) return rc;
   }
   return MFG_OK;
+}
+
+int mfg_train_rollout_deferred(const float* mat_pi0, int64_t num_start, const int32_t* idx, int64_t B, int d, int T,
+                               const double* theta, const double* w, const double* G_pending, double lr_critic_pending,
+                               double lr_actor_pending, double* reward_acc_pending, double* theta_out, double* w_out, double shift,
+                               double alpha_scale, double gamma, int reward_kind, uint64_t seed, uint32_t first_step,
+                               uint64_t traj_offset, int flags, float* pi_traj, float* pi_last, float* reward, double* delta,
+                               double* g, double* G, void* workspace, size_t workspace_bytes, mfg_stream_t stream) {
+  CHECK_TRAIN_ROLLOUT();
+  REQUIRE(!(flags & MFG_TRAIN_APPLY), "deferred update: MFG_TRAIN_APPLY makes no sense here");
+  REQUIRE(!G_pending || (theta_out && w_out && theta_out != theta && w_out != w), "pending update needs separate output parameters");
+  const DeferredUpdate du{G_pending, lr_critic_pending, lr_actor_pending, reward_acc_pending, theta_out, w_out};
+  return train_rollout_impl(mat_pi0, num_start, idx, B, d, T, const_cast<double*>(theta), shift, alpha_scale, const_cast<double*>(w),
+                            gamma, reward_kind, seed, first_step, traj_offset, flags, 0.0, 0.0, pi_traj, pi_last, reward, delta, g,
+                            G, nullptr, workspace, workspace_bytes, S(stream), G_pending ? &du : nullptr);
 }
 
 int mfg_grad_accumulate(const float* pi, int64_t stride_b, double* delta, const double* g, const float* reward, int64_t B,

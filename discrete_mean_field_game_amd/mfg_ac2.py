@@ -80,6 +80,8 @@ class actor_critic:
             raise ValueError('episode_steps must be >= 1')
         self._train_bufs = {}      # device buffers of train(), kept between calls (keyed by shape)
         self._force_collective = False   # debug (bench.py --force-dist): take the multi-rank update path with one rank
+        self._pending = None             # multi-rank rollout mode: (G, lr_critic, lr_actor, reward_acc) of an update not applied yet
+        self._w_alt = self._theta_alt = None
         self._theta = torch.zeros(1, dtype=torch.float64, device=self.device)
         self._theta_is_array = False
         self.theta = theta
@@ -106,16 +108,19 @@ class actor_critic:
     # ------------------------------------------------------------------ state on the device
     @property
     def theta(self):
+        self._flush_pending()
         v = float(self._theta.cpu()[0])
         return np.array([v]) if self._theta_is_array else v       # ndarray (1,) after the first update (:520)
 
     @theta.setter
     def theta(self, value):
+        self._flush_pending()
         self._theta_is_array = isinstance(value, np.ndarray)
         self._theta.copy_(torch.as_tensor(np.ravel(np.asarray(value, dtype=np.float64))[:1]))
 
     @property
     def w(self):
+        self._flush_pending()
         return self._w.cpu().numpy().reshape(-1, 1).copy()
 
     @w.setter
@@ -229,6 +234,7 @@ class actor_critic:
         """Everything a run needs to resume bit for bit: theta, w (fp64, device values copied to the host), the Philox
         step counter and seed, the policy hyper-parameters and the global np.random state (start-state draws).
         The reference keeps no RL checkpoint at all (only CSV logs); `torch.save(obj.state_dict(), path)` is ours."""
+        self._flush_pending()
         # tensors and plain Python scalars only, so torch.load(weights_only=True) can read the file: the legacy MT19937
         # state tuple ('MT19937', key[624] uint32, pos, has_gauss, cached_gaussian) is stored field by field
         name, key, pos, has_gauss, cached = np.random.get_state()
@@ -446,6 +452,8 @@ class actor_critic:
                 pi = self._train_one_episode(episode, shard, device_draw, native_episode, fused_rollout, G, ws, ebufs,
                                              rbufs if fused_rollout else None, ep_base + 8 * episode, gamma, constant,
                                              lr_critic, lr_actor, first_episode, write_all)
+            if self.check_finite or episode % consecutive == 0 or episode == num_episodes - 1:
+                self._flush_pending()
             if self.check_finite:
                 self._raise_if_not_finite(pi, episode)
             if episode % consecutive == 0:
@@ -466,6 +474,14 @@ class actor_critic:
         self._last_pi = pi
         self._check_status()
 
+    def _flush_pending(self):
+        """Apply the update a multi-rank rollout-mode episode left pending (see _train_one_episode): before anything reads
+        theta / w on the host, and after the last episode."""
+        if self._pending is not None:
+            G, lc, la, racc = self._pending
+            ops.apply_update(G, self.d, lc, la, self._w, self._theta, racc)
+            self._pending = None
+
     def _train_one_episode(self, episode, shard, device_draw, native_episode, fused_rollout, G, ws, ebufs, rbufs, reward_acc,
                            gamma, constant, lr_critic, lr_actor, first_episode, write_all):
         """One episode of train() issued from Python: the multi-rank path (an all-reduce sits between the batch sums and
@@ -482,6 +498,24 @@ class actor_critic:
             # (+ the update itself on one GPU): 2-3 launches
             idx = None if device_draw else self._draw_start(shard)
             single = shard.world == 1 and not self._force_collective
+            if not single and self.trace is None:
+                # several ranks: rollout | sums | all-reduce -- and nothing else.  The update of THIS episode is left pending
+                # and applied by the next episode's rollout kernel while it stages its weights (mfg_train_rollout_deferred;
+                # parameters ping-pong between two buffers); _flush_pending applies the last one.
+                if self._w_alt is None or self._w_alt.shape != self._w.shape:
+                    self._w_alt, self._theta_alt = torch.empty_like(self._w), torch.empty_like(self._theta)
+                ops.train_rollout_deferred(self._mat_pi0_dev, idx, T, self._theta, self._w, self._pending, self._theta_alt,
+                                           self._w_alt, self.shift, self.alpha_scale, gamma, G, ws, rbufs,
+                                           reward_kind=self.reward_kind, seed=self.seed, first_step=self._rng_step,
+                                           traj_offset=shard.traj_offset, precision=self.precision)
+                if self._pending is not None:
+                    self._theta, self._theta_alt = self._theta_alt, self._theta
+                    self._w, self._w_alt = self._w_alt, self._w
+                self._rng_step += T
+                all_reduce_gradients_(G, self.group, self._force_collective)       # the ONE exchange of an update
+                self._pending = (G, lr_critic * sc, lr_actor * sa, reward_acc)
+                self._theta_is_array = True
+                return rbufs['pi_last']
             ops.train_rollout(self._mat_pi0_dev, idx, T, self._theta, self.shift, self.alpha_scale, self._w, gamma, G,
                               ws, rbufs, lr_critic * sc, lr_actor * sa, apply=single, reward_kind=self.reward_kind,
                               seed=self.seed, first_step=self._rng_step, traj_offset=shard.traj_offset,

@@ -264,6 +264,28 @@ def train_rollout(mat_pi0, idx, T, theta, shift, alpha_scale, w, gamma, G, ws, b
     return bufs
 
 
+def train_rollout_deferred(mat_pi0, idx, T, theta, w, pending, theta_out, w_out, shift, alpha_scale, gamma, G, ws, bufs,
+                           reward_kind=L.REWARD_MFG_AC2, seed=0, first_step=0, traj_offset=0, discount_pow=False,
+                           precision='mixed'):
+    """Multi-rank update cycle without an update launch (mfg_train_rollout_deferred): `pending` = None or
+    (G_all_reduced, lr_critic, lr_actor, reward_acc) of the PREVIOUS update, applied while this rollout stages its weights;
+    the updated parameters land in (theta_out, w_out) -- other tensors than (theta, w).  G = this rank's sums afterwards."""
+    _chk_f32(mat_pi0, 'mat_pi0'); _chk_f64(theta, 'theta'); _chk_f64(w, 'w'); _chk_f64(G, 'G')
+    B, d = bufs['pi_traj'].shape[0], mat_pi0.shape[1]
+    flags = L.ROLLOUT_DISCOUNT_POW if discount_pow else 0
+    if L.PRECISIONS[precision] == L.PRECISION_F64:
+        flags |= L.ROLLOUT_F64
+    pG, plc, pla, pacc = pending if pending is not None else (None, 0.0, 0.0, None)
+    L.check(L.lib().mfg_train_rollout_deferred(mat_pi0.data_ptr(), mat_pi0.shape[0], _ptr(idx), B, d, int(T), theta.data_ptr(),
+                                               w.data_ptr(), _ptr(pG), float(plc), float(pla), _ptr(pacc), _ptr(theta_out),
+                                               _ptr(w_out), float(shift), float(alpha_scale), float(gamma), int(reward_kind),
+                                               int(seed), int(first_step), int(traj_offset), flags, bufs['pi_traj'].data_ptr(),
+                                               _ptr(bufs.get('pi_last')), bufs['reward'].data_ptr(), bufs['delta'].data_ptr(),
+                                               bufs['g'].data_ptr(), G.data_ptr(), ws.data_ptr(), ws.numel() * 8, _stream()),
+            'mfg_train_rollout_deferred')
+    return bufs
+
+
 def train_rollouts(mat_pi0, T, episodes, first_episode, constant, theta, shift, alpha_scale, w, gamma, G, ws, bufs, lr_critic,
                    lr_actor, reward_kind=L.REWARD_MFG_AC2, seed=0, first_step=0, traj_offset=0, discount_pow=False,
                    reward_acc=None, precision='mixed'):

@@ -72,6 +72,40 @@ def broadcast_start_indices(idx, group=None, device=None):
     return t.cpu().numpy()
 
 
+def all_reduce_mean_flat_(tensors, group=None):
+    """Average a list of tensors over the ranks with ONE collective: flatten, all-reduce (SUM), divide by the world size,
+    scatter back in place.  Used for the replicated reward network's gradient (7 235 floats at d = 21,
+    n_fc3 = 8, n_fc4 = 4 -- ten parameter tensors, one message).  No-op for a single process.  Returns the number of
+    collectives issued (0 or 1)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1 or not tensors:
+        return 0
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    if flat.is_cuda and dist.get_backend(group) != 'nccl':             # gloo (tests): staged through the host
+        h = flat.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(h)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+    return 1
+
+
+def broadcast_seed(value: int, group=None, device=None) -> int:
+    """Rank 0's `value` (a non-negative integer below 2^62) on every rank: the ranks of a job re-seed their HOST samplers
+    from it (Python `random` / torch generator of AC_IRL.update_reward) instead of relying on a shared start-up seed."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return int(value)
+    on_dev = dist.get_backend(group) == 'nccl'
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device if on_dev else 'cpu')
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return int(t.cpu()[0])
+
+
 def lr_scales(episode: int, constant) -> tuple:
     """(critic, actor) learning-rate multipliers of the reference schedule in `episode`
     (mfg_ac2.py:511-522: 1/(episode+1) and 1/((episode+1) ln ln(episode+20)); 1, 1 if constant)."""

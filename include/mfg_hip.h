@@ -218,6 +218,24 @@ int mfg_train_rollouts(const float* mat_pi0, int64_t num_start, int64_t B, int d
                        float* pi_traj, float* pi_last, float* reward, double* delta, double* g, double* G, double* reward_acc,
                        void* workspace, size_t workspace_bytes, mfg_stream_t stream);
 
+/* a9 on several GPUs: the update cycle of a rank without an update launch.  A multi-GPU update is
+ *   rollout | batch sums | all-reduce(G) | w, theta += lr G / count              (mfg_ac2.py:511-522 for the global batch)
+ * and its last step needs nothing but G: this entry point takes the all-reduced sums of the PREVIOUS update as G_pending
+ * (NULL: none) and applies them while the rollout kernel stages its weights (d <= 64; a separate out-of-place launch
+ * above): the parameters the rollout runs with -- and (theta_out, w_out), written by one block -- are
+ *   theta + lr_actor_pending G_pending[F] / count,  w + lr_critic_pending G_pending[:F] / count,  count = G_pending[F+2],
+ * bit for bit what mfg_apply_update would have produced in place; *reward_acc_pending += G_pending[F+1] / count.  The
+ * outputs must be OTHER buffers than theta / w (blocks that start later still read the old values): callers ping-pong
+ * two parameter sets.  Then as mfg_train_rollout without MFG_TRAIN_APPLY: G holds this rank's sums of the new update on
+ * return (G may alias G_pending: it is written by a later launch).  A rank's cycle is rollout -> sums -> all-reduce, and
+ * mfg_apply_update only once, after the last episode. */
+int mfg_train_rollout_deferred(const float* mat_pi0, int64_t num_start, const int32_t* idx, int64_t B, int d, int T,
+                               const double* theta, const double* w, const double* G_pending, double lr_critic_pending,
+                               double lr_actor_pending, double* reward_acc_pending, double* theta_out, double* w_out, double shift,
+                               double alpha_scale, double gamma, int reward_kind, uint64_t seed, uint32_t first_step,
+                               uint64_t traj_offset, int flags, float* pi_traj, float* pi_last, float* reward, double* delta,
+                               double* g, double* G, void* workspace, size_t workspace_bytes, mfg_stream_t stream);
+
 /* f1 (IRL): reward[b] = r_net(state_b, action_b), the reward network of networks.py:46-81 evaluated for B
  * transitions in one launch (ac_irl.py:683 evaluates it with batch 1 per env step).  fp32.  Weight layouts are
  * PyTorch's: conv1_w [k1*k1], conv2_w [f2][k2*k2], fc3_w [n3][d*d*f2] with the input index (pixel*f2 + channel)

@@ -949,6 +949,60 @@ def test_native_multi_episode_loop_equals_the_per_episode_loop(dev, mode, d, B, 
         assert fa == fb and np.array_equal(va, vb)
 
 
+@pytest.mark.parametrize('d,B,T', [(21, 1000, 15), (15, 77, 15), (47, 30, 4), (128, 40, 5)])
+def test_deferred_update_chain_equals_update_launches(dev, d, B, T):
+    """mfg_train_rollout_deferred: the multi-rank cycle rollout -> sums -> [all-reduce] with the update of episode e applied
+    inside episode e+1's rollout kernel (weight staging; out of place at d > 64) gives bit for bit what
+    rollout -> sums -> [all-reduce] -> mfg_apply_update gives: parameters after every episode, the per-episode reward
+    accumulators and all outputs of the last rollout."""
+    from discrete_mean_field_game_amd import ops
+    rs = np.random.RandomState(d)
+    mat = torch.as_tensor(rs.dirichlet(np.ones(d), size=9).astype(np.float32), device=dev)
+    F = ops.num_features(d)
+    w0 = rs.rand(F)
+    E = 4
+    lrs = [(0.1 / (e + 1), 0.001 / (e + 2)) for e in range(E)]
+    outs = []
+    for deferred in (True, False):
+        theta = torch.tensor([8.86349], dtype=torch.float64, device=dev)
+        w = torch.as_tensor(w0.copy(), device=dev)
+        theta2, w2 = torch.empty_like(theta), torch.empty_like(w)
+        G = torch.zeros(F + 3, dtype=torch.float64, device=dev)
+        ws = ops.workspace(B * T, d, dev)
+        racc = torch.zeros(E, dtype=torch.float64, device=dev)
+        bufs = {'pi_traj': torch.empty(B, T + 1, d, device=dev), 'pi_last': torch.empty(B, d, device=dev),
+                'reward': torch.empty(B, T, device=dev), 'delta': torch.empty(B, T, dtype=torch.float64, device=dev),
+                'g': torch.empty(B, T, dtype=torch.float64, device=dev)}
+        hist = []
+        pending = None
+        for e in range(E):
+            if deferred:
+                ops.train_rollout_deferred(mat, None, T, theta, w, pending, theta2, w2, 0.16, 12000.0, 0.9, G, ws, bufs, seed=5,
+                                           first_step=e * T, traj_offset=11)
+                if pending is not None:
+                    theta, theta2, w, w2 = theta2, theta, w2, w
+                    hist.append((theta.clone(), w.clone()))             # parameters after update e-1
+                pending = (G, lrs[e][0], lrs[e][1], racc.data_ptr() + 8 * e)
+            else:
+                ops.train_rollout(mat, None, T, theta, 0.16, 12000.0, w, 0.9, G, ws, bufs, apply=False, seed=5,
+                                  first_step=e * T, traj_offset=11)
+                ops.apply_update(G, d, lrs[e][0], lrs[e][1], w, theta, racc.data_ptr() + 8 * e)
+                hist.append((theta.clone(), w.clone()))
+        if deferred:
+            ops.apply_update(G, d, lrs[-1][0], lrs[-1][1], w, theta, racc.data_ptr() + 8 * (E - 1))
+            hist.append((theta.clone(), w.clone()))
+        torch.cuda.synchronize()
+        outs.append((hist, racc.clone(), [bufs[k].clone() for k in ('pi_traj', 'reward', 'delta', 'g', 'pi_last')], G.clone()))
+    assert len(outs[0][0]) == len(outs[1][0]) == E
+    for (ta, wa), (tb, wb) in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(ta, tb) and torch.equal(wa, wb)
+    assert torch.equal(outs[0][1], outs[1][1]) and bool((outs[0][1] != 0).all())
+    for x, y in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(x, y)
+    assert torch.equal(outs[0][3], outs[1][3])
+    assert float(outs[0][0][-1][0]) != 8.86349
+
+
 def test_batched_philox_training_uses_no_host_rng(dev):
     """Batched runs draw their start states on the device: train() neither consumes nor depends on np.random (the
     reference's `np.random.randint` at mfg_ac2.py:466 is kept for batch 1 and rng='numpy' only), and the states an episode

@@ -94,6 +94,63 @@ def test_two_rank_gradient_allreduce_equals_single_process():
     assert np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
 
 
+def _worker_flat(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        calls = {'all_reduce': 0, 'broadcast': 0}
+        real_ar, real_bc = dist.all_reduce, dist.broadcast
+
+        def ar(*a, **k):
+            calls['all_reduce'] += 1
+            return real_ar(*a, **k)
+
+        def bc(*a, **k):
+            calls['broadcast'] += 1
+            return real_bc(*a, **k)
+        dist.all_reduce, dist.broadcast = ar, bc
+        # ten "parameter gradients" of the reward net's shapes (networks.py:46-81 at d = 21, n_fc3 = 8, n_fc4 = 4), different
+        # on every rank
+        rs = np.random.RandomState(10 + rank)
+        shapes = [(1, 1, 5, 5), (1,), (2, 1, 3, 3), (2,), (8, 882), (8,), (4, 29), (4,), (1, 4), (1,)]
+        grads = [torch.as_tensor(rs.randn(*sh).astype(np.float32)) for sh in shapes]
+        before = [g.clone() for g in grads]
+        n = parallel.all_reduce_mean_flat_(grads)
+        seed = parallel.broadcast_seed(1000 + 17 * rank)             # every rank proposes a different value: rank 0's wins
+        # the device-side start draw needs no exchange at all: a rank's shard is a slice of the global vector
+        from oracle.philox_ref import start_indices
+        sh = parallel.current_shard(37)
+        idx = start_indices(5, 30, sh.traj_offset + np.arange(sh.local_batch), 64)
+        q.put((rank, [g.numpy().copy() for g in grads], [g.numpy().copy() for g in before], n, dict(calls), seed, idx))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_reward_net_gradient_exchange_is_one_collective_and_host_samplers_are_seeded_from_rank_0():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_flat, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, g0, b0, n0, c0, s0, i0), (_, g1, b1, n1, c1, s1, i1) = res
+    assert n0 == n1 == 1 and c0 == c1 == {'all_reduce': 1, 'broadcast': 1}      # ONE collective for ten tensors
+    assert sum(x.size for x in g0) == 7235                                       # parameter count at d = 21
+    for a, b, x, y in zip(g0, g1, b0, b1):
+        assert np.array_equal(a, b)                                              # replicated after the exchange
+        assert np.allclose(a, (x + y) / 2, rtol=1e-6, atol=1e-7)
+    assert s0 == s1 == 1000
+    from oracle.philox_ref import start_indices
+    assert np.array_equal(np.concatenate([i0, i1]), start_indices(5, 30, np.arange(37), 64))   # shards tile the global draw
+
+
 def test_all_reduce_is_noop_without_process_group():
     G = torch.arange(6, dtype=torch.float64)
     assert torch.equal(parallel.all_reduce_gradients_(G.clone()), G)
@@ -101,3 +158,6 @@ def test_all_reduce_is_noop_without_process_group():
     assert (s.rank, s.world, s.local_batch, s.traj_offset) == (0, 1, 10, 0)
     idx = np.arange(5)
     assert parallel.broadcast_start_indices(idx) is idx
+    g = [torch.ones(3), torch.zeros(2, 2)]
+    assert parallel.all_reduce_mean_flat_(g) == 0 and torch.equal(g[0], torch.ones(3))
+    assert parallel.broadcast_seed(123) == 123
