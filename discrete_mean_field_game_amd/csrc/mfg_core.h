@@ -136,6 +136,8 @@ __device__ __forceinline__ void policy_setup_sep(PolicyElem<true>& e, const Core
   float sg;
   softplus_sigmoid_e(Ej * Fi, e.al_f, sg);
   e.ad_f = x * sg;
+  // (round 4: the lookup through a raw buffer resource -- 32-bit offset instead of a 64-bit address per element -- measured
+  //  0.6 % SLOWER than the plain global load: not kept)
   if (TD) e.psi_ad = x * htab_eval(a.htab, x, ts.thn);
   if (SAMPLE) gamma_setup_hot(e.gs, e.al_f, (float)a.alpha_scale, 9.0f * (float)a.alpha_scale);
 }
@@ -242,22 +244,32 @@ __device__ __forceinline__ void sample_elems_g(const CoreArgs& a, double theta, 
       }
 #endif
     }
-    bool cold = false;
+    // "some lane of the wave needs the exact path": the compare masks of the pair, OR-ed as scalars (gamma_try_mask)
+    uint64_t coldm = 0;
 #pragma unroll
     for (int u = 0; u < PW; ++u) {
       if (u < n2) {
         const int e = PW * h + u;
-        v[u] = gamma_try(pe[u].gs, xn[u], q.kf[e], sure[u]);
+        uint64_t cm;
+        if (quad_kbits(e) == 16) v[u] = gamma_try_mask<16>(pe[u].gs, xn[u], q.kf[e], cm);
+        else v[u] = gamma_try_mask<12>(pe[u].gs, xn[u], q.kf[e], cm);
         y[e] = pe[u].gs.dd * v[u];
-        cold = cold || (valid[e] && (!sure[u] || pe[u].gs.small));
+        coldm |= cm & __builtin_amdgcn_ballot_w64(valid[e]);
       }
     }
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(cold) != 0, 0)) {  // wave-uniform, ~1 % of the pairs at the reference policies
+    const bool any_cold = coldm != 0;
+    if (__builtin_expect(any_cold, 0)) {  // wave-uniform, ~2 % of the pairs at the reference policies
 #pragma unroll
       for (int u = 0; u < PW; ++u) {
         const int e = PW * h + u;
-        if (u < n2 && valid[e] && (!sure[u] || pe[u].gs.small))
-          y[e] = gamma_fix(pe[u].gs, xn[u], q.kf[e], sure[u], v[u], a.seed, elem[e], step, traj);
+        if (u < n2 && valid[e]) {
+          const bool k16 = quad_kbits(e) == 16;
+          if (k16) (void)gamma_try<16>(pe[u].gs, xn[u], q.kf[e], sure[u]);   // (the per-lane flags, recomputed off the hot path)
+          else (void)gamma_try<12>(pe[u].gs, xn[u], q.kf[e], sure[u]);
+          if (!sure[u] || pe[u].gs.small)
+            y[e] = gamma_fix(pe[u].gs, xn[u], q.kf[e], k16 ? TryConst<16>::kscale : TryConst<12>::kscale, sure[u], v[u], a.seed,
+                             elem[e], step, traj);
+        }
       }
     }
 #pragma unroll
@@ -276,8 +288,9 @@ __device__ __forceinline__ void sample_elems_g(const CoreArgs& a, double theta, 
   }
 }
 
-// Small-d wrapper: NE neighbouring elements of ONE row (all valid); the row sums of the NE elements are ADDED to
-// ys / as / ds / gs in the working precision.
+// Small-d wrapper: NE neighbouring elements of ONE row (all valid); ys / as / ds / gs RETURN the sums of the NE elements in
+// the working precision.  (They used to be added onto zero-initialised sums of the caller: `0.0f + x` is not foldable --
+// it turns -0 into +0 -- and cost four v_add_f32 per quad.)
 template <int NE, bool TD, bool FAST, bool SEP>
 __device__ __forceinline__ void sample_elems(const CoreArgs& a, double theta, const ThetaSplit& ts, const float* pj,
                                              const float* ej, float pai, float Fi, uint32_t elem0, uint32_t step,
@@ -296,8 +309,14 @@ __device__ __forceinline__ void sample_elems(const CoreArgs& a, double theta, co
     ok[e] = true;
   }
   sample_elems_g<NE, TD, FAST, SEP>(a, theta, ts, pj, ej, pa, fi, el, ok, step, traj, y, al, ad, gt);
+  ys = y[0];
+  if (TD) {
+    as = al[0];
+    ds = ad[0];
+    gs = gt[0];
+  }
 #pragma unroll
-  for (int e = 0; e < NE; ++e) {
+  for (int e = 1; e < NE; ++e) {
     ys += y[e];
     if (TD) {
       as += al[e];
@@ -368,10 +387,12 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
   double* red = pis64 + (SAMPLE ? 2 * TB * d : 0);  // [TB][4][d]: per-lane terms of reward / score / V(next) / V(start), summed by lane 0 / 1
   float* tile = reinterpret_cast<float*>(red + 4 * TB * d);
   float* pis = tile + TB * d * dp;
-  float* pin = pis + TB * d;       // [TB][pnw]
+  float* pex = pis + TB * d;       // SAMPLE, mixed: E_j = e^{theta pi_j} (separable exponential, mfg_device.h).  DIRECTLY behind
+                                   // pis: the quad loop reads pi_j and E_j of four columns from ONE base address (TB d <= 252
+                                   // floats apart: inside the offset field of ds_read2_b32)
+  float* pin = pex + TB * d;       // [TB][pnw]
   float* pal = pin + TB * 2 * d;
-  float* pex = pal + TB * d;       // SAMPLE, mixed: E_j = e^{theta pi_j} (separable exponential, mfg_device.h)
-  double* scal = reinterpret_cast<double*>(pex + TB * d + ((TB * d) & 1));  // SUMS: (delta, g, r) per trajectory of the tile
+  double* scal = reinterpret_cast<double*>(pal + TB * d + ((TB * d) & 1));  // SUMS: (delta, g, r) per trajectory of the tile
   double* tot = scal + TB * 3;                           // [TB][8]: even / odd partial sums of the per-trajectory sums
   float* pst = reinterpret_cast<float*>(tot + TB * 8);   // [TB][pnw]: the rollout's START state (doubled for CIRC): its value is
                                                          // evaluated inside step 0, next to V of the next state
@@ -536,6 +557,47 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
           const uint32_t erow = (uint32_t)(i * d);
           const float pas = sep ? pai + ts.sh : pai;  // row operand of the sampler (policy_setup_sep takes pi_i + shift)
           const int dq = d & ~3;
+          if constexpr (D > 0 && sep) {
+            // Running LDS pointers (address space 3, one VGPR each), made opaque to the loop optimiser once per iteration:
+            // with the scalar loop counter it re-derived SIX vector addresses per quad from it (two shifts-and-adds and four
+            // constant adds); now pi_j and E_j of the quad come from one base with immediate offsets (E_j sits TB*D floats
+            // behind pi_j) and the tile row from a second one: two v_add_u32 per quad.
+            typedef __attribute__((address_space(3))) const float lds_cf;
+            typedef __attribute__((address_space(3))) float lds_f;
+            constexpr int EOFF = WAVES * (WAVE / D) * D;  // floats from pis to pex
+            static_assert(EOFF + 3 <= 255, "E_j must sit inside the ds_read2_b32 offset field of the pi_j base");
+            lds_cf* rp = (lds_cf*)pav;
+            lds_f* wp = (lds_f*)trow;
+            // one full quad at columns j .. j+3 through the running pointers
+            auto quad = [&](int j, float& ys, TT& as, TT& ds, TT& gs) __attribute__((always_inline)) {
+              float y[4], pjv[4], ejv[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                pjv[e] = rp[e];
+                ejv[e] = rp[EOFF + e];
+              }
+              sample_elems<4, TD, FAST, sep>(a, theta, ts, pjv, ejv, pas, Fi, erow + (uint32_t)j, step, traj, y, ys, as, ds, gs);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) wp[e] = y[e];
+              rp += 4;
+              wp += 4;
+              asm volatile("" : "+v"(rp), "+v"(wp));
+            };
+#pragma unroll 1
+            for (int j = 0; j < dq; j += 4) {
+              float ys;
+              TT as, ds, gs;
+              quad(j, ys, as, ds, gs);
+              Ssum += (double)ys;
+              if (TD) {
+                A += (double)as;
+                D_ += (double)ds;
+                gacc += (double)gs;
+              }
+            }
+            // (folding the quad sums in PAIRS of quads -- half the conversions and fp64 adds -- needs a two-quad loop body:
+            //  twice the code, every cold continuation replicated; measured 1.08 -> 1.27 ms.  Not kept.)
+          } else
 #pragma unroll 1
           for (int j = 0; j < dq; j += 4) {
             float y[4], ys = 0.0f;

@@ -140,8 +140,18 @@ __device__ __forceinline__ float box_muller_radius(uint32_t r) {
 struct QuadRand {
   float radu[2];   // radius uniforms in (0,1)
   float ang[2];    // angles in revolutions, (0,1)
-  float kf[4];     // 12-bit acceptance integers as floats, 0 .. 4095
+  float kf[4];     // acceptance integers as floats: 0 .. 2^KBITS(e) - 1
 };
+// Bit layout of the quad block r = (x, y, z, w) (round 4):
+//   radius uniform of pair h: the top 20 bits of r.x / r.y        ((k + 1/2) 2^-20: Box-Muller radii up to 5.4)
+//   angle of pair h:          high / low half of r.z               (16 bits)
+//   acceptance integers:      k0 = r.w >> 16, k1 = r.w & 0xFFFF    (16 bits: elements 0, 1)
+//                             k2 = r.x & 0xFFF, k3 = r.y & 0xFFF   (12 bits: elements 2, 3)
+// Every field is one shift / mask / half-word select away from its word (round 2 cut 4 x 12 bits out of r.w and the low
+// BYTES of r.x, r.y: 8 instructions per quad for k2, k3 alone), and the two 16-bit integers are undecided 16 times less
+// often: the wave-uniform exact-path branch was taken by 3.4 % of the pairs (any of 128 elements with k in the top cell of
+// 4096) at ~110 instructions each -- 1.9 instructions per element on average; now 1.8 % of the pairs.
+__host__ __device__ constexpr int quad_kbits(int e) { return e < 2 ? 16 : 12; }
 
 __device__ __forceinline__ void quad_rand(QuadRand& q, uint64_t seed, uint32_t elem0, uint32_t step, uint64_t traj) {
 #ifdef MFG_ABL_PHILOX  // timing ablation only (tools/ablate.sh): a two-multiply hash instead of the Philox block
@@ -153,23 +163,24 @@ __device__ __forceinline__ void quad_rand(QuadRand& q, uint64_t seed, uint32_t e
 #else
   const u32x4 r = philox_elem(seed, elem0, step, traj, 0);
 #endif
-  q.radu[0] = u01(r.x);
-  q.radu[1] = u01(r.y);
   q.ang[0] = fmaf((float)(r.z >> 16), 1.52587890625e-5f, 7.62939453125e-6f);
   q.ang[1] = fmaf((float)(r.z & 0xFFFFu), 1.52587890625e-5f, 7.62939453125e-6f);
-  q.kf[0] = (float)(r.w >> 20);
-  q.kf[1] = (float)((r.w >> 8) & 0xFFFu);
-  q.kf[2] = (float)(((r.w & 0xFFu) << 4) | (r.x & 0xFu));
-  q.kf[3] = (float)((((r.x >> 4) & 0xFu) << 8) | (r.y & 0xFFu));
+  q.radu[0] = fmaf((float)(r.x >> 12), 9.5367431640625e-7f, 4.76837158203125e-7f);   // (k + 1/2) 2^-20
+  q.radu[1] = fmaf((float)(r.y >> 12), 9.5367431640625e-7f, 4.76837158203125e-7f);
+  q.kf[0] = (float)(r.w >> 16);
+  q.kf[1] = (float)(r.w & 0xFFFFu);
+  q.kf[2] = (float)(r.x & 0xFFFu);
+  q.kf[3] = (float)(r.y & 0xFFFu);
 }
 
 // Exact continuation for one element: returns v = (1 + c x)^3 of the accepted draw.
-__device__ __forceinline__ float gamma_exact_path(const GammaState& g, float x, float kf, uint64_t seed, uint32_t elem,
-                                                  uint32_t step, uint64_t traj) {
+//   kscale = 2^-KBITS of the element's acceptance integer kf (quad_kbits)
+__device__ __forceinline__ float gamma_exact_path(const GammaState& g, float x, float kf, float kscale, uint64_t seed,
+                                                  uint32_t elem, uint32_t step, uint64_t traj) {
   float v = 1.0f;
   {
     const u32x4 r = philox_elem(seed, elem, step, traj, 1);
-    const float u = (kf + u01(r.x)) * 2.44140625e-4f;  // the element's full-precision acceptance uniform
+    const float u = (kf + u01(r.x)) * kscale;  // the element's full-precision acceptance uniform
     if (mt_accept(g, x, u, v)) return v;
   }
   for (uint32_t block = 2; block < 64; ++block) {
@@ -180,36 +191,62 @@ __device__ __forceinline__ float gamma_exact_path(const GammaState& g, float x, 
   return 1.0f;  // never reached in practice
 }
 
-// Branch-free hot half of the quad sampler: v = (1 + c x)^3 and whether the 12 leading
-// acceptance bits already decide the draw.
+// Branch-free hot half of the quad sampler: v = (1 + c x)^3 and whether the KB leading acceptance bits already decide
+// the draw.
+//   (kf + 1) / 2^KB <= 1 - x^2 (0.19 t^2 + 1e-6)   <=>   kf <= 2^KB - 1 - 0.19 2^KB (x t)^2 - 2^KB 1e-6 x^2.  Box-Muller radii
+//   stay below 5.89 (24-bit uniforms; 5.4 with the 20-bit uniforms of the v2 layout), so the last term is < 2^KB 3.5e-5: a
+//   constant keeps the bound (conservatively) and the test needs (x t)^2 only -- two instructions fewer than forming t^2,
+//   x^2 and the inner fma.   KB = 12: kf <= 4094.85 - 778.24 (x t)^2;   KB = 16: kf <= 65532.7 - 12451.84 (x t)^2.
+template <int KB>
+struct TryConst {
+  static constexpr float slope = KB == 16 ? -12451.84f : -778.24f;
+  static constexpr float top = KB == 16 ? 65532.7f : 4094.85f;
+  static constexpr float kscale = KB == 16 ? 1.52587890625e-5f : 2.44140625e-4f;
+};
+template <int KB = 12>
 __device__ __forceinline__ float gamma_try(const GammaState& g, float x, float kf, bool& sure) {
 #ifdef MFG_ABL_TRY
   sure = true;
   return 1.0f + 3.0f * g.c * x;
 #endif
   const float t = g.c * x;
-  // (kf + 1) / 4096 <= 1 - x^2 (0.19 t^2 + 1e-6)   <=>   kf <= 4095 - 778.24 (x t)^2 - 4.096e-3 x^2.  Box-Muller radii from
-  // 24-bit uniforms stay below 5.89, so the last term is < 0.15: a constant keeps the bound (conservatively) and the test
-  // needs (x t)^2 only -- two instructions fewer than forming t^2, x^2 and the inner fma.
   const float q = x * t;
-  const float thr = fmaf(q * q, -778.24f, 4094.85f);
+  const float thr = fmaf(q * q, TryConst<KB>::slope, TryConst<KB>::top);
   sure = (fabsf(t) <= 0.5f) && (kf <= thr);
   return 1.0f + t * (3.0f + t * (3.0f + t));
 }
+// The same, with the "not decided / small shape" condition returned as a WAVE MASK (bit = lane) straight from the compare
+// instructions: the sampling loop only asks "any lane?", which is then a scalar test of the mask.  (A per-lane bool that is
+// OR-ed over the pair and passed through the ballot builtin compiled to v_cndmask + v_cmp per pair on top of the scalar
+// mask arithmetic: 1 VALU instruction per element.)  Unordered compares: a NaN anywhere sends the element to the cold path.
+template <int KB>
+__device__ __forceinline__ float gamma_try_mask(const GammaState& g, float x, float kf, uint64_t& cold) {
+#ifdef MFG_ABL_TRY
+  cold = 0;
+  return 1.0f + 3.0f * g.c * x;
+#endif
+  const float t = g.c * x;
+  const float q = x * t;
+  const float thr = fmaf(q * q, TryConst<KB>::slope, TryConst<KB>::top);
+  constexpr int FCMP_OLT = 4, FCMP_UGT = 10;
+  cold = __builtin_amdgcn_fcmpf(fabsf(t), 0.5f, FCMP_UGT) | __builtin_amdgcn_fcmpf(kf, thr, FCMP_UGT) |
+         __builtin_amdgcn_fcmpf(g.dd, 2.0f / 3.0f, FCMP_OLT);
+  return 1.0f + t * (3.0f + t * (3.0f + t));
+}
 // Cold half: exact continuation and the shape < 1 boost; returns the variate.
-__device__ __forceinline__ float gamma_fix(const GammaState& g, float x, float kf, bool sure, float v, uint64_t seed,
-                                           uint32_t elem, uint32_t step, uint64_t traj) {
+__device__ __forceinline__ float gamma_fix(const GammaState& g, float x, float kf, float kscale, bool sure, float v,
+                                           uint64_t seed, uint32_t elem, uint32_t step, uint64_t traj) {
   if (g.small) {
     // shape < 1: Gamma(a) = Gamma(a + 1) U^(1/a); the boosted draw runs the exact test from the start
     GammaState gb;
     gamma_setup(gb, g.a);
-    v = gamma_exact_path(gb, x, kf, seed, elem, step, traj);
+    v = gamma_exact_path(gb, x, kf, kscale, seed, elem, step, traj);
     const u32x4 rb = philox_elem(seed, elem, step, traj, 0xFFFFu);
     float y = gb.dd * v * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u01(rb.x)) * __builtin_amdgcn_rcpf(g.a));
     if (y == 0.0f) y = ZERO_GAMMA_REPLACEMENT;  // underflow of the boost (mfg_ac2.py:244)
     return y;
   }
-  if (!sure) v = gamma_exact_path(g, x, kf, seed, elem, step, traj);
+  if (!sure) v = gamma_exact_path(g, x, kf, kscale, seed, elem, step, traj);
   return g.dd * v;
 }
 
