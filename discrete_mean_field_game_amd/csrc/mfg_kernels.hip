@@ -2414,7 +2414,11 @@ static int launch_core(const CoreArgs& a_in, bool sample, bool td, int precision
     const StatusWord sw = status_word();
     if (!sw.host) return fail(MFG_ELAUNCH, "%s", "status word allocation failed");
     const unsigned bits = *(volatile unsigned*)sw.host;
-    if (bits) return status_error(bits);  // sticky until mfg_clear_status()
+    // sticky until mfg_clear_status() -- for the launches the condition concerns: MFG_STATUS_MIXED_RANGE is a property of
+    // mixed-precision SAMPLING (theta beyond the range of its fp32 factors); strict-precision launches and launches on given
+    // actions have no such limit and go ahead whatever another instance / thread on this device ran into
+    const unsigned blocking = (sample && precision == MFG_PRECISION_MIXED) ? bits : (bits & ~(unsigned)MFG_STATUS_MIXED_RANGE);
+    if (blocking) return status_error(blocking);
     a.status = sw.dev;
   }
 #ifdef MFG_TIMING

@@ -523,6 +523,9 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
     __builtin_amdgcn_wave_barrier();
   }
   if constexpr (SUMS) {
+    // (a geometry with D > 31, or conv kernels so small that the tiles are shorter than the rows, would overflow LDS silently)
+    static_assert(D + 1 <= 32, "the per-wave line [state | 1] of the SUMS variant holds 32 floats");
+    static_assert(RN_WAVES * FO * 8 <= RN_WAVES * (Gm::T1 + Gm::T2) * 4, "the waves' partial rows reuse the tile region");
     __syncthreads();  // every wave is done with its tiles: they now hold the waves' rows
     double* rows = reinterpret_cast<double*>(smem + off);
 #pragma unroll
@@ -577,7 +580,11 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
   int64_t grid = (B + RN_WAVES - 1) / RN_WAVES;
   if (grid > 256 * MFG_RN_BPC) grid = 256 * MFG_RN_BPC;
   // stage the FC3 weights in LDS only when a block amortises the copy over enough samples (and the pointer is
-  // 16-byte aligned); otherwise they are read straight from L2 (coalesced, 28 KB at d = 21)
+  // 16-byte aligned); otherwise they are read straight from L2 (coalesced, 28 KB at d = 21).
+  // (Round 4, tried for the one-sample-per-wave launches of the per-step IRL update, B = 4 096: fetch the weights into
+  //  registers under the convolutions and commit them to LDS in front of the first FC3 -- 19.7 -> 20.5 us per launch and
+  //  0.527 -> 0.625 ms per 15-step episode: the block barrier in front of FC3 makes all eight waves wait for the slowest
+  //  convolution, which costs more than the L2 round trips it removes.  Not kept.)
   const int64_t samples_per_block = (B + grid - 1) / grid;
   a.w3_in_lds = (w3fl * 4 <= 64 * 1024 && samples_per_block >= MFG_RN_LDS_MIN && (((uintptr_t)fc3_w & 15) == 0)) ? 1 : 0;
   if (a.w3_in_lds) fl += w3fl;

@@ -424,6 +424,10 @@ class actor_critic:
             if 'pi_ep' not in bufs:
                 bufs['pi_ep'] = torch.empty(Bl, d, dtype=torch.float32, device=self.device)
             pi_ep = bufs['pi_ep']
+        # reports (every `consecutive` episodes): in the native loop their values are read back behind the NEXT chunk of
+        # episodes; a subclass hook that reads the live parameters (mfg_synthetic logs w) keeps the immediate form
+        defer_reports = native_loop and type(self)._train_log_extra is actor_critic._train_log_extra
+        report = None
         episode = 0
         while episode < num_episodes:
             if native_loop:
@@ -456,23 +460,49 @@ class actor_critic:
                 self._flush_pending()
             if self.check_finite:
                 self._raise_if_not_finite(pi, episode)
+            if report is not None:
+                # the previous report: its values were copied out asynchronously BEFORE the chunk above was enqueued, so
+                # waiting for them does not drain the launch stream (the GPU keeps working on that chunk meanwhile)
+                self._emit_report(report, consecutive, write_file, file_theta, file_pi, file_reward)
+                report = None
             if episode % consecutive == 0:
                 # the reference divides the sum over the window by `consecutive` even at episode 0 (:530-534)
-                reward_avg = float(ep_reward[window_start:episode + 1].sum().cpu()) * ret_scale / consecutive
+                report = self._snapshot_report(ep_reward, window_start, episode, pi, ret_scale)
                 window_start = episode + 1
-                pi_host = pi[0].cpu().numpy().astype(np.float64)
-                if self.verbose:
-                    print('Theta\n', self.theta)
-                    print('pi\n', pi_host)
-                    print('Average reward during previous %d episodes: ' % consecutive, str(reward_avg))
-                if write_file:
-                    self.train_log(np.ravel(self.theta), file_theta, '%.5e')
-                    self.train_log(pi_host, file_pi, '%.3e')
-                    self.train_log(np.array([reward_avg]), file_reward, '%.3e')
-                    self._train_log_extra()
+                if not defer_reports:
+                    self._emit_report(report, consecutive, write_file, file_theta, file_pi, file_reward)
+                    report = None
             episode += 1
+        if report is not None:
+            self._emit_report(report, consecutive, write_file, file_theta, file_pi, file_reward)
         self._last_pi = pi
         self._check_status()
+
+    def _snapshot_report(self, ep_reward, window_start, episode, pi, ret_scale):
+        """Values of a report (theta, the first trajectory's state, the window's reward sum) copied to pinned host memory
+        without waiting: device-side snapshots, non-blocking copies, one event."""
+        host = torch.empty(self.d + 2, dtype=torch.float64, pin_memory=True)
+        dev = torch.cat([self._theta, ep_reward[window_start:episode + 1].sum().reshape(1) * ret_scale, pi[0].double()])
+        host.copy_(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return {'host': host, 'event': ev, 'dev': dev, 'theta_is_array': self._theta_is_array}
+
+    def _emit_report(self, report, consecutive, write_file, file_theta, file_pi, file_reward):
+        report['event'].synchronize()
+        h = report['host'].numpy()
+        theta = np.array([h[0]]) if report['theta_is_array'] else float(h[0])
+        reward_avg = float(h[1]) / consecutive
+        pi_host = h[2:].astype(np.float32).astype(np.float64)       # (the state is fp32 on the device)
+        if self.verbose:
+            print('Theta\n', theta)
+            print('pi\n', pi_host)
+            print('Average reward during previous %d episodes: ' % consecutive, str(reward_avg))
+        if write_file:
+            self.train_log(np.ravel(theta), file_theta, '%.5e')
+            self.train_log(pi_host, file_pi, '%.3e')
+            self.train_log(np.array([reward_avg]), file_reward, '%.3e')
+            self._train_log_extra()
 
     def _flush_pending(self):
         """Apply the update a multi-rank rollout-mode episode left pending (see _train_one_episode): before anything reads
@@ -573,9 +603,10 @@ class actor_critic:
 
     def _check_status(self):
         """Raise MfgError if a launch of this run reported a numeric-range condition (mixed-precision sampling with
-        theta outside its range, include/mfg_hip.h mfg_status) -- the end-of-train check; during a run the next launch
-        after the condition is refused by the library itself."""
-        if ops.status(synchronize=True):
+        theta outside its range, include/mfg_hip.h mfg_status) -- the end-of-train check; during a run the next sampling
+        launch after the condition is refused by the library itself.  The word is one per device: an instance the condition
+        cannot concern (strict precision, host-injected variates) does not raise for another instance's bit."""
+        if self.precision == 'mixed' and self.rng == 'philox' and ops.status(synchronize=True):
             L.check(L.lib().mfg_status(None), 'train')
 
     def _train_log_extra(self):

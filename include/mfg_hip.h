@@ -77,11 +77,13 @@ int mfg_init(void);
  * factors e^{theta (pi_j - 1/2)} e^{-theta (pi_i + shift - 1/2)}; that is exact business as usual while
  * |theta| (1/2 + |shift|) <= 86 (theta ~ 130 at the reference's shift 0.16; the reference trains at theta ~ 9).  theta lives
  * on the device, so the host cannot check it before a launch: a sampling kernel that finds theta outside that range (or
- * not finite) sets MFG_STATUS_MIXED_RANGE in a host-visible status word and its outputs are NaN.  EVERY later call that
- * launches a policy kernel (sample / score / td / rollout / train entry points) then fails with MFG_ERANGE until
- * mfg_clear_status() -- a diverged run stops with an error code instead of carrying NaNs.  mfg_status() reads the word
- * without synchronising (synchronise the stream first to be sure a given launch has reported); it returns MFG_OK or
- * MFG_ERANGE and stores the bits in *bits_host (may be NULL).  MFG_PRECISION_F64 has no such limit. */
+ * not finite) sets MFG_STATUS_MIXED_RANGE in a host-visible status word and its outputs are NaN.  Every later call that
+ * launches a mixed-precision SAMPLING kernel (sample / rollout / train entry points with MFG_PRECISION_MIXED) then fails
+ * with MFG_ERANGE until mfg_clear_status() -- a diverged run stops with an error code instead of carrying NaNs.  The word is
+ * one per device and process: launches the condition does not concern (MFG_PRECISION_F64, kernels on given actions) are
+ * not refused, so another model instance or thread on the device keeps working.  mfg_status() reads the word without
+ * synchronising (synchronise the stream first to be sure a given launch has reported); it returns MFG_OK or MFG_ERANGE and
+ * stores the bits in *bits_host (may be NULL). */
 enum { MFG_STATUS_MIXED_RANGE = 1 };
 int mfg_status(unsigned* bits_host);
 int mfg_clear_status(void);

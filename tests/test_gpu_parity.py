@@ -738,8 +738,8 @@ def test_mixed_sampler_range_of_the_separable_exponential(dev):
     """Mixed precision forms e^{theta (pi_j - pi_i - shift)} as E_j F_i, fp32 factors centred on pi = 1/2.  Inside the
     documented range, |theta| (1/2 + |shift|) <= 86, the sampler is still exact (KS on Beta marginals at theta = 40 and,
     on a peaked state, at theta = 100, where the uncentred factors of round 2 overflowed).  Beyond it the launch must not
-    fail silently: the outputs are NaN, the device status word reports MFG_STATUS_MIXED_RANGE, and every later policy
-    launch is refused with MFG_ERANGE until mfg_clear_status(); precision 'f64' has no such limit."""
+    fail silently: the outputs are NaN, the device status word reports MFG_STATUS_MIXED_RANGE, and every later
+    mixed-precision sampling launch is refused with MFG_ERANGE until mfg_clear_status(); precision 'f64' has no such limit."""
     from scipy import stats
     from discrete_mean_field_game_amd import _lib as L
     o_ = ops()
@@ -768,12 +768,13 @@ def test_mixed_sampler_range_of_the_separable_exponential(dev):
     assert o_.status() == L.STATUS_MIXED_RANGE
     with pytest.raises(L.MfgError, match='86'):                   # sticky: the next policy launch is refused
         o_.sample_dirichlet(t32(peaked, dev), t64([8.0], dev), shift, scale, seed=11, precision='mixed')
-    with pytest.raises(L.MfgError):
-        o_.score(t32(peaked, dev), Pm, t64([8.0], dev), shift)
-    o_.clear_status()
-    assert o_.status() == 0
+    # ... and only the launches the condition concerns: strict-precision sampling and launches on given actions (another
+    # model instance or thread on this device) are not held up by it
     Pf = o_.sample_dirichlet(t32(peaked, dev), big, shift, scale, seed=11, precision='f64')
     assert bool(torch.isfinite(Pf).all()) and bool((Pf.sum(-1) - 1).abs().max() < 1e-5)
+    assert bool(torch.isfinite(o_.score(t32(peaked, dev), Pf, t64([8.0], dev), shift)).all())
+    assert o_.status() == L.STATUS_MIXED_RANGE                   # still set: f64 launches neither report nor clear it
+    o_.clear_status()
     assert o_.status() == 0
     # a NaN theta is reported as well (the test is !(x <= limit))
     o_.sample_dirichlet(t32(peaked, dev), t64([float('nan')], dev), shift, scale, seed=11, precision='mixed')
