@@ -180,6 +180,11 @@ __device__ __forceinline__ PolicyTerms<FAST> policy_terms(const PolicyElem<FAST>
     const float lnv = (!SAMPLE && v == 0.0f) ? (float)(LOG_ZERO_P * INV_LN2) : __builtin_amdgcn_logf(v);
 #endif
     o.al = e.al_f;
+#ifdef MFG_ABL_TERMS  // instruction-count ablation: no alpha' / score term arithmetic
+    o.ad = e.al_f;
+    o.gt = lnv;
+    return o;
+#endif
     o.ad = e.ad_f;
     o.gt = fmaf(lnv, e.ad_f, -e.psi_ad);
   } else {
@@ -315,6 +320,14 @@ __device__ __forceinline__ void sample_elems(const CoreArgs& a, double theta, co
     ds = ad[0];
     gs = gt[0];
   }
+#ifdef MFG_ABL_FOLD  // instruction-count ablation: the other elements' terms are kept alive but not added
+#pragma unroll
+  for (int e = 1; e < NE; ++e) {
+    asm volatile("" ::"v"(y[e]));
+    if (TD) asm volatile("" ::"v"(al[e]), "v"(ad[e]), "v"(gt[e]));
+  }
+  return;
+#endif
 #pragma unroll
   for (int e = 1; e < NE; ++e) {
     ys += y[e];
@@ -520,8 +533,13 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
         }
         if (SAMPLE) pis64[2 * (tlc * d + i)] = (double)pi_i;
         if (sep) {
+#ifdef MFG_ABL_EF  // instruction-count ablation: no per-step E / F exponentials
+          pex[tlc * d + i] = pi_i;
+          Fi = 0.25f;
+#else
           pex[tlc * d + i] = exp_f64arg(theta * ((double)pi_i - SEP_CENTRE));
           Fi = exp_f64arg(-theta * ((double)pi_i + (a.shift - SEP_CENTRE)));
+#endif
         }
       }
       if (!SAMPLE) {
@@ -577,23 +595,35 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
                 ejv[e] = rp[EOFF + e];
               }
               sample_elems<4, TD, FAST, sep>(a, theta, ts, pjv, ejv, pas, Fi, erow + (uint32_t)j, step, traj, y, ys, as, ds, gs);
+#ifdef MFG_ABL_TSTORE  // instruction-count ablation: no tile stores (the variates are kept alive)
+              asm volatile("" ::"v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));
+              rp += 4;
+              asm volatile("" : "+v"(rp));
+#else
 #pragma unroll
               for (int e = 0; e < 4; ++e) wp[e] = y[e];
               rp += 4;
               wp += 4;
               asm volatile("" : "+v"(rp), "+v"(wp));
+#endif
             };
 #pragma unroll 1
             for (int j = 0; j < dq; j += 4) {
               float ys;
               TT as, ds, gs;
               quad(j, ys, as, ds, gs);
+#ifdef MFG_ABL_FOLD  // instruction-count ablation: no conversions / fp64 adds of the quad sums
+              asm volatile("" ::"v"(ys));
+              if (TD) asm volatile("" ::"v"(as), "v"(ds), "v"(gs));
+              Ssum = 1000.0, A = 3.0, D_ = 0.5;
+#else
               Ssum += (double)ys;
               if (TD) {
                 A += (double)as;
                 D_ += (double)ds;
                 gacc += (double)gs;
               }
+#endif
             }
             // (folding the quad sums in PAIRS of quads -- half the conversions and fp64 adds -- needs a two-quad loop body:
             //  twice the code, every cold continuation replicated; measured 1.08 -> 1.27 ms.  Not kept.)

@@ -163,6 +163,12 @@ __device__ __forceinline__ void quad_rand(QuadRand& q, uint64_t seed, uint32_t e
 #else
   const u32x4 r = philox_elem(seed, elem0, step, traj, 0);
 #endif
+#ifdef MFG_ABL_KBITS  // instruction-count ablation (tools/cycle_table.sh): the block is kept alive, its fields are not extracted
+  asm volatile("" ::"v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w));
+  q.ang[0] = 0.11f, q.ang[1] = 0.23f, q.radu[0] = 0.37f, q.radu[1] = 0.41f;
+  q.kf[0] = q.kf[1] = q.kf[2] = q.kf[3] = 1.0f;
+  return;
+#endif
   q.ang[0] = fmaf((float)(r.z >> 16), 1.52587890625e-5f, 7.62939453125e-6f);
   q.ang[1] = fmaf((float)(r.z & 0xFFFFu), 1.52587890625e-5f, 7.62939453125e-6f);
   q.radu[0] = fmaf((float)(r.x >> 12), 9.5367431640625e-7f, 4.76837158203125e-7f);   // (k + 1/2) 2^-20

@@ -3,10 +3,11 @@
 # kernels at d = 21 / 128 / 256, SQ issue counters of the fused rollout kernels at the bench shape, C3 and the C5 share).
 # Counters are collected in their own runs (never combined with the trace domains gpurun refuses).
 # usage: bash tools/profile_round.sh <tag>     (outputs under gpurun_out/<tag>/; copy the summaries into profiles/)
-R=$GRAFT_REPO_ROOT; TAG=${1:-r03}; O=$R/gpurun_out/$TAG; mkdir -p $O
+R=$GRAFT_REPO_ROOT; TAG=${1:-r04}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 $R/bench.py --steps 10 --warmup 2 > $O/bench_under_rocprof.json 2> $O/prof.err
+# (the CPU-baseline leg forks one process per host core; it is left out of the traced run -- the kernels are the same)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/prof.err
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 for SH in 21,15,65536 128,1,16384 256,1,16384; do
   N=${SH//,/_}
@@ -36,3 +37,10 @@ for SH in 21,15,65536 128,40,16384 256,40,16384; do bash $R/tools/cycle_table.sh
 bash $R/tools/trace_gaps.sh $R/tools/irl_mode_probe.py 4096 > $O/irl_step_mode_trace.txt 2>&1
 python3 $R/tools/perf_train.py 4096 > $O/perf_train_4096.txt 2>&1
 python3 $R/tools/perf_train.py 65536 > $O/perf_train_65536.txt 2>&1
+python3 $R/tools/irl_step_probe.py 4096 > $O/irl_step_probe_4096.txt 2>&1
+# round 4: the multi-rank update cycle on a 1-rank RCCL communicator (bench.py --force-dist: per-episode loop, deferred update,
+# ONE all-reduce per update) at the 8-GPU shard and the full batch, with the measured latency of the exchange step
+for BB in 8192 65536; do
+  MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 python3 $R/bench.py --gpus 1 --force-dist --steps 50 --warmup 10 \
+    --no-configs --no-cpu-baseline --no-roofline --batch $BB > $O/collective_1rank_$BB.json 2> $O/collective_1rank_$BB.err
+done

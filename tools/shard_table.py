@@ -43,9 +43,21 @@ def probe(d, T, B, prec='mixed'):
     t_core = timeit(lambda: ops.rollout(pi, T, th, 0.16, 12000.0, w=w, seed=1, td=True, reward_kind=2, out=out, precision=prec))
     t_sums = timeit(lambda: ops.train_rollout(mat, idx, T, th, 0.16, 12000.0, w, 1.0, G, ws, bufs, 0.0, 0.0, apply=False, seed=1, precision=prec))
     t_upd = timeit(lambda: ops.train_rollout(mat, idx, T, th, 0.16, 12000.0, w, 1.0, G, ws, bufs, 0.0, 0.0, apply=True, seed=1, precision=prec))
-    print('d=%d T=%d B=%6d  rollout kernel %8.1f us   rollout+sums %8.1f us   full update %8.1f us   %.3e env-steps/s'
-          % (d, T, B, t_core * 1e6, t_sums * 1e6, t_upd * 1e6, B * T / t_upd), flush=True)
-    return t_core, t_sums, t_upd
+    # a rank's cycle in a multi-GPU job (round 4): rollout with the PREVIOUS update applied in its weight staging | sums --
+    # no update launch; start rows drawn in the kernel.  (The all-reduce between two cycles is not part of this number.)
+    th2, w2 = torch.empty_like(th), torch.empty_like(w)
+    state = {'p': (th, w), 'q': (th2, w2)}
+
+    def cycle():
+        (ta, wa), (tb, wb) = state['p'], state['q']
+        ops.train_rollout_deferred(mat, None, T, ta, wa, (G, 0.0, 0.0, None), tb, wb, 0.16, 12000.0, 1.0, G, ws, bufs, seed=1,
+                                   precision=prec)
+        state['p'], state['q'] = (tb, wb), (ta, wa)
+    G[F + 2] = 1.0
+    t_cyc = timeit(cycle)
+    print('d=%d T=%d B=%6d  rollout kernel %8.1f us   rollout+sums %8.1f us   full update %8.1f us   multi-rank cycle (deferred update) %8.1f us   %.3e env-steps/s'
+          % (d, T, B, t_core * 1e6, t_sums * 1e6, t_upd * 1e6, t_cyc * 1e6, B * T / t_upd), flush=True)
+    return t_core, t_sums, t_upd, t_cyc
 
 
 if __name__ == '__main__':
@@ -55,6 +67,17 @@ if __name__ == '__main__':
     Bs = a[2:] if len(a) > 2 else [65536, 32768, 16384, 8192, 4096, 2048, 1024]
     res = {B: probe(d, T, B) for B in Bs}
     if 65536 in res and 8192 in res:
-        for ar in (0.0, 20e-6, 30e-6):
-            print('projected strong scaling, all-reduce + apply = %2.0f us: ' % (ar * 1e6)
-                  + '  '.join('%dx: %.2f' % (n, res[65536][2] / (res[65536 // n][1] + ar)) for n in (2, 4, 8) if 65536 // n in res))
+        # exchange step = ONE all-reduce of G (the update itself rides in the next rollout).  Measured input: the 1-rank RCCL
+        # all-reduce of the 2 KB buffer on this box (profiles/rNN_collective_1rank.json: ~10 us of launch + kernel); an
+        # 8-rank ring over xGMI adds hops, so 10 us is the floor, 20 / 30 us the assumption of earlier rounds
+        ar_meas = None
+        try:
+            import json, glob
+            f = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r*_collective_1rank.json')))
+            if f:
+                ar_meas = json.load(open(f[-1]))['collective']['all_reduce_us'] * 1e-6
+        except Exception:
+            pass
+        for ar in [0.0] + ([ar_meas] if ar_meas else []) + [20e-6, 30e-6]:
+            print('projected strong scaling, all-reduce = %4.1f us%s: ' % (ar * 1e6, ' (measured, 1 rank)' if ar is ar_meas and ar_meas else '')
+                  + '  '.join('%dx: %.2f' % (n, res[65536][2] / (res[65536 // n][3] + ar)) for n in (2, 4, 8) if 65536 // n in res))
