@@ -117,7 +117,7 @@ __device__ __forceinline__ void policy_setup(PolicyElem<FAST>& e, const CoreArgs
     softplus_sigmoid_fast(zh, zl, e.al_f, sg);
     e.ad_f = x * sg;
     if (TD) e.psi_ad = x * htab_eval(a.htab, x, ts.thn);  // fp32 product is ample for a table lookup (|dh/dz| < 1)
-    if (SAMPLE) gamma_setup_hot(e.gs, e.al_f, (float)a.alpha_scale, 9.0f * (float)a.alpha_scale);
+    if (SAMPLE) gamma_setup_hot(e.gs, e.al_f, (float)a.alpha_scale, (9.0f / BM_K2) * (float)a.alpha_scale);
   } else {
     const double x = (double)pj - (double)pi - a.shift;
     double sg;
@@ -139,7 +139,7 @@ __device__ __forceinline__ void policy_setup_sep(PolicyElem<true>& e, const Core
   // (round 4: the lookup through a raw buffer resource -- 32-bit offset instead of a 64-bit address per element -- measured
   //  0.6 % SLOWER than the plain global load: not kept)
   if (TD) e.psi_ad = x * htab_eval(a.htab, x, ts.thn);
-  if (SAMPLE) gamma_setup_hot(e.gs, e.al_f, (float)a.alpha_scale, 9.0f * (float)a.alpha_scale);
+  if (SAMPLE) gamma_setup_hot(e.gs, e.al_f, (float)a.alpha_scale, (9.0f / BM_K2) * (float)a.alpha_scale);
 }
 
 // Fold one finished element into the row sums / score.  v = gamma variate (SAMPLE) or stored probability.
@@ -151,7 +151,7 @@ __device__ __forceinline__ void policy_accumulate(const PolicyElem<FAST>& e, con
     const float lnv = (!SAMPLE && v == 0.0f) ? (float)(LOG_ZERO_P * INV_LN2) : __builtin_amdgcn_logf(v);  // log2 units
     A += (double)e.al_f;
     D += (double)e.ad_f;
-    gacc += (double)fmaf(lnv, e.ad_f, -e.psi_ad);
+    gacc += (double)__builtin_fmaf(lnv, e.ad_f, -e.psi_ad);
   } else {
     const double lnv = (!SAMPLE && v == 0.0f) ? LOG_ZERO_P : log((double)v);
     A += e.al_d;
@@ -180,13 +180,8 @@ __device__ __forceinline__ PolicyTerms<FAST> policy_terms(const PolicyElem<FAST>
     const float lnv = (!SAMPLE && v == 0.0f) ? (float)(LOG_ZERO_P * INV_LN2) : __builtin_amdgcn_logf(v);
 #endif
     o.al = e.al_f;
-#ifdef MFG_ABL_TERMS  // instruction-count ablation: no alpha' / score term arithmetic
-    o.ad = e.al_f;
-    o.gt = lnv;
-    return o;
-#endif
     o.ad = e.ad_f;
-    o.gt = fmaf(lnv, e.ad_f, -e.psi_ad);
+    o.gt = __builtin_fmaf(lnv, e.ad_f, -e.psi_ad);
   } else {
     const double lnv = (!SAMPLE && v == 0.0f) ? LOG_ZERO_P : log((double)v);
     o.al = e.al_d;
@@ -243,7 +238,8 @@ __device__ __forceinline__ void sample_elems_g(const CoreArgs& a, double theta, 
       if (u + 1 < PW) xn[u + 1] = (q.radu[hp] - 0.5f) * q.ang[hp];
 #else
       if (u < n2) {
-        const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(q.radu[hp]));
+        // radius in units of K = sqrt(2 ln 2) (GammaState, mfg_device.h): sqrt(-log2 u), the sign is a source modifier
+        const float rad = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(q.radu[hp]));
         xn[u] = rad * __builtin_amdgcn_cosf(q.ang[hp]);
         if (u + 1 < PW) xn[u + 1] = rad * __builtin_amdgcn_sinf(q.ang[hp]);
       }
@@ -320,14 +316,6 @@ __device__ __forceinline__ void sample_elems(const CoreArgs& a, double theta, co
     ds = ad[0];
     gs = gt[0];
   }
-#ifdef MFG_ABL_FOLD  // instruction-count ablation: the other elements' terms are kept alive but not added
-#pragma unroll
-  for (int e = 1; e < NE; ++e) {
-    asm volatile("" ::"v"(y[e]));
-    if (TD) asm volatile("" ::"v"(al[e]), "v"(ad[e]), "v"(gt[e]));
-  }
-  return;
-#endif
 #pragma unroll
   for (int e = 1; e < NE; ++e) {
     ys += y[e];
@@ -533,13 +521,8 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
         }
         if (SAMPLE) pis64[2 * (tlc * d + i)] = (double)pi_i;
         if (sep) {
-#ifdef MFG_ABL_EF  // instruction-count ablation: no per-step E / F exponentials
-          pex[tlc * d + i] = pi_i;
-          Fi = 0.25f;
-#else
           pex[tlc * d + i] = exp_f64arg(theta * ((double)pi_i - SEP_CENTRE));
           Fi = exp_f64arg(-theta * ((double)pi_i + (a.shift - SEP_CENTRE)));
-#endif
         }
       }
       if (!SAMPLE) {
@@ -595,35 +578,23 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
                 ejv[e] = rp[EOFF + e];
               }
               sample_elems<4, TD, FAST, sep>(a, theta, ts, pjv, ejv, pas, Fi, erow + (uint32_t)j, step, traj, y, ys, as, ds, gs);
-#ifdef MFG_ABL_TSTORE  // instruction-count ablation: no tile stores (the variates are kept alive)
-              asm volatile("" ::"v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]));
-              rp += 4;
-              asm volatile("" : "+v"(rp));
-#else
 #pragma unroll
               for (int e = 0; e < 4; ++e) wp[e] = y[e];
               rp += 4;
               wp += 4;
               asm volatile("" : "+v"(rp), "+v"(wp));
-#endif
             };
 #pragma unroll 1
             for (int j = 0; j < dq; j += 4) {
               float ys;
               TT as, ds, gs;
               quad(j, ys, as, ds, gs);
-#ifdef MFG_ABL_FOLD  // instruction-count ablation: no conversions / fp64 adds of the quad sums
-              asm volatile("" ::"v"(ys));
-              if (TD) asm volatile("" ::"v"(as), "v"(ds), "v"(gs));
-              Ssum = 1000.0, A = 3.0, D_ = 0.5;
-#else
               Ssum += (double)ys;
               if (TD) {
                 A += (double)as;
                 D_ += (double)ds;
                 gacc += (double)gs;
               }
-#endif
             }
             // (folding the quad sums in PAIRS of quads -- half the conversions and fp64 adds -- needs a two-quad loop body:
             //  twice the code, every cold continuation replicated; measured 1.08 -> 1.27 ms.  Not kept.)
@@ -1325,7 +1296,7 @@ void k_core_large(CoreArgs a) {
               tot = x[0];
             }
             float inv = __builtin_amdgcn_rcpf(tot);
-            inv = fmaf(fmaf(-tot, inv, 1.0f), inv, inv);
+            inv = __builtin_fmaf(__builtin_fmaf(-tot, inv, 1.0f), inv, inv);
             auto fold_batch = [&](auto wp) __attribute__((always_inline)) {
               float yr[KB][R], pb[KB];  // the whole batch is requested up front: one LDS round trip per batch, not per row
 #pragma unroll

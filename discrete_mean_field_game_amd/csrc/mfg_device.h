@@ -50,7 +50,7 @@ __device__ __forceinline__ u32x4 philox_elem(uint64_t seed, uint32_t elem, uint3
 }
 
 // (0,1] from the top 24 bits (the +0.5 keeps log(u) finite).
-__device__ __forceinline__ float u01(uint32_t r) { return fmaf((float)(r >> 8), 5.9604644775390625e-8f, 2.98023223876953125e-8f); }
+__device__ __forceinline__ float u01(uint32_t r) { return __builtin_fmaf((float)(r >> 8), 5.9604644775390625e-8f, 2.98023223876953125e-8f); }
 
 // Raw hardware transcendentals (v_log_f32 / v_exp_f32: base 2, ~1 ulp, no denormal fix-ups: every
 // argument below is a normal number).
@@ -62,8 +62,14 @@ __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp
 // Matrix elements are sampled in QUADS (see "Quad sampler" below): one Philox block gives two Box-Muller pairs
 // (cos / sin of the same radius) and four 12-bit acceptance integers.
 // ---------------------------------------------------------------------------
+// The quad sampler's normals are kept in units of K = sqrt(2 ln 2): Box-Muller gives x = sqrt(-2 ln u) cos(phi) =
+// K sqrt(-log2 u) cos(phi), and everything the hot path does with x is scale covariant (t = c x, the squeeze threshold in
+// (x t)^2), so the hot path works with xs = x / K and a pre-scaled c -- the multiplication by -2 ln 2 in front of the square
+// root (one instruction per Box-Muller pair) is folded into constants.  The exact continuation restores x = K xs.
+constexpr float BM_K = 1.1774100225154747f;       // sqrt(2 ln 2)
+constexpr float BM_K2 = 1.3862943611198906f;      // 2 ln 2
 struct GammaState {
-  float a, dd, c;
+  float a, dd, c;  // hot path (gamma_setup_hot): c = K / sqrt(9 d), applied to xs; gamma_setup: c = 1 / sqrt(9 d), applied to x
   bool small;
 };
 
@@ -80,16 +86,17 @@ __device__ __forceinline__ void gamma_setup_hot(GammaState& g, float a) {
   g.a = a;
   g.small = a < 1.0f;
   g.dd = a - (1.0f / 3.0f);
-  g.c = __builtin_amdgcn_rsqf(9.0f * g.dd);  // garbage for a < 1/3: such elements never use the hot-path result
+  g.c = __builtin_amdgcn_rsqf((9.0f / BM_K2) * g.dd);  // K / sqrt(9 d); garbage for a < 1/3: such elements never use the hot-path result
 }
 // The same from the concentration alpha and the scale (shape a = alpha * scale), one instruction shorter: d and 9 d are
 // one fma each of alpha, the small-shape flag is read off d (a < 1 <=> d < 2/3), and the shape itself -- which only the
 // cold small-shape continuation needs -- is d + 1/3.
-__device__ __forceinline__ void gamma_setup_hot(GammaState& g, float alpha, float scale, float scale9) {
-  g.dd = fmaf(alpha, scale, -(1.0f / 3.0f));
+//   scale9k = 9 scale / (2 ln 2): c = K / sqrt(9 d) = rsq(9 d / K^2)
+__device__ __forceinline__ void gamma_setup_hot(GammaState& g, float alpha, float scale, float scale9k) {
+  g.dd = __builtin_fmaf(alpha, scale, -(1.0f / 3.0f));
   g.small = g.dd < (2.0f / 3.0f);
   g.a = g.dd + (1.0f / 3.0f);  // dead on the hot path
-  g.c = __builtin_amdgcn_rsqf(fmaf(alpha, scale9, -3.0f));
+  g.c = __builtin_amdgcn_rsqf(__builtin_fmaf(alpha, scale9k, -3.0f / BM_K2));
 }
 
 // Marsaglia-Tsang acceptance for normal x and uniform u; v = (1 + c x)^3.
@@ -102,7 +109,7 @@ __device__ __forceinline__ bool mt_accept(const GammaState& g, float x, float u,
   if (!acc) {
     // log(v) - eps: series for small eps (large shapes), direct otherwise
     float lme;
-    if (fabsf(eps) < 0.125f) {
+    if (__builtin_fabsf(eps) < 0.125f) {
       const float e2 = eps * eps;
       lme = e2 * (-0.5f + eps * (1.0f / 3.0f + eps * (-0.25f + eps * (0.2f + eps * (-1.0f / 6.0f +
             eps * (1.0f / 7.0f + eps * (-0.125f)))))));
@@ -163,16 +170,10 @@ __device__ __forceinline__ void quad_rand(QuadRand& q, uint64_t seed, uint32_t e
 #else
   const u32x4 r = philox_elem(seed, elem0, step, traj, 0);
 #endif
-#ifdef MFG_ABL_KBITS  // instruction-count ablation (tools/cycle_table.sh): the block is kept alive, its fields are not extracted
-  asm volatile("" ::"v"(r.x), "v"(r.y), "v"(r.z), "v"(r.w));
-  q.ang[0] = 0.11f, q.ang[1] = 0.23f, q.radu[0] = 0.37f, q.radu[1] = 0.41f;
-  q.kf[0] = q.kf[1] = q.kf[2] = q.kf[3] = 1.0f;
-  return;
-#endif
-  q.ang[0] = fmaf((float)(r.z >> 16), 1.52587890625e-5f, 7.62939453125e-6f);
-  q.ang[1] = fmaf((float)(r.z & 0xFFFFu), 1.52587890625e-5f, 7.62939453125e-6f);
-  q.radu[0] = fmaf((float)(r.x >> 12), 9.5367431640625e-7f, 4.76837158203125e-7f);   // (k + 1/2) 2^-20
-  q.radu[1] = fmaf((float)(r.y >> 12), 9.5367431640625e-7f, 4.76837158203125e-7f);
+  q.ang[0] = __builtin_fmaf((float)(r.z >> 16), 1.52587890625e-5f, 7.62939453125e-6f);
+  q.ang[1] = __builtin_fmaf((float)(r.z & 0xFFFFu), 1.52587890625e-5f, 7.62939453125e-6f);
+  q.radu[0] = __builtin_fmaf((float)(r.x >> 12), 9.5367431640625e-7f, 4.76837158203125e-7f);   // (k + 1/2) 2^-20
+  q.radu[1] = __builtin_fmaf((float)(r.y >> 12), 9.5367431640625e-7f, 4.76837158203125e-7f);
   q.kf[0] = (float)(r.w >> 16);
   q.kf[1] = (float)(r.w & 0xFFFFu);
   q.kf[2] = (float)(r.x & 0xFFFu);
@@ -203,12 +204,14 @@ __device__ __forceinline__ float gamma_exact_path(const GammaState& g, float x, 
 //   stay below 5.89 (24-bit uniforms; 5.4 with the 20-bit uniforms of the v2 layout), so the last term is < 2^KB 3.5e-5: a
 //   constant keeps the bound (conservatively) and the test needs (x t)^2 only -- two instructions fewer than forming t^2,
 //   x^2 and the inner fma.   KB = 12: kf <= 4094.85 - 778.24 (x t)^2;   KB = 16: kf <= 65532.7 - 12451.84 (x t)^2.
+//   The hot path holds xs = x / K (GammaState): (x t)^2 = 2 ln 2 (xs t)^2, folded into the slope (rounded away from zero).
 template <int KB>
 struct TryConst {
-  static constexpr float slope = KB == 16 ? -12451.84f : -778.24f;
+  static constexpr float slope = KB == 16 ? -12451.84f * 1.3862944f : -778.24f * 1.3862944f;
   static constexpr float top = KB == 16 ? 65532.7f : 4094.85f;
   static constexpr float kscale = KB == 16 ? 1.52587890625e-5f : 2.44140625e-4f;
 };
+//   x = the normal in units of K (xs), g from gamma_setup_hot
 template <int KB = 12>
 __device__ __forceinline__ float gamma_try(const GammaState& g, float x, float kf, bool& sure) {
 #ifdef MFG_ABL_TRY
@@ -217,8 +220,8 @@ __device__ __forceinline__ float gamma_try(const GammaState& g, float x, float k
 #endif
   const float t = g.c * x;
   const float q = x * t;
-  const float thr = fmaf(q * q, TryConst<KB>::slope, TryConst<KB>::top);
-  sure = (fabsf(t) <= 0.5f) && (kf <= thr);
+  const float thr = __builtin_fmaf(q * q, TryConst<KB>::slope, TryConst<KB>::top);
+  sure = (__builtin_fabsf(t) <= 0.5f) && (kf <= thr);
   return 1.0f + t * (3.0f + t * (3.0f + t));
 }
 // The same, with the "not decided / small shape" condition returned as a WAVE MASK (bit = lane) straight from the compare
@@ -233,15 +236,17 @@ __device__ __forceinline__ float gamma_try_mask(const GammaState& g, float x, fl
 #endif
   const float t = g.c * x;
   const float q = x * t;
-  const float thr = fmaf(q * q, TryConst<KB>::slope, TryConst<KB>::top);
+  const float thr = __builtin_fmaf(q * q, TryConst<KB>::slope, TryConst<KB>::top);
   constexpr int FCMP_OLT = 4, FCMP_UGT = 10;
-  cold = __builtin_amdgcn_fcmpf(fabsf(t), 0.5f, FCMP_UGT) | __builtin_amdgcn_fcmpf(kf, thr, FCMP_UGT) |
+  cold = __builtin_amdgcn_fcmpf(__builtin_fabsf(t), 0.5f, FCMP_UGT) | __builtin_amdgcn_fcmpf(kf, thr, FCMP_UGT) |
          __builtin_amdgcn_fcmpf(g.dd, 2.0f / 3.0f, FCMP_OLT);
   return 1.0f + t * (3.0f + t * (3.0f + t));
 }
-// Cold half: exact continuation and the shape < 1 boost; returns the variate.
-__device__ __forceinline__ float gamma_fix(const GammaState& g, float x, float kf, float kscale, bool sure, float v,
+// Cold half: exact continuation and the shape < 1 boost; returns the variate.  xs = the hot path's normal (units of K), g from
+// gamma_setup_hot: the true normal and the true c are restored here.
+__device__ __forceinline__ float gamma_fix(const GammaState& g, float xs, float kf, float kscale, bool sure, float v,
                                            uint64_t seed, uint32_t elem, uint32_t step, uint64_t traj) {
+  const float x = BM_K * xs;
   if (g.small) {
     // shape < 1: Gamma(a) = Gamma(a + 1) U^(1/a); the boosted draw runs the exact test from the start
     GammaState gb;
@@ -252,7 +257,11 @@ __device__ __forceinline__ float gamma_fix(const GammaState& g, float x, float k
     if (y == 0.0f) y = ZERO_GAMMA_REPLACEMENT;  // underflow of the boost (mfg_ac2.py:244)
     return y;
   }
-  if (!sure) v = gamma_exact_path(g, x, kf, kscale, seed, elem, step, traj);
+  if (!sure) {
+    GammaState gt = g;
+    gt.c = g.c * (1.0f / BM_K);
+    v = gamma_exact_path(gt, x, kf, kscale, seed, elem, step, traj);
+  }
   return g.dd * v;
 }
 
@@ -298,11 +307,11 @@ __device__ __forceinline__ void softplus_sigmoid(double z, double& sp, double& s
 // relative error instead of |z| * 2^-24).  log1p as in softplus_sigmoid_e.
 __device__ __forceinline__ void softplus_sigmoid_fast(float zh, float zl, float& sp, float& sg) {
   float e = fast_exp(zh);
-  e = fmaf(e, zl, e);
+  e = __builtin_fmaf(e, zl, e);
   const float u = 1.0f + e;
   const float r = __builtin_amdgcn_rcpf(u);
   sg = e * r;
-  sp = fmaf(e - (u - 1.0f), r, fast_ln(u));  // log1p through the rounded sum + rounding-error correction (softplus_sigmoid_e)
+  sp = __builtin_fmaf(e - (u - 1.0f), r, fast_ln(u));  // log1p through the rounded sum + rounding-error correction (softplus_sigmoid_e)
 }
 
 // Round 2: the exponential is SEPARABLE, e^{theta (pi_j - pi_i - shift)} = E_j F_i with E_j = e^{theta (pi_j - 1/2)},
@@ -324,18 +333,18 @@ __device__ __forceinline__ float exp_f64arg(double z) {
   const float zh = (float)zl2;
   const float zt = (float)(zl2 - (double)zh);
   const float e = __builtin_amdgcn_exp2f(zh);
-  return fmaf(e, zt * 0.69314718055994531f, e);
+  return __builtin_fmaf(e, zt * 0.69314718055994531f, e);
 }
 
 // log1p(e) for 0 <= e <= 1/4: e * (degree-6 minimax polynomial of log1p(e)/e), 9.3e-8 relative in fp32 arithmetic
 // (replaces the atanh series and its reciprocal).
 __device__ __forceinline__ float log1p_small(float e) {
-  float p = fmaf(e, 0.0707516148686409f, -0.145447239279747f);
-  p = fmaf(e, p, 0.19665537774562836f);
-  p = fmaf(e, p, -0.24972063302993774f);
-  p = fmaf(e, p, 0.33332204818725586f);
-  p = fmaf(e, p, -0.4999998211860657f);
-  p = fmaf(e, p, 1.0f);
+  float p = __builtin_fmaf(e, 0.0707516148686409f, -0.145447239279747f);
+  p = __builtin_fmaf(e, p, 0.19665537774562836f);
+  p = __builtin_fmaf(e, p, -0.24972063302993774f);
+  p = __builtin_fmaf(e, p, 0.33332204818725586f);
+  p = __builtin_fmaf(e, p, -0.4999998211860657f);
+  p = __builtin_fmaf(e, p, 1.0f);
   return e * p;
 }
 
@@ -361,7 +370,7 @@ __device__ __forceinline__ void softplus_sigmoid_e(float e, float& sp, float& sg
   const float u = 1.0f + e;
   const float r = __builtin_amdgcn_rcpf(u);
   sg = e * r;
-  sp = fmaf(e - (u - 1.0f), r, fast_ln(u));
+  sp = __builtin_fmaf(e - (u - 1.0f), r, fast_ln(u));
 #endif
 }
 
@@ -408,7 +417,7 @@ __device__ __forceinline__ double digamma_pos_mixed(double x) {
 __device__ __forceinline__ float fast_rcp_f32_of_f64(double x) {
   const float xf = (float)x;
   float r = __builtin_amdgcn_rcpf(xf);
-  r = fmaf(fmaf(-xf, r, 1.0f), r, r);
+  r = __builtin_fmaf(__builtin_fmaf(-xf, r, 1.0f), r, r);
   return r;
 }
 
@@ -430,7 +439,7 @@ __device__ __forceinline__ ThetaSplit theta_split(double theta, double shift) {
 __device__ __forceinline__ void theta_times_x(const ThetaSplit& t, float pj, float pi, float& x, float& zh, float& zl) {
   x = (pj - pi) - t.sh;
   zh = t.th * x;
-  zl = fmaf(t.th, x, -zh) + fmaf(t.tl, x, -t.c0);
+  zl = __builtin_fmaf(t.th, x, -zh) + __builtin_fmaf(t.tl, x, -t.c0);
 }
 
 // ---------------------------------------------------------------------------
@@ -455,12 +464,12 @@ __device__ __forceinline__ float htab_eval(const float4* __restrict__ tab, float
   return x * thn * 0.1f;
 #endif
   static_assert(HTAB_PER_UNIT == 16, "ThetaSplit::thn assumes 16 intervals per unit of z");
-  float t = fmaf(x, thn, -HTAB_ZMIN * (float)HTAB_PER_UNIT);
+  float t = __builtin_fmaf(x, thn, -HTAB_ZMIN * (float)HTAB_PER_UNIT);
   t = __builtin_amdgcn_fmed3f(t, 0.0f, (float)HTAB_N - 0.001f);  // clamp: one instruction
   const unsigned k = (unsigned)t;                                 // truncation == floor (t >= 0)
   const float f = __builtin_amdgcn_fractf(t);
   const float4 c = tab[k];
-  return fmaf(fmaf(fmaf(c.w, f, c.z), f, c.y), f, c.x);
+  return __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(c.w, f, c.z), f, c.y), f, c.x);
 }
 
 // ---------------------------------------------------------------------------

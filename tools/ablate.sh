@@ -3,7 +3,7 @@
 # Build (no GPU needed):   bash tools/ablate.sh build
 # Run on the GPU box:      bash tools/ablate.sh run [d,B,T]
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/discrete_mean_field_game_amd/csrc; V=$C/variants
-ABL="PHILOX BM SETUP TRY HTAB LNY EPI COLREW V COLT TSUM KBITS TERMS FOLD TSTORE EF"
+ABL="PHILOX BM SETUP TRY HTAB LNY EPI COLREW V COLT TSUM"
 if [ "$1" = build ]; then
   mkdir -p $V
   for a in $ABL; do

@@ -28,7 +28,7 @@ PY
 )
 export CT_DUR0=$DUR0
 ABL=""
-for a in PHILOX KBITS BM SETUP TRY HTAB LNY TERMS FOLD TSTORE EF EPI COLT TSUM V; do
+for a in PHILOX BM SETUP TRY HTAB LNY EPI COLT TSUM V; do
   if [ -f $V/libabl_$a.so ]; then run /tmp/cta_$a "$P1" $V/libabl_$a.so; ABL="$ABL $a"; fi
 done
 python3 - "$SH" $ABL <<'PY'
@@ -93,8 +93,9 @@ if abl:
         dc = (act - 4.0 * c.get('SQ_ACTIVE_INST_VALU', 0.0) * W / max(c.get('SQ_WAVES', W), 1)) / W / elems
         ti += di; tc += dc
         print('%-10s %14.2f %14.1f %10.2f %11.1f%%' % (a, di, dc, dc / di if di else 0.0, 100 * di * W * elems / max(tot_i, 1)))
-    print('(KBITS = field extraction + conversion of the quad block; TERMS = alpha prime and score term of an element; FOLD = quad sums +'
-          ' fp64 folds; TSTORE = tile stores / running pointers; EF = per-step E_j, F_i exponentials; the loop control is scalar)')
+    print('(the rest = what no stand-in can replace without changing the trajectories: field extraction of the Philox block, score terms,'
+          ' quad sums, fp64 folds, pointers -- split statically, piece by piece, in profiles/rNN_loop_table_d21.txt (tools/loop_table.py) --'
+          ' plus per-step E / F staging, state loads / stores, trajectory outputs)')
     print('%-10s %14.2f %14.1f %10.2f %11.1f%%' % ('the rest', tot_i / W / elems - ti, act / W / elems - tc,
                                                  (act / W / elems - tc) / max(tot_i / W / elems - ti, 1e-9), 100 * (1 - ti * W * elems / max(tot_i, 1))))
 PY
