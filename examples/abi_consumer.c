@@ -2,7 +2,8 @@
  * Plain-C consumer of the C ABI (include/mfg_hip.h): no Python, no torch, no C++.
  * One forward-RL update at the reference's problem size, the way a host program written in any language with a C
  * FFI would drive the library: allocate device buffers with the HIP runtime, zero the workspace once, enqueue
- * mfg_gather_start -> mfg_rollout (fused TD rollout + batch gradients) -> mfg_apply_update on a stream, read
+ * mfg_gather_start -> mfg_rollout (fused TD rollout + batch gradients) -> mfg_apply_update on a stream, then the
+ * native episode loop mfg_train_rollouts (device-side start draws, schedule in C); read
  * theta and the mean reward back.  tests/test_c_consumer.py compares the printed numbers with the Python binding.
  *
  *   gcc -std=c99 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/abi_consumer.c \
@@ -101,8 +102,24 @@ int main(int argc, char** argv) {
   HIP_OK(hipMemcpy(&count, G + F + 2, sizeof(double), hipMemcpyDeviceToHost));
   double wsum = 0.0;
   for (int64_t k = 0; k < F; ++k) wsum += w_h[k];
+
+  /* The episode loop itself (mfg_ac2.py:460-526) as ONE native call: three more episodes, start states drawn on the
+   * device (mfg_draw_start semantics: Philox keyed by seed / the episode's first step / trajectory id), learning rates
+   * lr / (e + 1), lr / ((e + 1) ln ln (e + 20)) for e = 2, 3, 4, one return accumulator per episode. */
+  double* racc3;
+  HIP_OK(hipMalloc((void**)&racc3, 3 * sizeof(double)));
+  HIP_OK(hipMemset(racc3, 0, 3 * sizeof(double)));
+  MFG_OK_(mfg_train_rollouts(mat, num_start, B, d, T, /*episodes*/ 3, /*first_episode*/ 2, /*constant*/ 0, theta, 0.16, 12000.0, w,
+                             1.0, MFG_REWARD_MFG_AC2, /*seed*/ 42u, /*first_step*/ (uint32_t)(2 * T), /*traj_offset*/ 0u,
+                             /*flags*/ 0, 0.1, 0.001, pi_traj, pi_last, reward, delta, g, G, racc3, ws, ws_bytes, st));
+  HIP_OK(hipStreamSynchronize(st));
+  double theta2 = 0.0, racc3_h[3];
+  HIP_OK(hipMemcpy(&theta2, theta, sizeof(double), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(racc3_h, racc3, 3 * sizeof(double), hipMemcpyDeviceToHost));
+
   printf("{\"abi\": %d, \"arch\": \"%s\", \"cus\": %d, \"B\": %lld, \"theta\": %.17g, \"w_sum\": %.17g, "
-         "\"mean_reward_acc\": %.17g, \"count\": %.0f}\n",
-         mfg_abi_version(), arch, cus, (long long)B, theta_h, wsum, racc_h, count);
+         "\"mean_reward_acc\": %.17g, \"count\": %.0f, \"theta_after_native_loop\": %.17g, "
+         "\"native_loop_rewards\": [%.17g, %.17g, %.17g]}\n",
+         mfg_abi_version(), arch, cus, (long long)B, theta_h, wsum, racc_h, count, theta2, racc3_h[0], racc3_h[1], racc3_h[2]);
   return 0;
 }

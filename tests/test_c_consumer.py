@@ -53,3 +53,17 @@ def test_c_consumer_matches_python_binding():
     assert got['theta'] == float(theta[0])
     assert got['mean_reward_acc'] == float(racc[0])
     assert abs(got['w_sum'] - float(w.sum())) <= 1e-12 * abs(float(w.sum()))
+    # ... and the three further episodes the C program ran through the native episode loop (mfg_train_rollouts: start
+    # states drawn on the device, learning-rate schedule evaluated in C) against the per-episode Python sequence
+    from discrete_mean_field_game_amd.parallel import lr_scales
+    matd = torch.as_tensor(mat, device=dev)
+    bufs = {'pi_traj': torch.empty(B, T + 1, d, device=dev), 'pi_last': torch.empty(B, d, device=dev),
+            'reward': torch.empty(B, T, device=dev), 'delta': torch.empty(B, T, dtype=torch.float64, device=dev),
+            'g': torch.empty(B, T, dtype=torch.float64, device=dev)}
+    racc3 = torch.zeros(3, dtype=torch.float64, device=dev)
+    for k in range(3):
+        sc, sa = lr_scales(2 + k, False)
+        ops.train_rollout(matd, None, T, theta, 0.16, 12000.0, w, 1.0, G, ws, bufs, 0.1 * sc, 0.001 * sa, apply=True, seed=42,
+                          first_step=(2 + k) * T, reward_acc=racc3[k:k + 1])
+    assert got['theta_after_native_loop'] == float(theta[0])
+    assert got['native_loop_rewards'] == [float(v) for v in racc3.cpu()]
