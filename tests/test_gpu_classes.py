@@ -1003,6 +1003,67 @@ def test_deferred_update_chain_equals_update_launches(dev, d, B, T):
     assert float(outs[0][0][-1][0]) != 8.86349
 
 
+def test_native_loops_edge_cases_and_error_paths(dev):
+    """mfg_train_rollouts / mfg_train_episodes / mfg_draw_start / mfg_train_rollout_deferred: zero episodes and an empty batch
+    are no-ops, even and odd episode lengths leave the final states where the per-episode calls leave them, bad arguments
+    are refused with an error code before anything is launched."""
+    from discrete_mean_field_game_amd import ops, _lib as L
+    lib = L.lib()
+    d, B = 21, 50
+    rs = np.random.RandomState(4)
+    mat = torch.as_tensor(rs.dirichlet(np.ones(d), size=5).astype(np.float32), device=dev)
+    F = ops.num_features(d)
+
+    def fresh(T):
+        return dict(theta=torch.tensor([8.86349], dtype=torch.float64, device=dev), w=torch.as_tensor(rs.rand(F) * 0 + 0.3, device=dev),
+                    G=torch.zeros(F + 3, dtype=torch.float64, device=dev), ws=ops.workspace(B * T, d, dev),
+                    bufs={'pi_traj': torch.empty(B, T + 1, d, device=dev), 'pi_last': torch.empty(B, d, device=dev),
+                          'reward': torch.empty(B, T, device=dev), 'delta': torch.empty(B, T, dtype=torch.float64, device=dev),
+                          'g': torch.empty(B, T, dtype=torch.float64, device=dev)})
+    # zero episodes: nothing moves
+    z = fresh(15)
+    ops.train_rollouts(mat, 15, 0, 0, False, z['theta'], 0.16, 12000.0, z['w'], 1.0, z['G'], z['ws'], z['bufs'], 0.1, 0.001, seed=1)
+    torch.cuda.synchronize()
+    assert float(z['theta'][0]) == 8.86349 and float(z['G'].abs().sum()) == 0.0
+    # step-mode episodes of even and odd length: final states = those of per-episode mfg_train_episode calls
+    for T in (1, 2, 5, 6):
+        a, b2 = fresh(T), fresh(T)
+        eb = ops.episode_buffers(B, d, dev)
+        pi_a = torch.empty(B, d, device=dev)
+        ops.train_episodes(mat, pi_a, T, 3, 1, False, a['theta'], 0.16, 12000.0, a['w'], 0.9, 0.1, 0.001, a['G'], a['ws'], eb, seed=7,
+                           first_step=40)
+        from discrete_mean_field_game_amd.parallel import lr_scales
+        pi_b = None
+        for k in range(3):
+            _, pi_b = ops.draw_start(mat, B, 7, 40 + k * T)
+            sc, sa = lr_scales(1 + k, False)
+            ops.train_episode(pi_b, T, b2['theta'], 0.16, 12000.0, b2['w'], 0.9, 0.1 * sc, 0.001 * sa, b2['G'], b2['ws'],
+                              ops.episode_buffers(B, d, dev), seed=7, first_step=40 + k * T)
+        torch.cuda.synchronize()
+        assert torch.equal(a['theta'], b2['theta']) and torch.equal(a['w'], b2['w']) and torch.equal(pi_a, pi_b), T
+    # error paths: empty / oversized table, nothing to write, aliasing parameter sets of the deferred update, wrapped step counter
+    idx = torch.zeros(B, dtype=torch.int32, device=dev)
+    st = None
+    assert lib.mfg_draw_start(mat.data_ptr(), 0, B, d, 1, 0, 0, idx.data_ptr(), None, st) == -1
+    assert lib.mfg_draw_start(mat.data_ptr(), 1 << 31, B, d, 1, 0, 0, idx.data_ptr(), None, st) == -1
+    assert lib.mfg_draw_start(mat.data_ptr(), 5, B, d, 1, 0, 0, None, None, st) == -1
+    assert lib.mfg_draw_start(None, 5, B, d, 1, 0, 0, None, z['bufs']['pi_last'].data_ptr(), st) == -1
+    assert lib.mfg_draw_start(mat.data_ptr(), 5, 0, d, 1, 0, 0, idx.data_ptr(), None, st) == 0          # B = 0: no-op
+    zb = z['bufs']
+    args = [mat.data_ptr(), 5, None, B, d, 15, z['theta'].data_ptr(), z['w'].data_ptr(), z['G'].data_ptr(), 0.1, 0.001, None,
+            z['theta'].data_ptr(), z['w'].data_ptr(),                                                       # outputs alias the inputs
+            0.16, 12000.0, 1.0, 0, 1, 0, 0, 0, zb['pi_traj'].data_ptr(), zb['pi_last'].data_ptr(), zb['reward'].data_ptr(),
+            zb['delta'].data_ptr(), zb['g'].data_ptr(), z['G'].data_ptr(), z['ws'].data_ptr(), z['ws'].numel() * 8, st]
+    assert lib.mfg_train_rollout_deferred(*args) == -1 and b'separate output' in lib.mfg_last_error()
+    rc = lib.mfg_train_rollouts(mat.data_ptr(), 5, B, d, 15, 10, 0, 0, z['theta'].data_ptr(), 0.16, 12000.0, z['w'].data_ptr(), 1.0, 0, 1,
+                                0xFFFFFFF0, 0, 0, 0.1, 0.001, zb['pi_traj'].data_ptr(), zb['pi_last'].data_ptr(),
+                                zb['reward'].data_ptr(), zb['delta'].data_ptr(), zb['g'].data_ptr(), z['G'].data_ptr(), None,
+                                z['ws'].data_ptr(), z['ws'].numel() * 8, st)
+    assert rc == -1 and b'wrap' in lib.mfg_last_error()
+    torch.cuda.synchronize()
+    assert float(z['theta'][0]) == 8.86349                                                                 # nothing was launched
+
+
 def test_batched_philox_training_uses_no_host_rng(dev):
     """Batched runs draw their start states on the device: train() neither consumes nor depends on np.random (the
     reference's `np.random.randint` at mfg_ac2.py:466 is kept for batch 1 and rng='numpy' only), and the states an episode
