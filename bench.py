@@ -341,10 +341,24 @@ def main():
         sync()
         t_upd = event_time(lambda: exchange(True), n=50, warm=10) - t_fill
         sync()
+        t_nat = None
+        if args.backend == 'nccl':
+            # the same exchange as the product issues it inside train(): ncclAllReduce from the HIP library's own communicator
+            from discrete_mean_field_game_amd import parallel
+            comm = parallel.native_comm(None, dev, allow_single=True)
+            if comm:
+                stream = torch.cuda.current_stream().cuda_stream
+                t_nat = event_time(lambda: _lib.check(_lib.lib().mfg_dist_all_reduce(comm, Gc.data_ptr(), Fc + 3, stream), 'all_reduce'),
+                                   n=50, warm=10)
+                sync()
         collective = {'backend': ('rccl (torch.distributed nccl)' if args.backend == 'nccl'
                                   else 'gloo, staged through the host: wall time of a debug path, not a device collective'),
                       'world': world, 'payload_bytes': (Fc + 3) * 8, 'all_reduce_us': t_ar * 1e6,
-                      'all_reduce_plus_apply_update_us': t_upd * 1e6}
+                      'all_reduce_plus_apply_update_us': t_upd * 1e6,
+                      'native_all_reduce_us': (t_nat * 1e6 if t_nat is not None else None),
+                      'note': 'the timed training legs exchange G through the HIP library\'s own RCCL communicator '
+                              '(mfg_train_rollouts_dist: native episode loop, update applied inside the next rollout) when the '
+                              'backend is nccl; all_reduce_us is the same buffer through torch.distributed for comparison'}
 
     out = None
     if rank == 0:

@@ -15,6 +15,8 @@
 #include <string.h>
 #include <stdlib.h>
 
+#include <dlfcn.h>
+
 #include <atomic>
 #include <mutex>
 
@@ -2480,7 +2482,7 @@ static int reduce_core_sums(int d, int64_t B, double* G, int accumulate, void* w
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 13; }
+int mfg_abi_version(void) { return 14; }
 
 int mfg_init(void) {
   if (!htab_ptr()) return fail(MFG_ELAUNCH, "%s", "mfg_init: no HIP device / table initialisation failed");
@@ -3140,6 +3142,131 @@ int mfg_train_rollout_deferred(const float* mat_pi0, int64_t num_start, const in
   return train_rollout_impl(mat_pi0, num_start, idx, B, d, T, const_cast<double*>(theta), shift, alpha_scale, const_cast<double*>(w),
                             gamma, reward_kind, seed, first_step, traj_offset, flags, 0.0, 0.0, pi_traj, pi_last, reward, delta, g,
                             G, nullptr, workspace, workspace_bytes, S(stream), G_pending ? &du : nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU episode loop, native: RCCL called from this library (one all-reduce of G per update).
+// The RCCL entry points are resolved at run time from the librccl.so the process already holds (PyTorch's, so that one RCCL
+// instance serves the job); the library has no link-time dependency on it and reports MFG_EUNSUPPORTED where it is absent.
+// ---------------------------------------------------------------------------------------------
+}  // extern "C" (the helpers below have C++ linkage)
+namespace {
+struct RcclApi {
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, mfg_rccl_id_t, int) = nullptr;   // ncclUniqueId is passed BY VALUE (128 bytes)
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+const RcclApi& rccl() {
+  static RcclApi api = [] {
+    RcclApi a;
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);          // already in the process (torch)?
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);        // a stand-alone host program: load the system's
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return a;
+    a.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<int (*)(void**, int, mfg_rccl_id_t, int)>(dlsym(h, "ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
+    a.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclAllReduce"));
+    a.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(h, "ncclGetErrorString"));
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce;
+    return a;
+  }();
+  return api;
+}
+int rccl_fail(const char* what, int rc) {
+  const RcclApi& r = rccl();
+  return fail(MFG_ELAUNCH, "%s: RCCL error %d (%s)", what, rc, r.GetErrorString ? r.GetErrorString(rc) : "?");
+}
+constexpr int RCCL_SUM = 0, RCCL_FLOAT64 = 8;  // ncclSum, ncclFloat64 (rccl.h)
+}  // namespace
+extern "C" {
+
+int mfg_dist_unique_id(mfg_rccl_id_t* id_host) {
+  REQUIRE(id_host, "null pointer");
+  const RcclApi& r = rccl();
+  if (!r.ok) return fail(MFG_EUNSUPPORTED, "%s", "librccl.so is not available in this process");
+  const int rc = r.GetUniqueId(id_host);
+  return rc == 0 ? MFG_OK : rccl_fail("ncclGetUniqueId", rc);
+}
+
+int mfg_dist_init(const mfg_rccl_id_t* id_host, int nranks, int rank, void** comm_out) {
+  REQUIRE(id_host && comm_out && nranks >= 1 && rank >= 0 && rank < nranks, "bad arguments");
+  const RcclApi& r = rccl();
+  if (!r.ok) return fail(MFG_EUNSUPPORTED, "%s", "librccl.so is not available in this process");
+  void* comm = nullptr;
+  const int rc = r.CommInitRank(&comm, nranks, *id_host, rank);   // collective: every rank of the job calls it (current device)
+  if (rc != 0) return rccl_fail("ncclCommInitRank", rc);
+  *comm_out = comm;
+  return MFG_OK;
+}
+
+int mfg_dist_destroy(void* comm) {
+  if (!comm) return MFG_OK;
+  const RcclApi& r = rccl();
+  if (!r.ok) return fail(MFG_EUNSUPPORTED, "%s", "librccl.so is not available in this process");
+  const int rc = r.CommDestroy(comm);
+  return rc == 0 ? MFG_OK : rccl_fail("ncclCommDestroy", rc);
+}
+
+int mfg_dist_all_reduce(void* comm, double* G, int64_t n, mfg_stream_t stream) {
+  REQUIRE(comm && G && n >= 1, "bad arguments");
+  const RcclApi& r = rccl();
+  if (!r.ok) return fail(MFG_EUNSUPPORTED, "%s", "librccl.so is not available in this process");
+  const int rc = r.AllReduce(G, G, (size_t)n, RCCL_FLOAT64, RCCL_SUM, comm, S(stream));
+  return rc == 0 ? MFG_OK : rccl_fail("ncclAllReduce", rc);
+}
+
+int mfg_train_rollouts_dist(void* comm, const float* mat_pi0, int64_t num_start, int64_t B, int d, int T, int64_t episodes,
+                            int64_t first_episode, int constant, double* theta, double* w, double* theta_alt, double* w_alt,
+                            double shift, double alpha_scale, double gamma, int reward_kind, uint64_t seed, uint32_t first_step,
+                            uint64_t traj_offset, int flags, double lr_critic, double lr_actor, float* pi_traj, float* pi_last,
+                            float* reward, double* delta, double* g, double* G, double* reward_acc, void* workspace,
+                            size_t workspace_bytes, mfg_stream_t stream) {
+  CHECK_TRAIN_ROLLOUT();
+  REQUIRE(comm && theta_alt && w_alt && theta_alt != theta && w_alt != w, "needs a communicator and a second parameter set");
+  REQUIRE(episodes >= 0 && first_episode >= 0, "bad episode range");
+  REQUIRE(!(flags & MFG_TRAIN_APPLY), "MFG_TRAIN_APPLY makes no sense here");
+  REQUIRE((uint64_t)first_step + (uint64_t)episodes * (uint64_t)T <= 0xFFFFFFFFull, "Philox step counter would wrap");
+  const RcclApi& r = rccl();
+  if (!r.ok) return fail(MFG_EUNSUPPORTED, "%s", "librccl.so is not available in this process");
+  if (episodes == 0) return MFG_OK;
+  const int64_t F = mfg_num_features(d);
+  hipStream_t st = S(stream);
+  double *tc = theta, *wc = w, *tn = theta_alt, *wn = w_alt;   // current / next parameter set
+  double plc = 0.0, pla = 0.0;
+  double* pacc = nullptr;
+  bool pending = false;
+  for (int64_t k = 0; k < episodes; ++k) {
+    const DeferredUpdate du{G, plc, pla, pacc, tn, wn};
+    int rc = train_rollout_impl(mat_pi0, num_start, nullptr, B, d, T, tc, shift, alpha_scale, wc, gamma, reward_kind, seed,
+                                first_step + (uint32_t)(k * T), traj_offset, flags, 0.0, 0.0, pi_traj, pi_last, reward, delta, g, G,
+                                nullptr, workspace, workspace_bytes, st, pending ? &du : nullptr);
+    if (rc != MFG_OK) return rc;
+    if (pending) {  // the rollout left the updated parameters in the other set
+      double* t = tc; tc = tn; tn = t;
+      t = wc; wc = wn; wn = t;
+    }
+    rc = r.AllReduce(G, G, (size_t)(F + 3), RCCL_FLOAT64, RCCL_SUM, comm, st);   // the ONE exchange of the update
+    if (rc != 0) return rccl_fail("ncclAllReduce", rc);
+    double sc, sa;
+    lr_schedule(first_episode + k, constant, &sc, &sa);
+    plc = lr_critic * sc;
+    pla = lr_actor * sa;
+    pacc = reward_acc ? reward_acc + k : nullptr;
+    pending = true;
+  }
+  // the last update, and the parameters back in the caller's primary set
+  hipLaunchKernelGGL(k_apply_update, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, G, F, plc, pla, wc, tc, pacc);
+  if (tc != theta) {
+    if (hipMemcpyAsync(theta, tc, sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(w, wc, (size_t)F * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return fail(MFG_ELAUNCH, "%s", "train_rollouts_dist: parameter copy failed");
+  }
+  return check_launch("train_rollouts_dist");
 }
 
 int mfg_grad_accumulate(const float* pi, int64_t stride_b, double* delta, const double* g, const float* reward, int64_t B,

@@ -34,7 +34,7 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .parallel import all_reduce_gradients_, broadcast_start_indices, current_shard, lr_scales
+from .parallel import all_reduce_gradients_, broadcast_start_indices, current_shard, lr_scales, native_comm
 
 EPISODE_STEPS = 15  # mfg_ac2.py:478
 
@@ -82,6 +82,9 @@ class actor_critic:
         self._force_collective = False   # debug (bench.py --force-dist): take the multi-rank update path with one rank
         self._pending = None             # multi-rank rollout mode: (G, lr_critic, lr_actor, reward_acc) of an update not applied yet
         self._w_alt = self._theta_alt = None
+        # several GPUs over RCCL: a communicator owned by the HIP library, so that train() issues the one all-reduce per update
+        # natively.  Created HERE (a one-time collective hand-shake of the ranks), not inside train().
+        self._dist_comm = native_comm(group, torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device()))
         self._theta = torch.zeros(1, dtype=torch.float64, device=self.device)
         self._theta_is_array = False
         self.theta = theta
@@ -420,22 +423,38 @@ class actor_critic:
         multi = shard.world > 1 or self._force_collective
         native_loop = (device_draw and not multi and (fused_rollout or native_episode) and self.trace is None
                        and not write_all and not self.check_finite)
+        # several GPUs, one update per episode: the same native loop with the all-reduce issued by the library (RCCL)
+        dist_comm = None
+        if multi and fused_rollout and device_draw and self.trace is None and not write_all and not self.check_finite:
+            dist_comm = self._dist_comm
+            if dist_comm is None and self._force_collective:      # debug (one rank): made on first use
+                dist_comm = native_comm(self.group, self.device, allow_single=True)
+            if dist_comm is not None and (self._w_alt is None or self._w_alt.shape != self._w.shape):
+                self._w_alt, self._theta_alt = torch.empty_like(self._w), torch.empty_like(self._theta)
         if native_episode and device_draw:
             if 'pi_ep' not in bufs:
                 bufs['pi_ep'] = torch.empty(Bl, d, dtype=torch.float32, device=self.device)
             pi_ep = bufs['pi_ep']
         # reports (every `consecutive` episodes): in the native loop their values are read back behind the NEXT chunk of
         # episodes; a subclass hook that reads the live parameters (mfg_synthetic logs w) keeps the immediate form
-        defer_reports = native_loop and type(self)._train_log_extra is actor_critic._train_log_extra
+        defer_reports = (native_loop or dist_comm is not None) and type(self)._train_log_extra is actor_critic._train_log_extra
         report = None
         episode = 0
         while episode < num_episodes:
-            if native_loop:
+            if native_loop or dist_comm is not None:
                 # episodes episode .. last, `last` = the next reporting episode (episode % consecutive == 0) or the final one
                 last = episode if episode % consecutive == 0 else (episode // consecutive + 1) * consecutive
                 last = min(last, num_episodes - 1)
                 k = last - episode + 1
-                if fused_rollout:
+                if dist_comm is not None:
+                    self._flush_pending()
+                    ops.train_rollouts_dist(dist_comm, self._mat_pi0_dev, T, k, episode + first_episode, constant == 1, self._theta,
+                                            self._w, self._theta_alt, self._w_alt, self.shift, self.alpha_scale, gamma, G, ws, rbufs,
+                                            lr_critic, lr_actor, reward_kind=self.reward_kind, seed=self.seed,
+                                            first_step=self._rng_step, traj_offset=shard.traj_offset,
+                                            reward_acc=ep_base + 8 * episode, precision=self.precision)
+                    pi = rbufs['pi_last']
+                elif fused_rollout:
                     ops.train_rollouts(self._mat_pi0_dev, T, k, episode + first_episode, constant == 1, self._theta, self.shift,
                                        self.alpha_scale, self._w, gamma, G, ws, rbufs, lr_critic, lr_actor,
                                        reward_kind=self.reward_kind, seed=self.seed, first_step=self._rng_step,

@@ -307,6 +307,29 @@ def train_rollouts(mat_pi0, T, episodes, first_episode, constant, theta, shift, 
     return bufs
 
 
+def train_rollouts_dist(comm, mat_pi0, T, episodes, first_episode, constant, theta, w, theta_alt, w_alt, shift, alpha_scale, gamma, G,
+                        ws, bufs, lr_critic, lr_actor, reward_kind=L.REWARD_MFG_AC2, seed=0, first_step=0, traj_offset=0,
+                        discount_pow=False, reward_acc=None, precision='mixed'):
+    """`episodes` multi-GPU training updates issued natively (mfg_train_rollouts_dist): per episode the rollout kernel
+    (previous update applied in its weight staging, start states drawn in the kernel), the batch sums and ONE RCCL all-reduce
+    of G from the library itself; the last update is applied before returning, parameters end up in (theta, w).
+    comm: address of a communicator from parallel.native_comm()."""
+    _chk_f32(mat_pi0, 'mat_pi0'); _chk_f64(theta, 'theta'); _chk_f64(w, 'w'); _chk_f64(theta_alt, 'theta_alt'); _chk_f64(w_alt, 'w_alt')
+    _chk_f64(G, 'G')
+    B, d = bufs['pi_traj'].shape[0], mat_pi0.shape[1]
+    flags = L.ROLLOUT_DISCOUNT_POW if discount_pow else 0
+    if L.PRECISIONS[precision] == L.PRECISION_F64:
+        flags |= L.ROLLOUT_F64
+    L.check(L.lib().mfg_train_rollouts_dist(comm, mat_pi0.data_ptr(), mat_pi0.shape[0], B, d, int(T), int(episodes), int(first_episode),
+                                            int(bool(constant)), theta.data_ptr(), w.data_ptr(), theta_alt.data_ptr(),
+                                            w_alt.data_ptr(), float(shift), float(alpha_scale), float(gamma), int(reward_kind),
+                                            int(seed), int(first_step), int(traj_offset), flags, float(lr_critic), float(lr_actor),
+                                            bufs['pi_traj'].data_ptr(), _ptr(bufs.get('pi_last')), bufs['reward'].data_ptr(),
+                                            bufs['delta'].data_ptr(), bufs['g'].data_ptr(), G.data_ptr(), _ptr(reward_acc),
+                                            ws.data_ptr(), ws.numel() * 8, _stream()), 'mfg_train_rollouts_dist')
+    return bufs
+
+
 def grad_accumulate(pi, delta, g, reward, G, ws, T=1, stride_b=None, add_reward=False, accumulate=False):
     """Batch sums G (+)= [sum delta phi | sum delta g | sum r | N] over B*T samples; add_reward: delta += reward first
     (in place) -- the IRL step after the reward network has run."""

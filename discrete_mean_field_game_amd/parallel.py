@@ -106,6 +106,51 @@ def broadcast_seed(value: int, group=None, device=None) -> int:
     return int(t.cpu()[0])
 
 
+_NATIVE_COMMS = {}
+
+
+def native_comm(group=None, device=None, allow_single=False):
+    """Address of an RCCL communicator owned by the HIP library for `group` (None where it cannot be had): the multi-GPU
+    episode loop then issues its one all-reduce per update itself (mfg_train_rollouts_dist) instead of returning to Python
+    and torch.distributed for every episode.  Rank 0 obtains an ncclUniqueId from the library, it is broadcast through the
+    existing process group, every rank initialises the communicator on its current device.  Only for jobs whose process
+    group runs on RCCL ('nccl' backend: one GPU per rank); created once per group and kept for the life of the process."""
+    import ctypes as C
+    from . import _lib as L
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) != 'nccl' or (world == 1 and not allow_single):
+        return None
+    key = (id(group), world)
+    if key in _NATIVE_COMMS:
+        return _NATIVE_COMMS[key]
+    lib = L.lib()
+    rank = dist.get_rank(group)
+    buf = (C.c_char * 128)()
+    ok = torch.ones(1, dtype=torch.int32, device=device)
+    if rank == 0 and lib.mfg_dist_unique_id(buf) != 0:
+        ok.zero_()                                                   # no RCCL in this process: tell everybody
+    t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone().to(device)
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast(ok, src=src, group=group)
+    dist.broadcast(t, src=src, group=group)
+    comm = None
+    if int(ok.cpu()[0]) == 1:
+        idb = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+        out = C.c_void_p()
+        torch.cuda.synchronize(device)
+        if lib.mfg_dist_init(idb, world, rank, C.byref(out)) == 0 and out.value:
+            comm = out.value
+    # a rank that failed must not leave the others using a communicator it is not part of
+    flag = torch.tensor([1 if comm else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.cpu()[0]) == 0:
+        comm = None
+    _NATIVE_COMMS[key] = comm
+    return comm
+
+
 def lr_scales(episode: int, constant) -> tuple:
     """(critic, actor) learning-rate multipliers of the reference schedule in `episode`
     (mfg_ac2.py:511-522: 1/(episode+1) and 1/((episode+1) ln ln(episode+20)); 1, 1 if constant)."""

@@ -238,6 +238,29 @@ int mfg_train_rollout_deferred(const float* mat_pi0, int64_t num_start, const in
                                uint64_t traj_offset, int flags, float* pi_traj, float* pi_last, float* reward, double* delta,
                                double* g, double* G, void* workspace, size_t workspace_bytes, mfg_stream_t stream);
 
+/* a9 on several GPUs, natively: the episode loop of mfg_train_rollouts with ONE RCCL all-reduce of G per update issued by
+ * this library on the caller's stream -- per episode [rollout kernel (applies the previous update, draws the start
+ * states) | batch sums | ncclAllReduce(G)], then mfg_apply_update once after the last episode; no interpreter and no
+ * framework call between the updates of a multi-GPU job.  RCCL is resolved at run time from the librccl.so the process
+ * already holds (PyTorch's); MFG_EUNSUPPORTED where there is none.
+ *   mfg_dist_unique_id : ncclGetUniqueId on ONE rank; ship the 128 bytes to the others (e.g. torch.distributed.broadcast)
+ *   mfg_dist_init      : ncclCommInitRank on EVERY rank (collective; the current device is the rank's GPU)
+ *   mfg_dist_all_reduce: in-place SUM of n doubles (the exchange of a per-step update; test hook)
+ *   mfg_train_rollouts_dist: arguments as mfg_train_rollouts (B = this rank's shard, traj_offset = its first global
+ *     trajectory id, G / count summed over the ranks) plus the second parameter set (theta_alt, w_alt) the updates
+ *     ping-pong through; on return the parameters are in (theta, w) and identical on every rank. */
+typedef struct mfg_rccl_id { char bytes[128]; } mfg_rccl_id_t; /* ncclUniqueId */
+int mfg_dist_unique_id(mfg_rccl_id_t* id_host);
+int mfg_dist_init(const mfg_rccl_id_t* id_host, int nranks, int rank, void** comm_out);
+int mfg_dist_destroy(void* comm);
+int mfg_dist_all_reduce(void* comm, double* G, int64_t n, mfg_stream_t stream);
+int mfg_train_rollouts_dist(void* comm, const float* mat_pi0, int64_t num_start, int64_t B, int d, int T, int64_t episodes,
+                            int64_t first_episode, int constant, double* theta, double* w, double* theta_alt, double* w_alt,
+                            double shift, double alpha_scale, double gamma, int reward_kind, uint64_t seed, uint32_t first_step,
+                            uint64_t traj_offset, int flags, double lr_critic, double lr_actor, float* pi_traj, float* pi_last,
+                            float* reward, double* delta, double* g, double* G, double* reward_acc, void* workspace,
+                            size_t workspace_bytes, mfg_stream_t stream);
+
 /* f1 (IRL): reward[b] = r_net(state_b, action_b), the reward network of networks.py:46-81 evaluated for B
  * transitions in one launch (ac_irl.py:683 evaluates it with batch 1 per env step).  fp32.  Weight layouts are
  * PyTorch's: conv1_w [k1*k1], conv2_w [f2][k2*k2], fc3_w [n3][d*d*f2] with the input index (pixel*f2 + channel)

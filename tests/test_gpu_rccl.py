@@ -101,3 +101,62 @@ def test_product_helpers_over_an_rccl_communicator():
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     z = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
     assert z['ok'] and z['backend'] == 'nccl' and z['all_reduce_calls'] == 1
+
+
+_CHILD_NATIVE = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+from discrete_mean_field_game_amd import parallel, ops, _lib as L
+from discrete_mean_field_game_amd.mfg_ac2 import actor_critic
+import ctypes as C
+mat = np.random.RandomState(3).dirichlet(np.ones(21), size=7)
+res = {}
+# the library's own communicator (a job with several ranks makes it in the class constructor; with ONE rank it only exists
+# for this test): bootstrapped through the process group, cached per group
+comm = parallel.native_comm(None, torch.device('cuda', 0), allow_single=True)
+calls = {'train_rollouts_dist': 0, 'all_reduce': 0}
+real_d, real_ar = ops.train_rollouts_dist, dist.all_reduce
+ops.train_rollouts_dist = lambda *a, **k: (calls.__setitem__('train_rollouts_dist', calls['train_rollouts_dist'] + 1), real_d(*a, **k))[1]
+for mode in ('native_dist', 'single'):
+    np.random.seed(11)
+    ac = actor_critic(d=21, pi0=mat, batch=500, rng='philox', seed=5, update_every='rollout', verbose=0)
+    ac._force_collective = mode == 'native_dist'
+    logs = []
+    ac.train_log = lambda v, f, fmt, logs=logs: logs.append(np.array(v, dtype=np.float64).tolist())
+    if mode == 'native_dist':
+        dist.all_reduce = lambda *a, **k: (_ for _ in ()).throw(AssertionError('train() must not go through torch.distributed per episode'))
+    ac.train(num_episodes=7, gamma=0.9, constant=0, consecutive=3, write_file=1, first_episode=1)
+    dist.all_reduce = real_ar
+    res[mode] = (float(np.ravel(ac.theta)[0]), ac.w[:, 0].tolist(), logs, ac._rng_step)
+# the exchange itself through the library's communicator: a 1-rank SUM is the identity
+assert parallel.native_comm(None, torch.device('cuda', 0), allow_single=True) == comm      # cached
+G = torch.arange(8, dtype=torch.float64, device='cuda')
+L.check(L.lib().mfg_dist_all_reduce(comm, G.data_ptr(), 8, torch.cuda.current_stream().cuda_stream), 'mfg_dist_all_reduce')
+torch.cuda.synchronize()
+print(json.dumps({'same_theta': res['native_dist'][0] == res['single'][0], 'same_w': res['native_dist'][1] == res['single'][1],
+                  'same_logs': res['native_dist'][2] == res['single'][2], 'steps': [res['native_dist'][3], res['single'][3]],
+                  'dist_calls': calls['train_rollouts_dist'], 'comm': bool(comm), 'G': G.cpu().tolist(),
+                  'theta': res['native_dist'][0]}))
+dist.destroy_process_group()
+'''
+
+
+def test_native_rccl_episode_loop_equals_the_single_gpu_loop():
+    """mfg_train_rollouts_dist: the multi-GPU episode loop with the all-reduce issued by the library itself (its own RCCL
+    communicator, bootstrapped through the process group), on a 1-rank communicator: the class takes it (no per-episode
+    torch.distributed call), chunks it at the reports like the single-GPU native loop, and -- a 1-rank sum being the
+    identity and the deferred update being bit-equal to an update launch -- ends with the same parameters, reports and
+    Philox counter as the single-GPU run."""
+    if not torch.cuda.is_available():
+        pytest.fail('-m gpu tests need a GPU')
+    p = subprocess.run([sys.executable, '-c', _CHILD_NATIVE % {'root': ROOT}], cwd=ROOT, env=_env(), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    z = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert z['comm'] and z['dist_calls'] == 3                      # chunks: episode 0 | 1..3 | 4..6 (reports at 0, 3, 6)
+    assert z['same_theta'] and z['same_w'] and z['same_logs'] and z['steps'] == [105, 105]
+    assert z['G'] == list(range(8)) and z['theta'] != 8.86349

@@ -32,8 +32,8 @@ z2 = json.loads([l for l in open('$O/collective_1rank_65536.json') if l.startswi
 out = {'source': 'bench.py --gpus 1 --force-dist (1-rank RCCL communicator on one MI355X; tools/profile_round.sh)',
        'collective': z['collective'],
        'multi_rank_cycle_ms_per_update': {'batch_8192': z['ms_per_step'], 'batch_65536': z2['ms_per_step']},
-       'note': 'per update: rollout kernel (previous update applied in its weight staging) | batch sums | ONE all-reduce of G; '
-               'issued per episode from Python (actor_critic.train with a process group)'}
+       'note': 'per update: rollout kernel (previous update applied in its weight staging) | batch sums | ONE all-reduce of G, '
+               'issued natively (mfg_train_rollouts_dist: the library\'s own RCCL communicator) by actor_critic.train'}
 json.dump(out, open('profiles/${P}_collective_1rank.json', 'w'), indent=1)
 print(out)
 PY
