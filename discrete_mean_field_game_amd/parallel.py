@@ -11,6 +11,7 @@ on the world size.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 
 import torch
@@ -117,8 +118,8 @@ def native_comm(group=None, device=None, allow_single=False):
     group runs on RCCL ('nccl' backend: one GPU per rank); created once per group and kept for the life of the process."""
     import ctypes as C
     from . import _lib as L
-    if not (dist.is_available() and dist.is_initialized()):
-        return None
+    if not (dist.is_available() and dist.is_initialized()) or os.environ.get('MFG_NATIVE_RCCL', '1') == '0':
+        return None                                  # MFG_NATIVE_RCCL=0: keep the exchange in torch.distributed (every rank)
     world = dist.get_world_size(group)
     if dist.get_backend(group) != 'nccl' or (world == 1 and not allow_single):
         return None
