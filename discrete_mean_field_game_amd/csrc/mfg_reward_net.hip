@@ -249,6 +249,24 @@ __device__ __forceinline__ float wave_sum_f32_dpp(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// four wave sums advancing together (every step's four DPP adds are independent)
+__device__ __forceinline__ void wave_sum4_f32_dpp(float (&v)[4]) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) v[u] += dpp_mov_f32<0xB1, 0xF>(v[u]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) v[u] += dpp_mov_f32<0x4E, 0xF>(v[u]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) v[u] += dpp_mov_f32<0x141, 0xF>(v[u]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) v[u] += dpp_mov_f32<0x140, 0xF>(v[u]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) v[u] += dpp_mov_f32<0x142, 0xA>(v[u]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) v[u] += dpp_mov_f32<0x143, 0xC>(v[u]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) v[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[u]), 63));
+}
+
 template <int D, int RUN, int RPR, int P1, int P2>
 struct RunsGeom {
   static_assert(RUN * RPR == D && D * RPR <= WAVE, "runs must tile a row exactly and fit one wavefront");
@@ -543,6 +561,456 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// FC3 on the matrix cores (round 4; reference networks.py:67-69: the [2 d^2] -> [n_fc3] layer is 70 % of the network's
+// multiply-adds).  Across SAMPLES the layer is a GEMM  H[16 samples x n3] = ACT[16 x 2d^2] . W3^T[2d^2 x n3]  -- but a
+// wave that owns 16 samples would run their convolutions one after the other (no good at B = 4 096, where every wave
+// has ONE sample).  So the block is 16 waves = 16 samples and the GEMM is split along K:
+//   phase 1  wave s evaluates the convolutions of sample s (run-mapped, as above) and leaves the 2 d^2 activations of its
+//            sample as row s of an LDS matrix (pitch = 2 mod 32: the operand reads of a 32-lane group touch 32 distinct banks);
+//   phase 2  wave w owns the k-slice [w KW, (w+1) KW) of ALL 16 samples: NSTEP = KW / 4 v_mfma_f32_16x16x4_f32 with
+//            A = activations (one ds_read_b32 per step) and B = ITS slice of the FC3 weights, which it fetched ONCE at
+//            kernel start and keeps in NSTEP registers -- the weights are neither staged in LDS nor re-read from L2 per
+//            sample (the run-mapped kernel reads all 28 KB per sample: 115 MB of L2 traffic per 4 096-sample launch);
+//            the 16 x 16 partial product (4 registers) goes to LDS;
+//   phase 3  wave s adds the 16 partials of its sample (4 LDS reads + two lane swaps, a fixed order), and finishes
+//            FC3's ReLU / dropout, FC4, the output unit (and the SUMS fold) like the run-mapped kernel.
+// Two block barriers per 16 samples.  fp32 multiply-add on the matrix cores (no reduced precision).  n3 <= 16.
+// ---------------------------------------------------------------------------------------------
+#ifndef MFG_RN_MFMA
+#define MFG_RN_MFMA 1
+#endif
+#ifndef MFG_RM_P21
+#define MFG_RM_P21 28  // tile pitch of the matrix-core kernel at d = 21: a conv read of a 32-lane group costs 2 LDS cycles
+#endif                 // instead of 3 at pitch 25 (banks (28 y + 7 r) mod 32; 116.5 -> 105.5 us at 65 536 samples)
+#ifndef MFG_RM_P15
+#define MFG_RM_P15 19
+#endif
+constexpr int RM_WAVES = 16, RM_BLOCK = RM_WAVES * WAVE, RM_RED = 260;  // RM_RED: floats per wave's partial (= 4 mod 64 x 4)
+typedef float rn_v4f_t __attribute__((ext_vector_type(4)));
+
+// Entry k of the row [sum delta phi | sum delta g | sum r | count]: positions of its two factors in the line [state | 1]
+// and the coefficient kind (0 delta, 1 delta g, 2 r, 3 one, -1 none), packed ia | ib << 8 | (kind + 1) << 16; built at
+// compile time (mfg_ac2.py:333 feature order: row-major upper triangle, then the linear terms, then the bias).
+template <int D>
+struct SumsTable {
+  static constexpr int Qs = D * (D + 1) / 2, Fs = Qs + D + 1, FO = Fs + 3, N = ((FO + WAVE - 1) / WAVE) * WAVE;
+  uint32_t e[N];
+  constexpr SumsTable() : e{} {
+    for (int k = 0; k < N; ++k) {
+      int ia = D, ib = D, cm = -1;
+      if (k < Qs) {
+        int i = 0;
+        while (i + 1 < D && (i + 1) * D - ((i + 1) * i) / 2 <= k) ++i;
+        ia = i;
+        ib = i + (k - (i * D - (i * (i - 1)) / 2));
+        cm = 0;
+      } else if (k < Qs + D) {
+        ia = k - Qs;
+        cm = 0;
+      } else if (k == Qs + D) {
+        cm = 0;
+      } else if (k < FO) {
+        cm = k - Fs + 1;
+      }
+      e[k] = (uint32_t)ia | ((uint32_t)ib << 8) | ((uint32_t)(cm + 1) << 16);
+    }
+  }
+};
+
+constexpr bool rows_hit_distinct_even_banks(int stride) {  // 16 rows `stride` floats apart: 16 different even banks of 32
+  unsigned seen = 0;
+  for (int n = 0; n < 16; ++n) {
+    const int b = (stride * n) % 32;
+    if ((b & 1) || ((seen >> b) & 1u)) return false;
+    seen |= 1u << b;
+  }
+  return true;
+}
+
+template <int D, int RUN, int RPR, int P1, int P2>
+struct MfmaGeom : RunsGeom<D, RUN, RPR, P1, P2> {
+  using Base = RunsGeom<D, RUN, RPR, P1, P2>;
+  static constexpr int K = Base::F2 * Base::DD;             // FC3 inputs
+  static constexpr int NSTEP = (K + 4 * RM_WAVES - 1) / (4 * RM_WAVES);  // matrix instructions per wave and group
+  static constexpr int KW = 4 * NSTEP, KP = RM_WAVES * KW;  // k's per wave, padded K
+  // ds_read_b32 is served in two 32-lane groups over 32 banks: the A-operand read of a group touches samples 0..15 at
+  // k, k + 1 -> banks (s PITCH + {0, 1}) mod 32 must be 32 different ones: PITCH = 2 mod 32
+  static constexpr int PITCH = ((KP - 2 + 31) / 32) * 32 + 2;
+  static_assert(PITCH >= KP && (PITCH & 31) == 2, "activation rows: room for the padded K, conflict-free operand reads");
+  static size_t lds_floats(int n3, int n4, bool sums) {
+    size_t fl = (size_t)(n4 * (n3 + D) + 2 * n4 + 1 + n3);
+    fl = (fl + 3) & ~(size_t)3;
+    return fl + (size_t)RM_WAVES * (PITCH + RM_RED + Base::T1 + Base::T2) + (sums ? RM_WAVES * 32 : 0);
+  }
+};
+
+// Developer build (-DMFG_RN_STAMPS, tools/rn_stamps.py): shader-clock stamps of the phases of blocks 0 and 100, every wave,
+// first group; read back with mfg_debug_rn_stamps.
+#ifdef MFG_RN_STAMPS
+__device__ unsigned long long rn_stamps[2 * RM_WAVES * 12];
+#define RN_STAMP(i)                                                                                          \
+  if ((blockIdx.x == 0 || blockIdx.x == 100) && lane == 0 && first_pass)                                     \
+    rn_stamps[((blockIdx.x ? 1 : 0) * RM_WAVES + wv) * 12 + (i)] = __builtin_readcyclecounter();
+#else
+#define RN_STAMP(i)
+#endif
+
+template <int D, int RUN, int RPR, int P1, int P2, bool SUMS>
+__global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
+  using Gm = MfmaGeom<D, RUN, RPR, P1, P2>;
+  constexpr int K1 = Gm::K1, K2 = Gm::K2, F2 = Gm::F2, H1 = Gm::H1, H2 = Gm::H2, DD = Gm::DD, PP = Gm::PP;
+  constexpr int KK = Gm::K, NSTEP = Gm::NSTEP, KW = Gm::KW, PITCH = Gm::PITCH;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n3 = a.n3, n4 = a.n4, nin = n3 + D;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  bool first_pass = true;
+  (void)first_pass;
+  RN_STAMP(0)
+  float* s_w4 = smem;
+  float* s_b4 = s_w4 + n4 * nin;
+  float* s_wo = s_b4 + n4;
+  float* s_bo = s_wo + n4;
+  float* s_b3 = s_bo + 1;
+  int off = n4 * nin + 2 * n4 + 1 + n3;
+  off = (off + 3) & ~3;
+  float* acts = smem + off;                          // [16 samples][PITCH]
+  float* red = acts + RM_WAVES * PITCH;              // [16 k-slices][RM_RED]: register r of lane l at r*64 + l
+  float* tiles = red + RM_WAVES * RM_RED;
+  float* tin = tiles + wv * (Gm::T1 + Gm::T2);
+  float* tc1 = tin + Gm::T1;
+  // the first group's action is in flight under everything below
+  const int64_t ngroups = (a.B + RM_WAVES - 1) / RM_WAVES;
+  int64_t g = blockIdx.x;
+  int64_t b = g * RM_WAVES + wv;
+  float av[PP], st_mine = 0.0f;
+  double d0_next = 0.0, g_next = 0.0;
+  // (every load of the prologue is UNCONDITIONAL, from a clamped address, and masked afterwards: loads under branches make
+  //  the compiler wait for all outstanding loads at the first use of any of them -- including the weight slice below)
+  {
+    const int64_t bc = b < a.B ? b : 0;
+#pragma unroll
+    for (int q = 0; q < PP; ++q) {
+      const bool ok = b < a.B && lane + q * WAVE < DD;
+      const float v = a.action[bc * DD + (lane + q * WAVE < DD ? lane + q * WAVE : 0)];
+      av[q] = ok ? v : 0.0f;
+    }
+    const bool st_ok = b < a.B && lane >= n3 && lane < nin;
+    const float sv = a.state[bc * D + (lane >= n3 && lane < nin ? lane - n3 : 0)];
+    st_mine = st_ok ? sv : 0.0f;
+    if constexpr (SUMS) {
+      d0_next = a.delta0[bc];
+      g_next = a.gsc[bc];
+    }
+  }
+  // This wave's slice of the FC3 weights, rows n < 16 x k in [wv KW, (wv + 1) KW): fetched as whole row pieces (8-byte
+  // lanes, RPI rows per instruction: 8 instructions at d = 21), transposed into the B-operand layout through the wave's own
+  // tile region before that is initialised -- wave-local, no block barrier -- and kept in NSTEP registers for every group.
+  // (Fetched directly in the operand layout the slice is 14 gathers per wave -- 8 cache lines per instruction, 16 bytes used
+  //  of each: 6 000 cycles of the CU's address path per block, in front of the other waves' action loads or, issued later,
+  //  in front of the last waves' convolutions; staged for the whole block in LDS it costs two block barriers.)
+  // Rows >= n3 repeat row n3 - 1 (columns nobody reads); a padded k >= KK repeats the row's last pair (it meets a zero
+  // activation, any finite weight will do).
+  constexpr int JW = KW / 2, LPR = JW > 16 ? 32 : 16, RPI = WAVE / LPR, NLD = 16 / RPI, WS = KW + 2;
+  static_assert(JW <= LPR && (KK & 1) == 0 && 16 * WS <= Gm::T1 + Gm::T2 && rows_hit_distinct_even_banks(WS),
+                "weight scratch: fits the tile region; the operand read of a 32-lane group (16 rows x 2 k's) hits 32 banks");
+  float2 w3r[NLD];
+  {
+    const int j = lane & (LPR - 1), nr = lane / LPR;
+    const int k2 = wv * KW + 2 * j < KK - 2 ? wv * KW + 2 * j : KK - 2;
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int n = u * RPI + nr;
+      w3r[u] = *reinterpret_cast<const float2*>(a.w3 + (n < n3 ? n : n3 - 1) * KK + (j < JW ? k2 : KK - 2));
+    }
+  }
+  // ALL global reads of the prologue are issued before the first use (one round trip: a launch of the per-step IRL update
+  // has one sample per wave, so the prologue is on the critical path -- with the parameter copies, the conv-weight gather
+  // and the SUMS table each waiting for their own loads it took 10 800 of the kernel's 31 000 cycles)
+  constexpr int NW1 = K1 * K1, NW2 = F2 * K2 * K2;
+  static_assert(NW1 + 1 + NW2 + F2 <= WAVE, "conv parameters must fit one wavefront");
+  float wtab;
+  {
+    const float* src = lane < NW1 ? a.c1w + lane
+                     : lane == NW1 ? a.c1b
+                     : lane < NW1 + 1 + NW2 ? a.c2w + (lane - NW1 - 1)
+                     : a.c2b + (lane < NW1 + 1 + NW2 + F2 ? lane - NW1 - 1 - NW2 : 0);
+    wtab = *src;
+  }
+  constexpr int Qs = D * (D + 1) / 2, Fs = Qs + D + 1, FO = Fs + 3, NPL = (FO + WAVE - 1) / WAVE;
+  uint32_t tabv[NPL];
+  if constexpr (SUMS) {
+    static constexpr SumsTable<D> tab{};
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) tabv[q] = tab.e[lane + q * WAVE];
+  }
+  const int nw4 = n4 * nin;  // <= 32 * 48: at most two entries per thread
+  const float pw4a = a.w4[tid < nw4 ? tid : 0], pw4b = a.w4[tid + RM_BLOCK < nw4 ? tid + RM_BLOCK : 0];
+  const float pb4 = a.b4[tid < n4 ? tid : 0], pwo = a.wo[tid < n4 ? tid : 0], pb3 = a.b3[tid < n3 ? tid : 0];
+  const float pbo = a.bo[0];
+  // LDS initialisation (independent of the loads): the padded k's of every activation row stay zero (a row's real entries
+  // are rewritten per group; the rows of samples beyond B hold whatever LDS held -- row m of A only reaches row m of the
+  // product); zero halos of the tiles (interiors are rewritten)
+  float wreg[NSTEP];
+  {
+    const int j = lane & (LPR - 1), nr = lane / LPR;
+    if (j < JW) {
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) *reinterpret_cast<float2*>(tin + (u * RPI + nr) * WS + 2 * j) = w3r[u];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < NSTEP; ++s) wreg[s] = tin[(lane & 15) * WS + 4 * s + (lane >> 4)];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int k = lane; k < Gm::T1 + Gm::T2; k += WAVE) tin[k] = 0.0f;
+  if (tid < nw4) s_w4[tid] = pw4a;
+  if (tid + RM_BLOCK < nw4) s_w4[tid + RM_BLOCK] = pw4b;
+  if (tid < n4) {
+    s_b4[tid] = pb4;
+    s_wo[tid] = pwo;
+  }
+  if (tid == 0) s_bo[0] = pbo;
+  if (tid < n3) s_b3[tid] = pb3;
+  float w1[NW1], w2[F2][K2 * K2];
+#pragma unroll
+  for (int k = 0; k < NW1; ++k) w1[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), k));
+  const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1));
+#pragma unroll
+  for (int c = 0; c < F2; ++c)
+#pragma unroll
+    for (int k = 0; k < K2 * K2; ++k)
+      w2[c][k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 1 + c * K2 * K2 + k));
+  const float b20 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 1 + NW2));
+  const float b21 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 2 + NW2));
+  for (int k = tid; k < RM_WAVES * (PITCH - KK); k += RM_BLOCK) acts[(k / (PITCH - KK)) * PITCH + KK + k % (PITCH - KK)] = 0.0f;
+  RN_STAMP(1)
+  __syncthreads();
+  RN_STAMP(2)
+  const float inv_keep = 1.0f / a.keep_prob;
+  const bool drop = a.keep_prob < 1.0f;
+  const bool active = lane < D * RPR;
+  const int y = active ? lane / RPR : 0, x0 = active ? (lane - y * RPR) * RUN : 0;
+  const float* win1 = tin + y * P1 + x0;
+  float* out1 = tc1 + (y + H2) * P2 + x0 + H2;
+  const float* win2 = tc1 + y * P2 + x0;
+  float2* act_out = reinterpret_cast<float2*>(acts + wv * PITCH + (y * D + x0) * F2);  // the run's 2 RUN inputs of FC3
+  const float* act_in = acts + (lane & 15) * PITCH + wv * KW + (lane >> 4);             // A operand: sample lane % 16
+  float* red_out = red + wv * RM_RED + lane;
+  // phase 3 reads the partials of sample wv: lane -> unit n = lane % 16, k-slices 4 (lane / 16) ... + 3
+  const float* red_in = red + (4 * (lane >> 4)) * RM_RED + (wv & 3) * 64 + 16 * (wv >> 2) + (lane & 15);
+  int o1[PP];
+#pragma unroll
+  for (int q = 0; q < PP; ++q) {
+    const int p = lane + q * WAVE;
+    const int pc = p < DD ? p : 0;
+    o1[q] = (pc / D + H1) * P1 + pc % D + H1;
+  }
+  float* xs = tiles + RM_WAVES * (Gm::T1 + Gm::T2) + wv * 32;  // (only allocated for SUMS launches)
+  double e_acc[NPL];
+  if constexpr (SUMS) {
+    // (the run-mapped kernel derives the entries with a search per lane: ~800 instructions per wave, as much as a sample's
+    //  convolutions; here they stay packed in one register each and are unpacked at the fold)
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) e_acc[q] = 0.0;
+    if (lane == 0) xs[D] = 1.0f;
+  }
+  RN_STAMP(3)
+  for (; g < ngroups; g += gridDim.x) {  // (block-uniform trip count: the barriers below are taken by all 16 waves)
+    b = g * RM_WAVES + wv;
+    const bool valid = b < a.B;
+    // 1. action -> padded LDS tile; the next group's sample is fetched under this one's evaluation
+#pragma unroll
+    for (int q = 0; q < PP; ++q)
+      if (lane + q * WAVE < DD) tin[o1[q]] = av[q];
+    const float st_cur = st_mine;
+    const double d0_cur = d0_next, g_cur = g_next;
+    if (SUMS && lane >= n3 && lane < nin) xs[lane - n3] = st_cur;
+    {
+      const int64_t bn = b + (int64_t)gridDim.x * RM_WAVES;
+#pragma unroll
+      for (int q = 0; q < PP; ++q) av[q] = (bn < a.B && lane + q * WAVE < DD) ? a.action[bn * DD + lane + q * WAVE] : 0.0f;
+      if (bn < a.B && lane >= n3 && lane < nin) st_mine = a.state[bn * D + (lane - n3)];
+      if (SUMS && bn < a.B) {
+        d0_next = a.delta0[bn];
+        g_next = a.gsc[bn];
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // 2. conv1 5x5 + ReLU over the run
+    float c1[RUN];
+#pragma unroll
+    for (int k = 0; k < RUN; ++k) c1[k] = b1;
+#pragma unroll
+    for (int dy = 0; dy < K1; ++dy) {
+      float row[RUN + K1 - 1];
+#pragma unroll
+      for (int t = 0; t < RUN + K1 - 1; ++t) row[t] = win1[dy * P1 + t];
+#pragma unroll
+      for (int k = 0; k < RUN; ++k)
+#pragma unroll
+        for (int dx = 0; dx < K1; ++dx) c1[k] = fmaf(row[k + dx], w1[dy * K1 + dx], c1[k]);
+    }
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < RUN; ++k) out1[k] = fmaxf(c1[k], 0.0f);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    RN_STAMP(4)
+    // 3. conv2 3x3, two filters + ReLU -> row wv of the activation matrix (NHWC order: pixel * 2 + channel)
+    float a2[RUN][F2];
+#pragma unroll
+    for (int k = 0; k < RUN; ++k) {
+      a2[k][0] = b20;
+      a2[k][1] = b21;
+    }
+#pragma unroll
+    for (int dy = 0; dy < K2; ++dy) {
+      float row[RUN + K2 - 1];
+#pragma unroll
+      for (int t = 0; t < RUN + K2 - 1; ++t) row[t] = win2[dy * P2 + t];
+#pragma unroll
+      for (int k = 0; k < RUN; ++k)
+#pragma unroll
+        for (int dx = 0; dx < K2; ++dx) {
+          a2[k][0] = fmaf(row[k + dx], w2[0][dy * K2 + dx], a2[k][0]);
+          a2[k][1] = fmaf(row[k + dx], w2[1][dy * K2 + dx], a2[k][1]);
+        }
+    }
+    if (active) {
+#pragma unroll
+      for (int k = 0; k < RUN; ++k) act_out[k] = make_float2(fmaxf(a2[k][0], 0.0f), fmaxf(a2[k][1], 0.0f));
+    }
+    float u_drop = 0.0f;
+    if (drop) {
+      const u32x4 r = philox_elem(a.seed, (uint32_t)(lane & 31), lane < 32 ? 3u : 4u, a.sample_offset + (uint64_t)b, 0);
+      u_drop = u01(r.x);
+    }
+    RN_STAMP(5)
+    __syncthreads();  // the 16 activation rows are complete
+    RN_STAMP(6)
+    // 4. FC3, this wave's k-slice of all 16 samples: C[sample 4 (lane / 16) + r][unit lane % 16]
+    {
+      rn_v4f_t acc = {0.0f, 0.0f, 0.0f, 0.0f};
+      float av3[NSTEP];
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) av3[s] = act_in[4 * s];
+#pragma unroll
+      for (int s = 0; s < NSTEP; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av3[s], wreg[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red_out[r * 64] = acc[r];
+    }
+    RN_STAMP(7)
+    __syncthreads();  // the 16 partial products are complete (and every wave is done reading the activations)
+    RN_STAMP(8)
+    // sample wv, unit lane % 16: the 16 k-slices in a fixed order
+    float h3 = (red_in[0] + red_in[RM_RED]) + (red_in[2 * RM_RED] + red_in[3 * RM_RED]);
+    {
+      const auto r4 = __builtin_amdgcn_permlane16_swap(__float_as_uint(h3), __float_as_uint(h3), false, false);
+      h3 = __uint_as_float(r4[0]) + __uint_as_float(r4[1]);  // lane bit 4
+      const auto r5 = __builtin_amdgcn_permlane32_swap(__float_as_uint(h3), __float_as_uint(h3), false, false);
+      h3 = __uint_as_float(r5[0]) + __uint_as_float(r5[1]);  // lane bit 5
+    }
+    // ReLU (+ dropout); lane o < n3 keeps unit o, lanes n3 .. n3+D-1 hold the state: `x4` is FC4's input
+    float x4 = (lane >= n3 && lane < nin) ? st_cur : 0.0f;
+    {
+      float h = fmaxf(h3 + s_b3[lane < n3 ? lane : 0], 0.0f);
+      if (drop) h = (u_drop <= a.keep_prob) ? h * inv_keep : 0.0f;  // lane o < 32 drew unit o of FC3
+      if (lane < n3) x4 = h;
+    }
+    // 5. FC4 over [h3, state] + ReLU (+ dropout), 6. output unit
+    // (four units at a time: their products come from four LDS reads in flight together and their wave sums advance in
+    //  step -- one unit after the other the layer was four dependent ~250-cycle chains per sample)
+    float z = s_bo[0];
+    for (int o0 = 0; o0 < n4; o0 += 4) {
+      float p4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p4[u] = (lane < nin && o0 + u < n4) ? x4 * s_w4[(o0 + u) * nin + lane] : 0.0f;
+      wave_sum4_f32_dpp(p4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int o = o0 + u < n4 ? o0 + u : 0;
+        float h4 = fmaxf(p4[u] + s_b4[o], 0.0f);
+        if (drop) h4 = (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(u_drop), (32 + o) & 63)) <= a.keep_prob) ? h4 * inv_keep : 0.0f;
+        z = fmaf(h4, o0 + u < n4 ? s_wo[o] : 0.0f, z);
+      }
+    }
+    const float rwd = tanhf(z);
+    if (valid && lane == 0) a.reward[b] = rwd;
+    RN_STAMP(9)
+    if constexpr (SUMS) {
+      if (valid) {
+        const double rr = (double)rwd, de = d0_cur + rr;  // delta = r + discount V(pi') - V(pi)   (ac_irl.py:691)
+        if (lane == 0) a.delta_out[b] = de;
+        const double dgc = de * g_cur;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+          const int cm = (int)(tabv[q] >> 16) - 1;
+          const double x = (double)xs[tabv[q] & 0xFFu] * (double)xs[(tabv[q] >> 8) & 0xFFu];
+          const double coef = cm == 0 ? de : (cm == 1 ? dgc : (cm == 2 ? rr : (cm == 3 ? 1.0 : 0.0)));
+          e_acc[q] = fma(coef, x, e_acc[q]);
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    RN_STAMP(10)
+    first_pass = false;
+  }
+  if constexpr (SUMS) {
+    static_assert(D + 1 <= 32, "the per-wave line [state | 1] of the SUMS variant holds 32 floats");
+    static_assert(RM_WAVES * FO * 8 <= RM_WAVES * (Gm::T1 + Gm::T2) * 4, "the waves' partial rows reuse the tile region");
+    __syncthreads();
+    double* rows = reinterpret_cast<double*>(tiles);
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+      const int k = lane + q * WAVE;
+      if (k < FO) rows[wv * FO + k] = e_acc[q];
+    }
+    __syncthreads();
+    for (int k = tid; k < FO; k += RM_BLOCK) {
+      double t = rows[k];
+#pragma unroll
+      for (int w_ = 1; w_ < RM_WAVES; ++w_) t += rows[w_ * FO + k];
+      a.part_rows[(int64_t)blockIdx.x * FO + k] = t;
+    }
+  }
+#ifdef MFG_RN_STAMPS
+  first_pass = true;
+#endif
+  RN_STAMP(11)
+}
+
+template <int D, int RUN, int RPR, int P1, int P2>
+static int launch_reward_net_mfma(const RewardNetArgs& a, bool want_sums, int64_t max_rows, int* rows_out, hipStream_t st) {
+  using Gm = MfmaGeom<D, RUN, RPR, P1, P2>;
+  int64_t grid = (a.B + RM_WAVES - 1) / RM_WAVES;
+  if (grid > 256) grid = 256;  // one 16-wave block per CU (LDS: 154 KB at d = 21)
+  const bool sums = want_sums && grid <= max_rows;
+  const size_t lds = Gm::lds_floats(a.n3, a.n4, sums) * 4;
+  static bool attr_set = false;  // (dynamic LDS above 64 KB)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, P2, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, P2, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    attr_set = true;
+  }
+  if (sums) {
+    hipLaunchKernelGGL((k_reward_net_mfma<D, RUN, RPR, P1, P2, true>), dim3((unsigned)grid), dim3(RM_BLOCK), lds, st, a);
+    *rows_out = (int)grid;
+  } else {
+    hipLaunchKernelGGL((k_reward_net_mfma<D, RUN, RPR, P1, P2, false>), dim3((unsigned)grid), dim3(RM_BLOCK), lds, st, a);
+  }
+  return 0;
+}
+
 }  // namespace mfg
 
 using namespace mfg;
@@ -600,6 +1068,14 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
   // w3 rows are read as float2 at even offsets: needs an 8-byte aligned fc3_w when it is not staged in LDS
   const bool runs_ok = ref_geom && (a.w3_in_lds || (((uintptr_t)fc3_w & 7) == 0));
   const bool want_sums = sums && sums->delta0 && sums->g && sums->delta_out && sums->part_rows && grid <= sums->max_rows;
+  const bool sums_ptrs = sums && sums->delta0 && sums->g && sums->delta_out && sums->part_rows;
+  const bool mfma_ok = MFG_RN_MFMA && ref_geom && n3 <= 16 && (d == 21 || d == 15) && (((uintptr_t)fc3_w & 7) == 0);
+  if (mfma_ok) {
+    int rows = 0;
+    if (d == 21) launch_reward_net_mfma<21, 7, 3, MFG_RM_P21, MFG_RM_P21>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st);
+    else launch_reward_net_mfma<15, 5, 3, MFG_RM_P15, MFG_RM_P15>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st);
+    if (rows_out) *rows_out = rows;
+  } else
   if (runs_ok && d == 21) {
     using Gm = RunsGeom<21, 7, 3, MFG_RN_P21, MFG_RN_P21>;
     if (want_sums) {
@@ -636,3 +1112,9 @@ extern "C" int mfg_reward_net_forward(const float* state, const float* action, i
   return mfg::reward_net_forward_sums(state, action, B, d, k1, f2, k2, n3, n4, conv1_w, conv1_b, conv2_w, conv2_b, fc3_w, fc3_b,
                                       fc4_w, fc4_b, out_w, out_b, keep_prob, seed, sample_offset, reward, nullptr, nullptr, stream);
 }
+
+#ifdef MFG_RN_STAMPS
+extern "C" int mfg_debug_rn_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mfg::rn_stamps), sizeof(mfg::rn_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif

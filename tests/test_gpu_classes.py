@@ -236,7 +236,8 @@ def test_irl_outerloop_smoke(dev):
 
 
 @pytest.mark.parametrize('reg', ['none', 'dropout_l1l2'])
-@pytest.mark.parametrize('d,n3,n4', [(15, 8, 4), (21, 8, 4), (21, 6, 8), (32, 4, 4), (4, 3, 2)])
+@pytest.mark.parametrize('d,n3,n4', [(15, 8, 4), (21, 8, 4), (21, 6, 8), (32, 4, 4), (4, 3, 2), (21, 16, 4), (15, 16, 8), (21, 20, 4),
+                                     (15, 17, 3)])
 def test_reward_net_hip_forward_matches_torch_and_numpy(dev, reg, d, n3, n4):
     """One-launch HIP forward of the reward net (ac_irl.py:683 batched) vs the PyTorch module and the NumPy
     restatement of networks.py:46-81 (dropout off: deterministic part)."""
@@ -264,7 +265,7 @@ def test_reward_net_hip_forward_matches_torch_and_numpy(dev, reg, d, n3, n4):
     assert np.max(np.abs(out)) < 1
 
 
-@pytest.mark.parametrize('d,n3,n4', [(21, 8, 4), (15, 8, 4), (32, 32, 32), (21, 6, 8)])
+@pytest.mark.parametrize('d,n3,n4', [(21, 8, 4), (15, 8, 4), (32, 32, 32), (21, 6, 8), (21, 16, 16), (21, 24, 4)])
 def test_reward_net_hip_dropout_masks_are_the_documented_philox_bits(dev, d, n3, n4):
     """With dropout ON (the reference's default reg and its behaviour when the net serves as the RL reward) the kernel's
     output equals the oracle evaluated with masks redrawn from the documented counters: unit o of FC3 / FC4 of sample n
@@ -290,6 +291,30 @@ def test_reward_net_hip_dropout_masks_are_the_documented_philox_bits(dev, d, n3,
         assert np.max(np.abs(out - ref)) < 5e-6, (seed, off)
         m3, m4 = RO.dropout_masks(0.4, seed, off, B, n3, n4)
         assert 0.3 < (m3 > 0).mean() < 0.5 and 0.25 < (m4 > 0).mean() < 0.55       # keep probability 0.4
+
+
+@pytest.mark.parametrize('d', [21, 15])
+@pytest.mark.parametrize('B', [1, 15, 16, 17, 4111, 8192 + 5])
+def test_reward_net_hip_group_edges(dev, d, B):
+    """The matrix-core kernel evaluates 16 samples per block pass (one per wave, FC3 split along K over the 16 waves):
+    batches that are not multiples of 16, fewer samples than one group, more groups than resident blocks (256) -- with
+    and without dropout, every sample against the oracle."""
+    from discrete_mean_field_game_amd import ops
+    from discrete_mean_field_game_amd.networks import RewardNet
+    from oracle import reward_net_oracle as RO
+    torch.manual_seed(B)
+    net = RewardNet(d=d, reg='dropout_l1l2').to(dev).eval()
+    rs = np.random.RandomState(B + d)
+    state = rs.dirichlet(np.ones(d), size=B).astype(np.float32)
+    action = rs.dirichlet(np.ones(d), size=(B, d)).astype(np.float32)
+    s_t, a_t = torch.as_tensor(state, device=dev), torch.as_tensor(action, device=dev)
+    params = RO.params_from_torch(net)
+    out = ops.reward_net_forward(net, s_t, a_t, dropout=False).cpu().numpy()
+    ref = RO.forward(params, state.astype(np.float64), action.astype(np.float64))[:, 0]
+    assert out.shape == (B,) and np.max(np.abs(out - ref)) < 2e-6
+    out = ops.reward_net_forward(net, s_t, a_t, seed=9, sample_offset=77).cpu().numpy()
+    ref = RO.forward(params, state.astype(np.float64), action.astype(np.float64), dropout=(0.4, 9, 77))[:, 0]
+    assert np.max(np.abs(out - ref)) < 5e-6
 
 
 def test_reward_net_hip_dropout_statistics(dev):
