@@ -249,22 +249,39 @@ __device__ __forceinline__ float wave_sum_f32_dpp(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-// four wave sums advancing together (every step's four DPP adds are independent)
-__device__ __forceinline__ void wave_sum4_f32_dpp(float (&v)[4]) {
-#pragma unroll
-  for (int u = 0; u < 4; ++u) v[u] += dpp_mov_f32<0xB1, 0xF>(v[u]);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) v[u] += dpp_mov_f32<0x4E, 0xF>(v[u]);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) v[u] += dpp_mov_f32<0x141, 0xF>(v[u]);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) v[u] += dpp_mov_f32<0x140, 0xF>(v[u]);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) v[u] += dpp_mov_f32<0x142, 0xA>(v[u]);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) v[u] += dpp_mov_f32<0x143, 0xC>(v[u]);
-#pragma unroll
-  for (int u = 0; u < 4; ++u) v[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[u]), 63));
+// Four wave sums advancing together: lane 63 ends up with the four totals.  One block of 24 DPP adds -- every step's four
+// instructions are independent and separate an instruction from the one that reads its result (the two wait states a DPP
+// source needs); the last two steps add lane 15 / 31 of the previous rows into rows {1, 3} / {2, 3} in place (as separate
+// move + add they are three instructions each).
+__device__ __forceinline__ void wave_sum4_to_lane63(float (&v)[4]) {
+  asm volatile(
+      "s_nop 1\n"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+      "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+      "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+      "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+      "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+      "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+      "s_nop 1\n"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
 }
 
 template <int D, int RUN, int RPR, int P1, int P2>
@@ -589,6 +606,7 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
 #endif
 constexpr int RM_WAVES = 16, RM_BLOCK = RM_WAVES * WAVE, RM_RED = 260;  // RM_RED: floats per wave's partial (= 4 mod 64 x 4)
 typedef float rn_v4f_t __attribute__((ext_vector_type(4)));
+typedef float rn_v4f_u __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte global access at any 4-byte address
 
 // Entry k of the row [sum delta phi | sum delta g | sum r | count]: positions of its two factors in the line [state | 1]
 // and the coefficient kind (0 delta, 1 delta g, 2 r, 3 one, -1 none), packed ia | ib << 8 | (kind + 1) << 16; built at
@@ -664,7 +682,8 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
   constexpr int KK = Gm::K, NSTEP = Gm::NSTEP, KW = Gm::KW, PITCH = Gm::PITCH;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n3 = a.n3, n4 = a.n4, nin = n3 + D;
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE);  // (uniform: per-sample scalars come through the scalar cache)
   bool first_pass = true;
   (void)first_pass;
   RN_STAMP(0)
@@ -704,25 +723,31 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
       g_next = a.gsc[bc];
     }
   }
-  // This wave's slice of the FC3 weights, rows n < 16 x k in [wv KW, (wv + 1) KW): fetched as whole row pieces (8-byte
-  // lanes, RPI rows per instruction: 8 instructions at d = 21), transposed into the B-operand layout through the wave's own
-  // tile region before that is initialised -- wave-local, no block barrier -- and kept in NSTEP registers for every group.
-  // (Fetched directly in the operand layout the slice is 14 gathers per wave -- 8 cache lines per instruction, 16 bytes used
-  //  of each: 6 000 cycles of the CU's address path per block, in front of the other waves' action loads or, issued later,
-  //  in front of the last waves' convolutions; staged for the whole block in LDS it costs two block barriers.)
-  // Rows >= n3 repeat row n3 - 1 (columns nobody reads); a padded k >= KK repeats the row's last pair (it meets a zero
-  // activation, any finite weight will do).
-  constexpr int JW = KW / 2, LPR = JW > 16 ? 32 : 16, RPI = WAVE / LPR, NLD = 16 / RPI, WS = KW + 2;
-  static_assert(JW <= LPR && (KK & 1) == 0 && 16 * WS <= Gm::T1 + Gm::T2 && rows_hit_distinct_even_banks(WS),
+  // This wave's slice of the FC3 weights, rows n < 16 x k in [wv KW, (wv + 1) KW): fetched as whole row pieces (16-byte
+  // lanes -- rows start at multiples of 8 bytes only, global loads need no more --, RPI rows per instruction: 2 instructions
+  // at d = 21, n3 = 8), transposed into the B-operand layout through the wave's own tile region before that is initialised
+  // -- wave-local, no block barrier -- and kept in NSTEP registers for every group.
+  // (The CU's address path takes ~16 cycles per vector-memory instruction whatever its width, and a launch of the per-step
+  //  IRL update has ONE sample per wave: the prologue's instruction count is its cost.  Fetched directly in the operand
+  //  layout the slice is 14 gathers per wave -- 6 000 cycles per block in front of the other waves' action loads or, issued
+  //  later, in front of the last waves' convolutions; staged for the whole block in LDS it costs two block barriers.)
+  // Rows >= n3 repeat row n3 - 1 (columns nobody reads); a piece that would pass the end of its row is fetched from the
+  // row's last 16 bytes: its real entries (KK = 2 mod 4: two) are moved to the front, the padded k's behind them meet zero
+  // activations -- any finite weight will do.
+  constexpr int J4 = KW / 4, LPR = J4 > 8 ? 16 : 8, RPI = WAVE / LPR, NLD = 16 / RPI, WS = KW + 2;
+  static_assert(J4 <= LPR && (KK & 3) == 2 && (KW & 3) == 0 && 16 * WS <= Gm::T1 + Gm::T2 && rows_hit_distinct_even_banks(WS),
                 "weight scratch: fits the tile region; the operand read of a 32-lane group (16 rows x 2 k's) hits 32 banks");
-  float2 w3r[NLD];
+  rn_v4f_u w3r[NLD];
+  const int w3j = lane & (LPR - 1), w3nr = lane / LPR;
+  const int w3k = wv * KW + 4 * w3j;                       // first k of this lane's piece
+  const bool w3_half = w3k == KK - 2;                      // the piece holds the row's last two entries
   {
-    const int j = lane & (LPR - 1), nr = lane / LPR;
-    const int k2 = wv * KW + 2 * j < KK - 2 ? wv * KW + 2 * j : KK - 2;
+    const int kc = (w3j < J4 && w3k <= KK - 4) ? w3k : KK - 4;
 #pragma unroll
     for (int u = 0; u < NLD; ++u) {
-      const int n = u * RPI + nr;
-      w3r[u] = *reinterpret_cast<const float2*>(a.w3 + (n < n3 ? n : n3 - 1) * KK + (j < JW ? k2 : KK - 2));
+      const int n = u * RPI + w3nr;
+      if (u * RPI < n3) w3r[u] = *reinterpret_cast<const rn_v4f_u*>(a.w3 + (n < n3 ? n : n3 - 1) * KK + kc);
+      else w3r[u] = w3r[0];
     }
   }
   // ALL global reads of the prologue are issued before the first use (one round trip: a launch of the per-step IRL update
@@ -738,26 +763,45 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
                      : a.c2b + (lane < NW1 + 1 + NW2 + F2 ? lane - NW1 - 1 - NW2 : 0);
     wtab = *src;
   }
+  // the small parameters and the SUMS table are the same for every wave: wave 0 fetches them, the others take them from LDS
   constexpr int Qs = D * (D + 1) / 2, Fs = Qs + D + 1, FO = Fs + 3, NPL = (FO + WAVE - 1) / WAVE;
-  uint32_t tabv[NPL];
-  if constexpr (SUMS) {
-    static constexpr SumsTable<D> tab{};
+  const int nw4 = n4 * nin;  // <= 32 * 37
+  constexpr int NP4 = (32 * (16 + D) + WAVE - 1) / WAVE;
+  uint32_t* s_tab = reinterpret_cast<uint32_t*>(red);  // (the partial-product buffer is idle until the first matrix phase)
+  if (wv == 0) {
+    float pw4[NP4];
 #pragma unroll
-    for (int q = 0; q < NPL; ++q) tabv[q] = tab.e[lane + q * WAVE];
+    for (int q = 0; q < NP4; ++q) pw4[q] = q * WAVE < nw4 ? a.w4[lane + q * WAVE < nw4 ? lane + q * WAVE : 0] : 0.0f;
+    const float pb4 = a.b4[lane < n4 ? lane : 0], pwo = a.wo[lane < n4 ? lane : 0], pb3 = a.b3[lane < n3 ? lane : 0];
+    const float pbo = a.bo[0];
+    if constexpr (SUMS) {
+      static constexpr SumsTable<D> tab{};
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) s_tab[lane + q * WAVE] = tab.e[lane + q * WAVE];
+    }
+#pragma unroll
+    for (int q = 0; q < NP4; ++q)
+      if (lane + q * WAVE < nw4) s_w4[lane + q * WAVE] = pw4[q];
+    if (lane < n4) {
+      s_b4[lane] = pb4;
+      s_wo[lane] = pwo;
+    }
+    if (lane == 0) s_bo[0] = pbo;
+    if (lane < n3) s_b3[lane] = pb3;
   }
-  const int nw4 = n4 * nin;  // <= 32 * 48: at most two entries per thread
-  const float pw4a = a.w4[tid < nw4 ? tid : 0], pw4b = a.w4[tid + RM_BLOCK < nw4 ? tid + RM_BLOCK : 0];
-  const float pb4 = a.b4[tid < n4 ? tid : 0], pwo = a.wo[tid < n4 ? tid : 0], pb3 = a.b3[tid < n3 ? tid : 0];
-  const float pbo = a.bo[0];
   // LDS initialisation (independent of the loads): the padded k's of every activation row stay zero (a row's real entries
   // are rewritten per group; the rows of samples beyond B hold whatever LDS held -- row m of A only reaches row m of the
   // product); zero halos of the tiles (interiors are rewritten)
   float wreg[NSTEP];
   {
-    const int j = lane & (LPR - 1), nr = lane / LPR;
-    if (j < JW) {
+    if (w3j < J4) {
 #pragma unroll
-      for (int u = 0; u < NLD; ++u) *reinterpret_cast<float2*>(tin + (u * RPI + nr) * WS + 2 * j) = w3r[u];
+      for (int u = 0; u < NLD; ++u) {
+        float* dst = tin + (u * RPI + w3nr) * WS + 4 * w3j;  // (8-byte aligned: WS is even)
+        const rn_v4f_u v = w3r[u];
+        *reinterpret_cast<float2*>(dst) = w3_half ? make_float2(v[2], v[3]) : make_float2(v[0], v[1]);
+        *reinterpret_cast<float2*>(dst + 2) = make_float2(v[2], v[3]);
+      }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -767,14 +811,6 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
     __builtin_amdgcn_wave_barrier();
   }
   for (int k = lane; k < Gm::T1 + Gm::T2; k += WAVE) tin[k] = 0.0f;
-  if (tid < nw4) s_w4[tid] = pw4a;
-  if (tid + RM_BLOCK < nw4) s_w4[tid + RM_BLOCK] = pw4b;
-  if (tid < n4) {
-    s_b4[tid] = pb4;
-    s_wo[tid] = pwo;
-  }
-  if (tid == 0) s_bo[0] = pbo;
-  if (tid < n3) s_b3[tid] = pb3;
   float w1[NW1], w2[F2][K2 * K2];
 #pragma unroll
   for (int k = 0; k < NW1; ++k) w1[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), k));
@@ -789,6 +825,11 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
   for (int k = tid; k < RM_WAVES * (PITCH - KK); k += RM_BLOCK) acts[(k / (PITCH - KK)) * PITCH + KK + k % (PITCH - KK)] = 0.0f;
   RN_STAMP(1)
   __syncthreads();
+  uint32_t tabv[NPL];
+  if constexpr (SUMS) {
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) tabv[q] = s_tab[lane + q * WAVE];
+  }
   RN_STAMP(2)
   const float inv_keep = 1.0f / a.keep_prob;
   const bool drop = a.keep_prob < 1.0f;
@@ -924,22 +965,37 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
       if (lane < n3) x4 = h;
     }
     // 5. FC4 over [h3, state] + ReLU (+ dropout), 6. output unit
-    // (four units at a time: their products come from four LDS reads in flight together and their wave sums advance in
-    //  step -- one unit after the other the layer was four dependent ~250-cycle chains per sample)
-    float z = s_bo[0];
+    // Four units at a time.  Their products come from four unconditional LDS reads in flight together (lanes >= nin hold
+    // x4 = 0 and read the last weight; units >= n4 repeat unit n4 - 1 and are dropped below), their wave sums advance in
+    // step, and the rest of the layer is lane-parallel: lane u < 4 takes the sum, bias, dropout uniform and output weight
+    // of unit o0 + u, the four contributions to z are added across the quad.  (One unit after the other, with guarded
+    // reads, the layer was ~250 instructions in four dependent chains per sample -- with four waves per SIMD the phase is
+    // bound by instruction issue.)
+    float z = 0.0f;  // lanes 0..3: partial sums of z; the rest stays 0
+    const int lc = lane < nin ? lane : nin - 1;
     for (int o0 = 0; o0 < n4; o0 += 4) {
       float p4[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) p4[u] = (lane < nin && o0 + u < n4) ? x4 * s_w4[(o0 + u) * nin + lane] : 0.0f;
-      wave_sum4_f32_dpp(p4);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int o = o0 + u < n4 ? o0 + u : 0;
-        float h4 = fmaxf(p4[u] + s_b4[o], 0.0f);
-        if (drop) h4 = (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(u_drop), (32 + o) & 63)) <= a.keep_prob) ? h4 * inv_keep : 0.0f;
-        z = fmaf(h4, o0 + u < n4 ? s_wo[o] : 0.0f, z);
+      for (int u = 0; u < 4; ++u) p4[u] = x4 * s_w4[(o0 + u < n4 ? o0 + u : n4 - 1) * nin + lc];
+      wave_sum4_to_lane63(p4);
+      const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p4[0]), 63));
+      const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p4[1]), 63));
+      const float t2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p4[2]), 63));
+      const float t3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p4[3]), 63));
+      const int o = o0 + (lane & 3);
+      const bool mine = lane < 4 && o < n4;
+      const int oc = o < n4 ? o : n4 - 1;
+      const float tot = (lane & 2) ? ((lane & 1) ? t3 : t2) : ((lane & 1) ? t1 : t0);
+      float h4 = fmaxf(tot + s_b4[oc], 0.0f);
+      if (drop) {
+        const float uo = __shfl(u_drop, (32 + oc) & 63, WAVE);  // unit o's uniform was drawn by lane 32 + o
+        h4 = (uo <= a.keep_prob) ? h4 * inv_keep : 0.0f;
       }
+      z = mine ? fmaf(h4, s_wo[oc], z) : z;
     }
+    z += dpp_mov_f32<0xB1, 0xF>(z);  // quad_perm [1,0,3,2]
+    z += dpp_mov_f32<0x4E, 0xF>(z);  // quad_perm [2,3,0,1]: lanes 0..3 hold the sum
+    z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z))) + s_bo[0];
     const float rwd = tanhf(z);
     if (valid && lane == 0) a.reward[b] = rwd;
     RN_STAMP(9)
