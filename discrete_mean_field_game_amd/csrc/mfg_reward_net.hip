@@ -599,10 +599,10 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
 #define MFG_RN_MFMA 1
 #endif
 #ifndef MFG_RM_P21
-#define MFG_RM_P21 28  // tile pitch of the matrix-core kernel at d = 21: a conv read of a 32-lane group costs 2 LDS cycles
-#endif                 // instead of 3 at pitch 25 (banks (28 y + 7 r) mod 32; 116.5 -> 105.5 us at 65 536 samples)
+#define MFG_RM_P21 43  // tile pitch of the matrix-core kernel at d = 21: lane (strip r, row y) reads at y P + 7 r -- with
+#endif                 // P = 11 mod 32 the 32 lanes of a group hit 32 different banks (any other pitch below 53: 2 or 3 deep)
 #ifndef MFG_RM_P15
-#define MFG_RM_P15 19
+#define MFG_RM_P15 21
 #endif
 constexpr int RM_WAVES = 16, RM_BLOCK = RM_WAVES * WAVE, RM_RED = 260;  // RM_RED: floats per wave's partial (= 4 mod 64 x 4)
 typedef float rn_v4f_t __attribute__((ext_vector_type(4)));
@@ -647,22 +647,37 @@ constexpr bool rows_hit_distinct_even_banks(int stride) {  // 16 rows `stride` f
   return true;
 }
 
-template <int D, int RUN, int RPR, int P1, int P2>
-struct MfmaGeom : RunsGeom<D, RUN, RPR, P1, P2> {
-  using Base = RunsGeom<D, RUN, RPR, P1, P2>;
-  static constexpr int K = Base::F2 * Base::DD;             // FC3 inputs
+template <int D, int RUN, int RPR, int P1>
+struct MfmaGeom {
+  static_assert(RUN * RPR == D && D * RPR <= WAVE, "runs must tile a row exactly and fit one wavefront");
+  static constexpr int K1 = 5, K2 = 3, F2 = 2, H1 = 2, H2 = 1, DD = D * D;
+  static constexpr int PP = (DD + WAVE - 1) / WAVE;
+  static constexpr int K = F2 * DD;                         // FC3 inputs
   static constexpr int NSTEP = (K + 4 * RM_WAVES - 1) / (4 * RM_WAVES);  // matrix instructions per wave and group
   static constexpr int KW = 4 * NSTEP, KP = RM_WAVES * KW;  // k's per wave, padded K
   // ds_read_b32 is served in two 32-lane groups over 32 banks: the A-operand read of a group touches samples 0..15 at
   // k, k + 1 -> banks (s PITCH + {0, 1}) mod 32 must be 32 different ones: PITCH = 2 mod 32
   static constexpr int PITCH = ((KP - 2 + 31) / 32) * 32 + 2;
   static_assert(PITCH >= KP && (PITCH & 31) == 2, "activation rows: room for the padded K, conflict-free operand reads");
+  // the wave's tile: the D rows of the action with a zero halo of H1 columns on either side (no rows above or below: the
+  // vertical neighbours come from the neighbouring lanes), pitch P1; before the first group it is the scratch of the
+  // weight transposition (16 rows of KW + 2)
+  static_assert(P1 >= D + 2 * H1, "tile pitch");
+  static constexpr int T1 = D * P1, WS = KW + 2, TS = ((T1 > 16 * WS ? T1 : 16 * WS) + 3) & ~3;
   static size_t lds_floats(int n3, int n4, bool sums) {
     size_t fl = (size_t)(n4 * (n3 + D) + 2 * n4 + 1 + n3);
     fl = (fl + 3) & ~(size_t)3;
-    return fl + (size_t)RM_WAVES * (PITCH + RM_RED + Base::T1 + Base::T2) + (sums ? RM_WAVES * 32 : 0);
+    return fl + (size_t)RM_WAVES * (PITCH + RM_RED + TS) + (sums ? RM_WAVES * 32 : 0);
   }
 };
+
+// wave shifts by one lane (DPP wave_shr:1 / wave_shl:1): lane l takes the value of lane l - 1 / l + 1
+__device__ __forceinline__ float lane_below(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_above(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true));
+}
 
 // Developer build (-DMFG_RN_STAMPS, tools/rn_stamps.py): shader-clock stamps of the phases of blocks 0 and 100, every wave,
 // first group; read back with mfg_debug_rn_stamps.
@@ -675,9 +690,9 @@ __device__ unsigned long long rn_stamps[2 * RM_WAVES * 12];
 #define RN_STAMP(i)
 #endif
 
-template <int D, int RUN, int RPR, int P1, int P2, bool SUMS>
+template <int D, int RUN, int RPR, int P1, bool SUMS>
 __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
-  using Gm = MfmaGeom<D, RUN, RPR, P1, P2>;
+  using Gm = MfmaGeom<D, RUN, RPR, P1>;
   constexpr int K1 = Gm::K1, K2 = Gm::K2, F2 = Gm::F2, H1 = Gm::H1, H2 = Gm::H2, DD = Gm::DD, PP = Gm::PP;
   constexpr int KK = Gm::K, NSTEP = Gm::NSTEP, KW = Gm::KW, PITCH = Gm::PITCH;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -697,8 +712,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
   float* acts = smem + off;                          // [16 samples][PITCH]
   float* red = acts + RM_WAVES * PITCH;              // [16 k-slices][RM_RED]: register r of lane l at r*64 + l
   float* tiles = red + RM_WAVES * RM_RED;
-  float* tin = tiles + wv * (Gm::T1 + Gm::T2);
-  float* tc1 = tin + Gm::T1;
+  float* tin = tiles + wv * Gm::TS;
   // the first group's action is in flight under everything below
   const int64_t ngroups = (a.B + RM_WAVES - 1) / RM_WAVES;
   int64_t g = blockIdx.x;
@@ -734,8 +748,8 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
   // Rows >= n3 repeat row n3 - 1 (columns nobody reads); a piece that would pass the end of its row is fetched from the
   // row's last 16 bytes: its real entries (KK = 2 mod 4: two) are moved to the front, the padded k's behind them meet zero
   // activations -- any finite weight will do.
-  constexpr int J4 = KW / 4, LPR = J4 > 8 ? 16 : 8, RPI = WAVE / LPR, NLD = 16 / RPI, WS = KW + 2;
-  static_assert(J4 <= LPR && (KK & 3) == 2 && (KW & 3) == 0 && 16 * WS <= Gm::T1 + Gm::T2 && rows_hit_distinct_even_banks(WS),
+  constexpr int J4 = KW / 4, LPR = J4 > 8 ? 16 : 8, RPI = WAVE / LPR, NLD = 16 / RPI, WS = Gm::WS;
+  static_assert(J4 <= LPR && (KK & 3) == 2 && (KW & 3) == 0 && 16 * WS <= Gm::TS && rows_hit_distinct_even_banks(WS),
                 "weight scratch: fits the tile region; the operand read of a 32-lane group (16 rows x 2 k's) hits 32 banks");
   rn_v4f_u w3r[NLD];
   const int w3j = lane & (LPR - 1), w3nr = lane / LPR;
@@ -810,18 +824,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
   }
-  for (int k = lane; k < Gm::T1 + Gm::T2; k += WAVE) tin[k] = 0.0f;
-  float w1[NW1], w2[F2][K2 * K2];
-#pragma unroll
-  for (int k = 0; k < NW1; ++k) w1[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), k));
-  const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1));
-#pragma unroll
-  for (int c = 0; c < F2; ++c)
-#pragma unroll
-    for (int k = 0; k < K2 * K2; ++k)
-      w2[c][k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 1 + c * K2 * K2 + k));
-  const float b20 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 1 + NW2));
-  const float b21 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 2 + NW2));
+  for (int k = lane; k < Gm::TS; k += WAVE) tin[k] = 0.0f;
   for (int k = tid; k < RM_WAVES * (PITCH - KK); k += RM_BLOCK) acts[(k / (PITCH - KK)) * PITCH + KK + k % (PITCH - KK)] = 0.0f;
   RN_STAMP(1)
   __syncthreads();
@@ -833,11 +836,16 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
   RN_STAMP(2)
   const float inv_keep = 1.0f / a.keep_prob;
   const bool drop = a.keep_prob < 1.0f;
+  // Lane -> run: strip r = lane / D (columns r RUN ... + RUN - 1), row y = lane % D -- the rows of a strip sit in
+  // CONSECUTIVE lanes, so the rows above and below come from the neighbouring lanes with one DPP move per value (the
+  // lanes at the ends of a strip skip the taps that would reach outside the image: their neighbours belong to another
+  // strip).  Only the run's own row is read from LDS: 11 + 0 reads per sample instead of 55 + 27, and the conv1 map needs
+  // no tile at all (its side columns come from the strips left and right with two lane permutes).  The last lane(s) beyond
+  // RPR D compute on the last run's addresses and store nothing.
   const bool active = lane < D * RPR;
-  const int y = active ? lane / RPR : 0, x0 = active ? (lane - y * RPR) * RUN : 0;
-  const float* win1 = tin + y * P1 + x0;
-  float* out1 = tc1 + (y + H2) * P2 + x0 + H2;
-  const float* win2 = tc1 + y * P2 + x0;
+  const int la = active ? lane : D * RPR - 1;
+  const int rs = la / D, y = la - rs * D, x0 = rs * RUN;
+  const float* win1 = tin + y * P1 + x0;                // the run's row in the padded tile: columns x0 - H1 .. x0 + RUN - 1 + H1
   float2* act_out = reinterpret_cast<float2*>(acts + wv * PITCH + (y * D + x0) * F2);  // the run's 2 RUN inputs of FC3
   const float* act_in = acts + (lane & 15) * PITCH + wv * KW + (lane >> 4);             // A operand: sample lane % 16
   float* red_out = red + wv * RM_RED + lane;
@@ -848,9 +856,9 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
   for (int q = 0; q < PP; ++q) {
     const int p = lane + q * WAVE;
     const int pc = p < DD ? p : 0;
-    o1[q] = (pc / D + H1) * P1 + pc % D + H1;
+    o1[q] = (pc / D) * P1 + pc % D + H1;
   }
-  float* xs = tiles + RM_WAVES * (Gm::T1 + Gm::T2) + wv * 32;  // (only allocated for SUMS launches)
+  float* xs = tiles + RM_WAVES * Gm::TS + wv * 32;  // (only allocated for SUMS launches)
   double e_acc[NPL];
   if constexpr (SUMS) {
     // (the run-mapped kernel derives the entries with a search per lane: ~800 instructions per wave, as much as a sample's
@@ -882,46 +890,109 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    // 2. conv1 5x5 + ReLU over the run
+    // 2. conv1 5x5 + ReLU over the run: the run's own row from LDS, rows y -+ 1, y -+ 2 from the lanes below / above.
+    // The weights of a convolution are broadcast from `wtab` (lane t holds entry t of [c1w | c1b | c2w | c2b]) into scalar
+    // registers right before it -- all 46 of them held for the whole loop do not fit next to the kernel's pointers, and
+    // every spilled one costs a lane move per use (142 in the first version of this loop).
+    asm volatile("" : "+v"(wtab));  // (not loop invariant as far as the compiler knows: the broadcasts stay in the loop)
     float c1[RUN];
+    {
+      float w1[NW1];
 #pragma unroll
-    for (int k = 0; k < RUN; ++k) c1[k] = b1;
+      for (int k = 0; k < NW1; ++k) w1[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), k));
+      const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1));
+      constexpr int W = RUN + K1 - 1;
+      float x0r[W], xs_[W];
 #pragma unroll
-    for (int dy = 0; dy < K1; ++dy) {
-      float row[RUN + K1 - 1];
+      for (int t = 0; t < W; ++t) x0r[t] = win1[t];
 #pragma unroll
-      for (int t = 0; t < RUN + K1 - 1; ++t) row[t] = win1[dy * P1 + t];
+      for (int k = 0; k < RUN; ++k) c1[k] = b1;
 #pragma unroll
       for (int k = 0; k < RUN; ++k)
 #pragma unroll
-        for (int dx = 0; dx < K1; ++dx) c1[k] = fmaf(row[k + dx], w1[dy * K1 + dx], c1[k]);
-    }
-    if (active) {
+        for (int dx = 0; dx < K1; ++dx) c1[k] = fmaf(x0r[k + dx], w1[H1 * K1 + dx], c1[k]);
 #pragma unroll
-      for (int k = 0; k < RUN; ++k) out1[k] = fmaxf(c1[k], 0.0f);
+      for (int t = 0; t < W; ++t) xs_[t] = x0r[t];
+#pragma unroll
+      for (int e = 1; e <= H1; ++e) {  // rows y - e
+#pragma unroll
+        for (int t = 0; t < W; ++t) xs_[t] = lane_below(xs_[t]);
+        if (y >= e) {
+#pragma unroll
+          for (int k = 0; k < RUN; ++k)
+#pragma unroll
+            for (int dx = 0; dx < K1; ++dx) c1[k] = fmaf(xs_[k + dx], w1[(H1 - e) * K1 + dx], c1[k]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < W; ++t) xs_[t] = x0r[t];
+#pragma unroll
+      for (int e = 1; e <= H1; ++e) {  // rows y + e
+#pragma unroll
+        for (int t = 0; t < W; ++t) xs_[t] = lane_above(xs_[t]);
+        if (y + e < D) {
+#pragma unroll
+          for (int k = 0; k < RUN; ++k)
+#pragma unroll
+            for (int dx = 0; dx < K1; ++dx) c1[k] = fmaf(xs_[k + dx], w1[(H1 + e) * K1 + dx], c1[k]);
+        }
+      }
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
     RN_STAMP(4)
     // 3. conv2 3x3, two filters + ReLU -> row wv of the activation matrix (NHWC order: pixel * 2 + channel)
     float a2[RUN][F2];
+    {
+      static_assert(H2 == 1, "one column from either neighbouring strip");
+      constexpr int W = RUN + K2 - 1;
+      float w2[F2][K2 * K2];
 #pragma unroll
-    for (int k = 0; k < RUN; ++k) {
-      a2[k][0] = b20;
-      a2[k][1] = b21;
-    }
+      for (int c = 0; c < F2; ++c)
 #pragma unroll
-    for (int dy = 0; dy < K2; ++dy) {
-      float row[RUN + K2 - 1];
+        for (int k = 0; k < K2 * K2; ++k)
+          w2[c][k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 1 + c * K2 * K2 + k));
+      const float b20 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 1 + NW2));
+      const float b21 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 2 + NW2));
+      float m0[W], ms[W];
 #pragma unroll
-      for (int t = 0; t < RUN + K2 - 1; ++t) row[t] = win2[dy * P2 + t];
+      for (int k = 0; k < RUN; ++k) m0[k + 1] = fmaxf(c1[k], 0.0f);
+      // the columns left and right of the run: the last / first value of the same row in the neighbouring strips
+      const float lft = __shfl(m0[RUN], (lane - D) & (WAVE - 1), WAVE), rgt = __shfl(m0[1], (lane + D) & (WAVE - 1), WAVE);
+      m0[0] = rs > 0 ? lft : 0.0f;
+      m0[W - 1] = rs + 1 < RPR ? rgt : 0.0f;
+#pragma unroll
+      for (int k = 0; k < RUN; ++k) {
+        a2[k][0] = b20;
+        a2[k][1] = b21;
+      }
 #pragma unroll
       for (int k = 0; k < RUN; ++k)
 #pragma unroll
         for (int dx = 0; dx < K2; ++dx) {
-          a2[k][0] = fmaf(row[k + dx], w2[0][dy * K2 + dx], a2[k][0]);
-          a2[k][1] = fmaf(row[k + dx], w2[1][dy * K2 + dx], a2[k][1]);
+          a2[k][0] = fmaf(m0[k + dx], w2[0][H2 * K2 + dx], a2[k][0]);
+          a2[k][1] = fmaf(m0[k + dx], w2[1][H2 * K2 + dx], a2[k][1]);
         }
+#pragma unroll
+      for (int t = 0; t < W; ++t) ms[t] = lane_below(m0[t]);
+      if (y >= 1) {
+#pragma unroll
+        for (int k = 0; k < RUN; ++k)
+#pragma unroll
+          for (int dx = 0; dx < K2; ++dx) {
+            a2[k][0] = fmaf(ms[k + dx], w2[0][(H2 - 1) * K2 + dx], a2[k][0]);
+            a2[k][1] = fmaf(ms[k + dx], w2[1][(H2 - 1) * K2 + dx], a2[k][1]);
+          }
+      }
+#pragma unroll
+      for (int t = 0; t < W; ++t) ms[t] = lane_above(m0[t]);
+      if (y + 1 < D) {
+#pragma unroll
+        for (int k = 0; k < RUN; ++k)
+#pragma unroll
+          for (int dx = 0; dx < K2; ++dx) {
+            a2[k][0] = fmaf(ms[k + dx], w2[0][(H2 + 1) * K2 + dx], a2[k][0]);
+            a2[k][1] = fmaf(ms[k + dx], w2[1][(H2 + 1) * K2 + dx], a2[k][1]);
+          }
+      }
     }
     if (active) {
 #pragma unroll
@@ -1020,7 +1091,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
   }
   if constexpr (SUMS) {
     static_assert(D + 1 <= 32, "the per-wave line [state | 1] of the SUMS variant holds 32 floats");
-    static_assert(RM_WAVES * FO * 8 <= RM_WAVES * (Gm::T1 + Gm::T2) * 4, "the waves' partial rows reuse the tile region");
+    static_assert(RM_WAVES * FO * 8 <= RM_WAVES * Gm::TS * 4, "the waves' partial rows reuse the tile region");
     __syncthreads();
     double* rows = reinterpret_cast<double*>(tiles);
 #pragma unroll
@@ -1042,27 +1113,27 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
   RN_STAMP(11)
 }
 
-template <int D, int RUN, int RPR, int P1, int P2>
+template <int D, int RUN, int RPR, int P1>
 static int launch_reward_net_mfma(const RewardNetArgs& a, bool want_sums, int64_t max_rows, int* rows_out, hipStream_t st) {
-  using Gm = MfmaGeom<D, RUN, RPR, P1, P2>;
+  using Gm = MfmaGeom<D, RUN, RPR, P1>;
   int64_t grid = (a.B + RM_WAVES - 1) / RM_WAVES;
   if (grid > 256) grid = 256;  // one 16-wave block per CU (LDS: 154 KB at d = 21)
   const bool sums = want_sums && grid <= max_rows;
   const size_t lds = Gm::lds_floats(a.n3, a.n4, sums) * 4;
   static bool attr_set = false;  // (dynamic LDS above 64 KB)
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, P2, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, P2, false>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
     attr_set = true;
   }
   if (sums) {
-    hipLaunchKernelGGL((k_reward_net_mfma<D, RUN, RPR, P1, P2, true>), dim3((unsigned)grid), dim3(RM_BLOCK), lds, st, a);
+    hipLaunchKernelGGL((k_reward_net_mfma<D, RUN, RPR, P1, true>), dim3((unsigned)grid), dim3(RM_BLOCK), lds, st, a);
     *rows_out = (int)grid;
   } else {
-    hipLaunchKernelGGL((k_reward_net_mfma<D, RUN, RPR, P1, P2, false>), dim3((unsigned)grid), dim3(RM_BLOCK), lds, st, a);
+    hipLaunchKernelGGL((k_reward_net_mfma<D, RUN, RPR, P1, false>), dim3((unsigned)grid), dim3(RM_BLOCK), lds, st, a);
   }
   return 0;
 }
@@ -1128,8 +1199,8 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
   const bool mfma_ok = MFG_RN_MFMA && ref_geom && n3 <= 16 && (d == 21 || d == 15) && (((uintptr_t)fc3_w & 7) == 0);
   if (mfma_ok) {
     int rows = 0;
-    if (d == 21) launch_reward_net_mfma<21, 7, 3, MFG_RM_P21, MFG_RM_P21>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st);
-    else launch_reward_net_mfma<15, 5, 3, MFG_RM_P15, MFG_RM_P15>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st);
+    if (d == 21) launch_reward_net_mfma<21, 7, 3, MFG_RM_P21>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st);
+    else launch_reward_net_mfma<15, 5, 3, MFG_RM_P15>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st);
     if (rows_out) *rows_out = rows;
   } else
   if (runs_ok && d == 21) {

@@ -1,7 +1,7 @@
 """Phase stamps of the matrix-core reward-network kernel (developer tool).
 Build the instrumented library first:  bash tools/variant.sh rn_stamps mfg_reward_net.hip "-DMFG_RN_STAMPS"
 then on the GPU box:  MFG_HIP_LIB=.../variants/librn_stamps.so python tools/rn_stamps.py [B]
-Prints, for blocks 0 and 100 (first group), the shader-clock offsets of the phase boundaries of waves 0, 5, 15."""
+Prints, for blocks 0 and 100 (first group), the shader-clock offsets of the phase boundaries of waves 0 .. 15."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -24,4 +24,4 @@ for blk in range(2):
     t0 = t[blk, :, 0].min()
     print('block', (0, 100)[blk])
     for i, n in enumerate(names):
-        print('  %-22s' % n, '  '.join('w%-2d %6d' % (w, t[blk, w, i] - t0) for w in (0, 5, 15)))
+        print('  %-22s' % n, ' '.join('%6d' % (t[blk, w, i] - t0) for w in range(16)))
