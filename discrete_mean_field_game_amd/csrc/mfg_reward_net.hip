@@ -606,6 +606,7 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
 #endif
 constexpr int RM_WAVES = 16, RM_BLOCK = RM_WAVES * WAVE, RM_RED = 260;  // RM_RED: floats per wave's partial (= 4 mod 64 x 4)
 typedef float rn_v4f_t __attribute__((ext_vector_type(4)));
+typedef float rn_v2f_t __attribute__((ext_vector_type(2)));
 typedef float rn_v4f_u __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte global access at any 4-byte address
 
 // Entry k of the row [sum delta phi | sum delta g | sum r | count]: positions of its two factors in the line [state | 1]
@@ -667,10 +668,17 @@ struct MfmaGeom {
   static size_t lds_floats(int n3, int n4, bool sums) {
     size_t fl = (size_t)(n4 * (n3 + D) + 2 * n4 + 1 + n3);
     fl = (fl + 3) & ~(size_t)3;
-    return fl + (size_t)RM_WAVES * (PITCH + RM_RED + TS) + (sums ? RM_WAVES * 32 : 0);
+    return fl + (size_t)RM_WAVES * (PITCH + RM_RED + TS) + 2 * RM_WAVES * 16 + (sums ? RM_WAVES * 32 : 0);
   }
 };
 
+typedef const __attribute__((address_space(4))) float* RnConstF;  // read-only global memory: uniform reads are scalar loads
+// max(x, 0) in ONE instruction (fmaxf first quiets a signalling NaN with a v_max_f32 x, x, x of its own)
+__device__ __forceinline__ float relu_f32(float x) {
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 // wave shifts by one lane (DPP wave_shr:1 / wave_shl:1): lane l takes the value of lane l - 1 / l + 1
 __device__ __forceinline__ float lane_below(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
@@ -682,10 +690,10 @@ __device__ __forceinline__ float lane_above(float v) {
 // Developer build (-DMFG_RN_STAMPS, tools/rn_stamps.py): shader-clock stamps of the phases of blocks 0 and 100, every wave,
 // first group; read back with mfg_debug_rn_stamps.
 #ifdef MFG_RN_STAMPS
-__device__ unsigned long long rn_stamps[2 * RM_WAVES * 12];
+__device__ unsigned long long rn_stamps[2 * RM_WAVES * 16];
 #define RN_STAMP(i)                                                                                          \
   if ((blockIdx.x == 0 || blockIdx.x == 100) && lane == 0 && first_pass)                                     \
-    rn_stamps[((blockIdx.x ? 1 : 0) * RM_WAVES + wv) * 12 + (i)] = __builtin_readcyclecounter();
+    rn_stamps[((blockIdx.x ? 1 : 0) * RM_WAVES + wv) * 16 + (i)] = __builtin_readcyclecounter();
 #else
 #define RN_STAMP(i)
 #endif
@@ -767,15 +775,13 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
   // ALL global reads of the prologue are issued before the first use (one round trip: a launch of the per-step IRL update
   // has one sample per wave, so the prologue is on the critical path -- with the parameter copies, the conv-weight gather
   // and the SUMS table each waiting for their own loads it took 10 800 of the kernel's 31 000 cycles)
-  constexpr int NW1 = K1 * K1, NW2 = F2 * K2 * K2;
-  static_assert(NW1 + 1 + NW2 + F2 <= WAVE, "conv parameters must fit one wavefront");
-  float wtab;
+  constexpr int NW1 = K1 * K1;
+  // the conv weights are read through the scalar cache at the top of every pass: touch their cache lines now, under the
+  // other loads of the prologue (cold, the first pass waited ~2 000 cycles for them with nothing else to do)
   {
-    const float* src = lane < NW1 ? a.c1w + lane
-                     : lane == NW1 ? a.c1b
-                     : lane < NW1 + 1 + NW2 ? a.c2w + (lane - NW1 - 1)
-                     : a.c2b + (lane < NW1 + 1 + NW2 + F2 ? lane - NW1 - 1 - NW2 : 0);
-    wtab = *src;
+    RnConstF p1 = (RnConstF)a.c1w, p2 = (RnConstF)a.c2w, p3 = (RnConstF)a.c1b, p4 = (RnConstF)a.c2b;
+    const float warm = p1[0] + p1[15] + p1[NW1 - 1] + p2[0] + p2[F2 * K2 * K2 - 1] + p3[0] + p4[F2 - 1];
+    asm volatile("" ::"s"(warm));
   }
   // the small parameters and the SUMS table are the same for every wave: wave 0 fetches them, the others take them from LDS
   constexpr int Qs = D * (D + 1) / 2, Fs = Qs + D + 1, FO = Fs + 3, NPL = (FO + WAVE - 1) / WAVE;
@@ -858,7 +864,8 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
     const int pc = p < DD ? p : 0;
     o1[q] = (pc / D) * P1 + pc % D + H1;
   }
-  float* xs = tiles + RM_WAVES * Gm::TS + wv * 32;  // (only allocated for SUMS launches)
+  float* s_udrop = tiles + RM_WAVES * Gm::TS;  // [2][16 samples][16 slots]
+  float* xs = s_udrop + 2 * RM_WAVES * 16 + wv * 32;  // (only allocated for SUMS launches)
   double e_acc[NPL];
   if constexpr (SUMS) {
     // (the run-mapped kernel derives the entries with a search per lane: ~800 instructions per wave, as much as a sample's
@@ -867,40 +874,56 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
     for (int q = 0; q < NPL; ++q) e_acc[q] = 0.0;
     if (lane == 0) xs[D] = 1.0f;
   }
+  const bool shared_u = n3 + n4 <= 16;
+  int u_par = 0;
   RN_STAMP(3)
   for (; g < ngroups; g += gridDim.x) {  // (block-uniform trip count: the barriers below are taken by all 16 waves)
     b = g * RM_WAVES + wv;
     const bool valid = b < a.B;
+    // Lane predicates (lane < n3, y >= 1, ...) are formed where they are used, from copies of the lane's coordinates that
+    // the compiler cannot see through: hoisted out of the loop they are ~30 lane masks = 60 scalar registers that do not
+    // fit -- spilled to the lanes of a register they cost ~330 instructions of set-up on the critical path of a
+    // one-pass launch and ~60 lane moves per pass.
+    int ln = lane, yv = y, rv = rs;
+    asm volatile("" : "+v"(ln), "+v"(yv), "+v"(rv));
     // 1. action -> padded LDS tile; the next group's sample is fetched under this one's evaluation
 #pragma unroll
     for (int q = 0; q < PP; ++q)
-      if (lane + q * WAVE < DD) tin[o1[q]] = av[q];
+      if (ln + q * WAVE < DD) tin[o1[q]] = av[q];
     const float st_cur = st_mine;
     const double d0_cur = d0_next, g_cur = g_next;
-    if (SUMS && lane >= n3 && lane < nin) xs[lane - n3] = st_cur;
+    if (SUMS && ln >= n3 && ln < nin) xs[lane - n3] = st_cur;
     {
+      // (one uniform branch, unconditional loads from clamped addresses: pixels beyond DD are never written to the tile, the
+      //  state entry is masked where it is used)
       const int64_t bn = b + (int64_t)gridDim.x * RM_WAVES;
+      if (bn < a.B) {
+        const float* src = a.action + bn * DD;
 #pragma unroll
-      for (int q = 0; q < PP; ++q) av[q] = (bn < a.B && lane + q * WAVE < DD) ? a.action[bn * DD + lane + q * WAVE] : 0.0f;
-      if (bn < a.B && lane >= n3 && lane < nin) st_mine = a.state[bn * D + (lane - n3)];
-      if (SUMS && bn < a.B) {
-        d0_next = a.delta0[bn];
-        g_next = a.gsc[bn];
+        for (int q = 0; q < PP; ++q) av[q] = src[(q + 1) * WAVE <= DD ? lane + q * WAVE : (ln + q * WAVE < DD ? lane + q * WAVE : 0)];
+        st_mine = a.state[bn * D + (ln >= n3 && ln < nin ? lane - n3 : 0)];
+        if constexpr (SUMS) {
+          d0_next = a.delta0[bn];
+          g_next = a.gsc[bn];
+        }
       }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     // 2. conv1 5x5 + ReLU over the run: the run's own row from LDS, rows y -+ 1, y -+ 2 from the lanes below / above.
-    // The weights of a convolution are broadcast from `wtab` (lane t holds entry t of [c1w | c1b | c2w | c2b]) into scalar
-    // registers right before it -- all 46 of them held for the whole loop do not fit next to the kernel's pointers, and
-    // every spilled one costs a lane move per use (142 in the first version of this loop).
-    asm volatile("" : "+v"(wtab));  // (not loop invariant as far as the compiler knows: the broadcasts stay in the loop)
+    // The weights of a convolution come in through the scalar cache right before it (read-only memory, uniform addresses:
+    // scalar loads, no vector instruction) -- all 46 of them held for the whole loop do not fit next to the kernel's
+    // pointers, every spilled one costs a lane move per use (142 in the first version of this loop), and broadcasting them
+    // from a register costs a v_readlane each (53 per sample).
+    RnConstF c1w_s = (RnConstF)a.c1w, c1b_s = (RnConstF)a.c1b, c2w_s = (RnConstF)a.c2w, c2b_s = (RnConstF)a.c2b;
+    asm volatile("" : "+s"(c1w_s), "+s"(c1b_s), "+s"(c2w_s), "+s"(c2b_s));  // (the loads stay in the loop)
+    RN_STAMP(12)
     float c1[RUN];
     {
       float w1[NW1];
 #pragma unroll
-      for (int k = 0; k < NW1; ++k) w1[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), k));
-      const float b1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1));
+      for (int k = 0; k < NW1; ++k) w1[k] = c1w_s[k];
+      const float b1 = c1b_s[0];
       constexpr int W = RUN + K1 - 1;
       float x0r[W], xs_[W];
 #pragma unroll
@@ -911,26 +934,28 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
       for (int k = 0; k < RUN; ++k)
 #pragma unroll
         for (int dx = 0; dx < K1; ++dx) c1[k] = fmaf(x0r[k + dx], w1[H1 * K1 + dx], c1[k]);
+      RN_STAMP(13)
 #pragma unroll
       for (int t = 0; t < W; ++t) xs_[t] = x0r[t];
 #pragma unroll
       for (int e = 1; e <= H1; ++e) {  // rows y - e
 #pragma unroll
         for (int t = 0; t < W; ++t) xs_[t] = lane_below(xs_[t]);
-        if (y >= e) {
+        if (yv >= e) {
 #pragma unroll
           for (int k = 0; k < RUN; ++k)
 #pragma unroll
             for (int dx = 0; dx < K1; ++dx) c1[k] = fmaf(xs_[k + dx], w1[(H1 - e) * K1 + dx], c1[k]);
         }
       }
+      RN_STAMP(14)
 #pragma unroll
       for (int t = 0; t < W; ++t) xs_[t] = x0r[t];
 #pragma unroll
       for (int e = 1; e <= H1; ++e) {  // rows y + e
 #pragma unroll
         for (int t = 0; t < W; ++t) xs_[t] = lane_above(xs_[t]);
-        if (y + e < D) {
+        if (yv + e < D) {
 #pragma unroll
           for (int k = 0; k < RUN; ++k)
 #pragma unroll
@@ -940,68 +965,69 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
     }
     RN_STAMP(4)
     // 3. conv2 3x3, two filters + ReLU -> row wv of the activation matrix (NHWC order: pixel * 2 + channel)
-    float a2[RUN][F2];
+    // (the two filters of a pixel advance together in one packed FMA: same input, weight pair (filter 0, filter 1))
+    rn_v2f_t a2[RUN];
     {
-      static_assert(H2 == 1, "one column from either neighbouring strip");
+      static_assert(H2 == 1 && F2 == 2, "one column from either neighbouring strip; two filters per packed instruction");
       constexpr int W = RUN + K2 - 1;
-      float w2[F2][K2 * K2];
+      rn_v2f_t w2[K2 * K2];
 #pragma unroll
-      for (int c = 0; c < F2; ++c)
-#pragma unroll
-        for (int k = 0; k < K2 * K2; ++k)
-          w2[c][k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 1 + c * K2 * K2 + k));
-      const float b20 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 1 + NW2));
-      const float b21 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wtab), NW1 + 2 + NW2));
+      for (int k = 0; k < K2 * K2; ++k) w2[k] = rn_v2f_t{c2w_s[k], c2w_s[K2 * K2 + k]};
+      const rn_v2f_t b2 = {c2b_s[0], c2b_s[1]};
       float m0[W], ms[W];
 #pragma unroll
-      for (int k = 0; k < RUN; ++k) m0[k + 1] = fmaxf(c1[k], 0.0f);
+      for (int k = 0; k < RUN; ++k) m0[k + 1] = relu_f32(c1[k]);
       // the columns left and right of the run: the last / first value of the same row in the neighbouring strips
       const float lft = __shfl(m0[RUN], (lane - D) & (WAVE - 1), WAVE), rgt = __shfl(m0[1], (lane + D) & (WAVE - 1), WAVE);
-      m0[0] = rs > 0 ? lft : 0.0f;
-      m0[W - 1] = rs + 1 < RPR ? rgt : 0.0f;
+      m0[0] = rv > 0 ? lft : 0.0f;
+      m0[W - 1] = rv + 1 < RPR ? rgt : 0.0f;
 #pragma unroll
-      for (int k = 0; k < RUN; ++k) {
-        a2[k][0] = b20;
-        a2[k][1] = b21;
-      }
+      for (int k = 0; k < RUN; ++k) a2[k] = b2;
 #pragma unroll
       for (int k = 0; k < RUN; ++k)
 #pragma unroll
-        for (int dx = 0; dx < K2; ++dx) {
-          a2[k][0] = fmaf(m0[k + dx], w2[0][H2 * K2 + dx], a2[k][0]);
-          a2[k][1] = fmaf(m0[k + dx], w2[1][H2 * K2 + dx], a2[k][1]);
-        }
+        for (int dx = 0; dx < K2; ++dx) a2[k] = __builtin_elementwise_fma(rn_v2f_t{m0[k + dx], m0[k + dx]}, w2[H2 * K2 + dx], a2[k]);
 #pragma unroll
       for (int t = 0; t < W; ++t) ms[t] = lane_below(m0[t]);
-      if (y >= 1) {
+      if (yv >= 1) {
 #pragma unroll
         for (int k = 0; k < RUN; ++k)
 #pragma unroll
-          for (int dx = 0; dx < K2; ++dx) {
-            a2[k][0] = fmaf(ms[k + dx], w2[0][(H2 - 1) * K2 + dx], a2[k][0]);
-            a2[k][1] = fmaf(ms[k + dx], w2[1][(H2 - 1) * K2 + dx], a2[k][1]);
-          }
+          for (int dx = 0; dx < K2; ++dx)
+            a2[k] = __builtin_elementwise_fma(rn_v2f_t{ms[k + dx], ms[k + dx]}, w2[(H2 - 1) * K2 + dx], a2[k]);
       }
 #pragma unroll
       for (int t = 0; t < W; ++t) ms[t] = lane_above(m0[t]);
-      if (y + 1 < D) {
+      if (yv + 1 < D) {
 #pragma unroll
         for (int k = 0; k < RUN; ++k)
 #pragma unroll
-          for (int dx = 0; dx < K2; ++dx) {
-            a2[k][0] = fmaf(ms[k + dx], w2[0][(H2 + 1) * K2 + dx], a2[k][0]);
-            a2[k][1] = fmaf(ms[k + dx], w2[1][(H2 + 1) * K2 + dx], a2[k][1]);
-          }
+          for (int dx = 0; dx < K2; ++dx)
+            a2[k] = __builtin_elementwise_fma(rn_v2f_t{ms[k + dx], ms[k + dx]}, w2[(H2 + 1) * K2 + dx], a2[k]);
       }
     }
-    if (active) {
+    if (ln < D * RPR) {
 #pragma unroll
-      for (int k = 0; k < RUN; ++k) act_out[k] = make_float2(fmaxf(a2[k][0], 0.0f), fmaxf(a2[k][1], 0.0f));
+      for (int k = 0; k < RUN; ++k) act_out[k] = make_float2(relu_f32(a2[k][0]), relu_f32(a2[k][1]));
     }
+    // Dropout uniforms (unit o of FC3 / FC4 of sample n <- Philox4x32-10 with counter (o, 3 | 4, sample_offset + n, 0)): a
+    // Philox block per lane costs ~100 instructions per wave whatever the number of lanes that need one, and a sample needs
+    // n3 + n4 of them.  With n3 + n4 <= 16 the waves 0..3 (one per SIMD) draw for four samples each -- lane = (sample,
+    // slot), slot < n3: FC3 unit, then the FC4 units -- and leave them in LDS (two buffers, by group parity: a wave may be a
+    // whole pass ahead of the slowest reader); otherwise every wave draws for its own sample (lane o < 32: FC3 unit o, lane
+    // 32 + o: FC4 unit o).
     float u_drop = 0.0f;
-    if (drop) {
-      const u32x4 r = philox_elem(a.seed, (uint32_t)(lane & 31), lane < 32 ? 3u : 4u, a.sample_offset + (uint64_t)b, 0);
-      u_drop = u01(r.x);
+    float* s_u = s_udrop + u_par * (RM_WAVES * 16);
+    u_par ^= 1;
+    if (drop && (!shared_u || wv < 4)) {
+      const int slot = ln & 15, smp = 4 * wv + (ln >> 4);
+      const bool fc3 = shared_u ? slot < n3 : ln < 32;
+      const uint32_t elem = shared_u ? (uint32_t)(fc3 ? slot : slot - n3) : (uint32_t)(lane & 31);
+      const uint64_t traj = a.sample_offset + (uint64_t)(shared_u ? g * RM_WAVES + smp : b);
+      uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+      asm volatile("" : "+s"(k0), "+s"(k1));  // (the ten round keys are formed here, not held in 20 scalar registers across the loop)
+      u_drop = u01(philox_elem(((uint64_t)k1 << 32) | k0, elem, fc3 ? 3u : 4u, traj, 0).x);
+      if (shared_u) s_u[smp * 16 + slot] = u_drop;
     }
     RN_STAMP(5)
     __syncthreads();  // the 16 activation rows are complete
@@ -1029,11 +1055,14 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
       h3 = __uint_as_float(r5[0]) + __uint_as_float(r5[1]);  // lane bit 5
     }
     // ReLU (+ dropout); lane o < n3 keeps unit o, lanes n3 .. n3+D-1 hold the state: `x4` is FC4's input
-    float x4 = (lane >= n3 && lane < nin) ? st_cur : 0.0f;
+    float x4 = (ln >= n3 && ln < nin) ? st_cur : 0.0f;
     {
-      float h = fmaxf(h3 + s_b3[lane < n3 ? lane : 0], 0.0f);
-      if (drop) h = (u_drop <= a.keep_prob) ? h * inv_keep : 0.0f;  // lane o < 32 drew unit o of FC3
-      if (lane < n3) x4 = h;
+      float h = fmaxf(h3 + s_b3[ln < n3 ? ln : 0], 0.0f);
+      if (drop) {
+        const float uo = shared_u ? s_u[wv * 16 + (lane & 15)] : u_drop;  // (own draw: lane o < 32 drew unit o of FC3)
+        h = (uo <= a.keep_prob) ? h * inv_keep : 0.0f;
+      }
+      if (ln < n3) x4 = h;
     }
     // 5. FC4 over [h3, state] + ReLU (+ dropout), 6. output unit
     // Four units at a time.  Their products come from four unconditional LDS reads in flight together (lanes >= nin hold
@@ -1043,7 +1072,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
     // reads, the layer was ~250 instructions in four dependent chains per sample -- with four waves per SIMD the phase is
     // bound by instruction issue.)
     float z = 0.0f;  // lanes 0..3: partial sums of z; the rest stays 0
-    const int lc = lane < nin ? lane : nin - 1;
+    const int lc = ln < nin ? ln : nin - 1;
     for (int o0 = 0; o0 < n4; o0 += 4) {
       float p4[4];
 #pragma unroll
@@ -1053,13 +1082,14 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
       const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p4[1]), 63));
       const float t2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p4[2]), 63));
       const float t3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p4[3]), 63));
-      const int o = o0 + (lane & 3);
-      const bool mine = lane < 4 && o < n4;
+      const int o = o0 + (ln & 3);
+      const bool mine = ln < 4 && o < n4;
       const int oc = o < n4 ? o : n4 - 1;
-      const float tot = (lane & 2) ? ((lane & 1) ? t3 : t2) : ((lane & 1) ? t1 : t0);
+      const float tot = (ln & 2) ? ((ln & 1) ? t3 : t2) : ((ln & 1) ? t1 : t0);
       float h4 = fmaxf(tot + s_b4[oc], 0.0f);
       if (drop) {
-        const float uo = __shfl(u_drop, (32 + oc) & 63, WAVE);  // unit o's uniform was drawn by lane 32 + o
+        // (own draw: unit o's uniform was drawn by lane 32 + o)
+        const float uo = shared_u ? s_u[wv * 16 + ((n3 + oc) & 15)] : __shfl(u_drop, (32 + oc) & 63, WAVE);
         h4 = (uo <= a.keep_prob) ? h4 * inv_keep : 0.0f;
       }
       z = mine ? fmaf(h4, s_wo[oc], z) : z;
@@ -1068,18 +1098,19 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
     z += dpp_mov_f32<0x4E, 0xF>(z);  // quad_perm [2,3,0,1]: lanes 0..3 hold the sum
     z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(z))) + s_bo[0];
     const float rwd = tanhf(z);
-    if (valid && lane == 0) a.reward[b] = rwd;
+    if (valid && ln == 0) a.reward[b] = rwd;
     RN_STAMP(9)
     if constexpr (SUMS) {
       if (valid) {
         const double rr = (double)rwd, de = d0_cur + rr;  // delta = r + discount V(pi') - V(pi)   (ac_irl.py:691)
-        if (lane == 0) a.delta_out[b] = de;
+        if (ln == 0) a.delta_out[b] = de;
         const double dgc = de * g_cur;
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
           const int cm = (int)(tabv[q] >> 16) - 1;
           const double x = (double)xs[tabv[q] & 0xFFu] * (double)xs[(tabv[q] >> 8) & 0xFFu];
-          const double coef = cm == 0 ? de : (cm == 1 ? dgc : (cm == 2 ? rr : (cm == 3 ? 1.0 : 0.0)));
+          // (entries below Fs all carry delta: known per q at compile time, no selects)
+          const double coef = (q + 1) * WAVE <= Fs ? de : (cm == 0 ? de : (cm == 1 ? dgc : (cm == 2 ? rr : (cm == 3 ? 1.0 : 0.0))));
           e_acc[q] = fma(coef, x, e_acc[q]);
         }
       }
@@ -1117,7 +1148,7 @@ template <int D, int RUN, int RPR, int P1>
 static int launch_reward_net_mfma(const RewardNetArgs& a, bool want_sums, int64_t max_rows, int* rows_out, hipStream_t st) {
   using Gm = MfmaGeom<D, RUN, RPR, P1>;
   int64_t grid = (a.B + RM_WAVES - 1) / RM_WAVES;
-  if (grid > 256) grid = 256;  // one 16-wave block per CU (LDS: 154 KB at d = 21)
+  if (grid > 256) grid = 256;  // one 16-wave block per CU (LDS: 137 KB at d = 21)
   const bool sums = want_sums && grid <= max_rows;
   const size_t lds = Gm::lds_floats(a.n3, a.n4, sums) * 4;
   static bool attr_set = false;  // (dynamic LDS above 64 KB)

@@ -15,11 +15,11 @@ ac = AC_IRL(theta=8.64, shift=0.0, alpha_scale=1e4, d=21, pi0=mat, demonstration
 ac.train(max_episodes=3, stop_criteria=-1)
 torch.cuda.synchronize()
 lib = C.CDLL(os.environ['MFG_HIP_LIB'])
-buf = (C.c_ulonglong * (2 * 16 * 12))()
+buf = (C.c_ulonglong * (2 * 16 * 16))()
 assert lib.mfg_debug_rn_stamps(buf) == 0
-t = np.array(buf, dtype=np.uint64).reshape(2, 16, 12).astype(np.int64)
+t = np.array(buf, dtype=np.uint64).reshape(2, 16, 16).astype(np.int64)
 names = ['entry', 'prologue issued', 'barrier 0 passed', 'setup done', 'conv1 done', 'conv2 + acts done', 'barrier a passed',
-         'mfma + partials done', 'barrier b passed', 'reward stored', 'sums folded', 'kernel end']
+         'mfma + partials done', 'barrier b passed', 'reward stored', 'sums folded', 'kernel end', 'c1: tile written', 'c1: centre row done', 'c1: rows above done', '-']
 for blk in range(2):
     t0 = t[blk, :, 0].min()
     print('block', (0, 100)[blk])
