@@ -317,6 +317,30 @@ def test_reward_net_hip_group_edges(dev, d, B):
     assert np.max(np.abs(out - ref)) < 5e-6
 
 
+def test_reward_net_hip_weights_at_odd_addresses(dev):
+    """The matrix-core kernel fetches the FC3 weights in 16-byte pieces from rows that start at multiples of 8 bytes; a
+    weight buffer that is only 4-byte aligned takes the other kernels -- same results."""
+    from discrete_mean_field_game_amd import ops
+    from discrete_mean_field_game_amd.networks import RewardNet
+    from oracle import reward_net_oracle as RO
+    torch.manual_seed(3)
+    d, B = 21, 100
+    net = RewardNet(d=d, reg='none').to(dev).eval()
+    rs = np.random.RandomState(2)
+    state = rs.dirichlet(np.ones(d), size=B).astype(np.float32)
+    action = rs.dirichlet(np.ones(d), size=(B, d)).astype(np.float32)
+    s_t, a_t = torch.as_tensor(state, device=dev), torch.as_tensor(action, device=dev)
+    ref = RO.forward(RO.params_from_torch(net), state.astype(np.float64), action.astype(np.float64))[:, 0]
+    out0 = ops.reward_net_forward(net, s_t, a_t).cpu().numpy()
+    w = net.fc3.weight.data
+    buf = torch.empty(w.numel() + 1, dtype=w.dtype, device=dev)
+    buf[1:].copy_(w.reshape(-1))
+    net.fc3.weight.data = buf[1:].view_as(w)                         # contiguous, 4 bytes past a 16-byte boundary
+    assert net.fc3.weight.data_ptr() % 8 == 4 and net.fc3.weight.is_contiguous()
+    out1 = ops.reward_net_forward(net, s_t, a_t).cpu().numpy()
+    assert np.max(np.abs(out0 - ref)) < 2e-6 and np.max(np.abs(out1 - ref)) < 2e-6
+
+
 def test_reward_net_hip_dropout_statistics(dev):
     """Dropout (keep 0.4, inverted scaling) stays on when the net is the RL reward, like the reference
     (tf.contrib.layers.dropout defaults to is_training=True): masks differ per call and per sample, and the
