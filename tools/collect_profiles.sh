@@ -22,7 +22,7 @@ print('value %.4g env-steps/s, %.4f ms/step; given-P %.0f GB/s frac %.3f (%.1f u
 for c in d['configs']:
     print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in c.items() if k in ('config', 'fused_ms_per_rollout', 'fused_env_steps_per_s', 'given_P_frac', 'env_steps_per_s')})
 PY
-for f in shards valu_rates mfma_f64_rate mfma_valu_overlap cycle_table_d21 cycle_table_d128 cycle_table_d256 irl_step_mode_trace perf_train_4096 perf_train_65536 irl_step_probe_4096; do
+for f in shards valu_rates mfma_f64_rate mfma_valu_overlap cycle_table_d21 cycle_table_d128 cycle_table_d256 irl_step_mode_trace perf_train_4096 perf_train_65536 irl_step_probe_4096 rn_probe rn_stamps_4096 pmc_sq_reward_net_65536; do
   [ -f $O/$f.txt ] && cp $O/$f.txt profiles/${P}_$f.txt
 done
 python3 - <<PY

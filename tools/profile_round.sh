@@ -38,6 +38,13 @@ bash $R/tools/trace_gaps.sh $R/tools/irl_mode_probe.py 4096 > $O/irl_step_mode_t
 python3 $R/tools/perf_train.py 4096 > $O/perf_train_4096.txt 2>&1
 python3 $R/tools/perf_train.py 65536 > $O/perf_train_65536.txt 2>&1
 python3 $R/tools/irl_step_probe.py 4096 > $O/irl_step_probe_4096.txt 2>&1
+# round 4: the matrix-core reward-network kernel: event-timed launches, phase stamps (instrumented variant library, if built:
+# bash tools/variant.sh rn_stamps mfg_reward_net.hip "-DMFG_RN_STAMPS"), SQ counters at 65 536 samples
+python3 $R/tools/rn_probe.py 4096 65536 > $O/rn_probe.txt 2>&1
+V=$R/discrete_mean_field_game_amd/csrc/variants/librn_stamps.so
+[ -f $V ] && MFG_HIP_LIB=$V python3 $R/tools/rn_stamps.py 4096 > $O/rn_stamps_4096.txt 2>&1
+bash $R/tools/pmc_sq.sh k_reward_net_mfma $R/tools/rn_probe.py 65536 > $O/pmc_sq_reward_net_65536.txt 2>&1
+cd /tmp
 # round 4: the multi-rank update cycle on a 1-rank RCCL communicator (bench.py --force-dist: per-episode loop, deferred update,
 # ONE all-reduce per update) at the 8-GPU shard and the full batch, with the measured latency of the exchange step
 for BB in 8192 65536; do
