@@ -58,9 +58,12 @@ struct CoreArgs {
 #ifdef MFG_TIMING
 #define MFG_STAMP(k) if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0 && s < 4) a.dbg[s * 16 + (k)] = __builtin_amdgcn_s_memtime();
 #define MFG_STAMP0(k) if (a.dbg && blockIdx.x == 0 && threadIdx.x == 0) a.dbg[(k)] = __builtin_amdgcn_s_memtime();  // slots 8..15 of row 0
+// every block's entry / exit time (wave 0), from slot 64 on: how the blocks of a launch spread over its duration
+#define MFG_STAMPB(k) if (a.dbg && threadIdx.x == 0) a.dbg[64 + 2 * blockIdx.x + (k)] = __builtin_amdgcn_s_memtime();
 #else
 #define MFG_STAMP(k)
 #define MFG_STAMP0(k)
+#define MFG_STAMPB(k)
 #endif
 
 int set_error(int code, const char* msg);  // records mfg_last_error() (defined in mfg_kernels.hip)
@@ -367,6 +370,7 @@ template <bool SAMPLE, bool TD, bool FAST, int D, bool SUMS = false>
 __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MFG_CORE_SMALL_WAVES_F64)) void k_core_small(CoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   MFG_STAMP0(8)
+  MFG_STAMPB(0)
   const int d = D ? D : a.d;
   const int dd = d * d, dp = d | 1, T = a.T;
   const int G = WAVE / d, TB = WAVES * G;
@@ -968,6 +972,7 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
       }
     }
     MFG_STAMP0(11)
+    MFG_STAMPB(1)
   }
 }
 

@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/mfg_hip.h"
 #include "mfg_core.h"
 
@@ -584,16 +586,20 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
 // multiply-adds).  Across SAMPLES the layer is a GEMM  H[16 samples x n3] = ACT[16 x 2d^2] . W3^T[2d^2 x n3]  -- but a
 // wave that owns 16 samples would run their convolutions one after the other (no good at B = 4 096, where every wave
 // has ONE sample).  So the block is 16 waves = 16 samples and the GEMM is split along K:
-//   phase 1  wave s evaluates the convolutions of sample s (run-mapped, as above) and leaves the 2 d^2 activations of its
-//            sample as row s of an LDS matrix (pitch = 2 mod 32: the operand reads of a 32-lane group touch 32 distinct banks);
+//   phase 1  wave s evaluates the convolutions of sample s -- lane = (strip of RUN columns, row), the rows of a strip in
+//            consecutive lanes: a lane reads its own row from the LDS tile and takes the rows above / below from the
+//            neighbouring lanes (DPP wave shifts), the side columns of the conv1 map from the neighbouring strips (lane
+//            permutes) -- and leaves the 2 d^2 activations of its sample as row s of an LDS matrix (pitch = 2 mod 32: the
+//            operand reads of a 32-lane group touch 32 distinct banks);
 //   phase 2  wave w owns the k-slice [w KW, (w+1) KW) of ALL 16 samples: NSTEP = KW / 4 v_mfma_f32_16x16x4_f32 with
 //            A = activations (one ds_read_b32 per step) and B = ITS slice of the FC3 weights, which it fetched ONCE at
 //            kernel start and keeps in NSTEP registers -- the weights are neither staged in LDS nor re-read from L2 per
 //            sample (the run-mapped kernel reads all 28 KB per sample: 115 MB of L2 traffic per 4 096-sample launch);
 //            the 16 x 16 partial product (4 registers) goes to LDS;
 //   phase 3  wave s adds the 16 partials of its sample (4 LDS reads + two lane swaps, a fixed order), and finishes
-//            FC3's ReLU / dropout, FC4, the output unit (and the SUMS fold) like the run-mapped kernel.
-// Two block barriers per 16 samples.  fp32 multiply-add on the matrix cores (no reduced precision).  n3 <= 16.
+//            FC3's ReLU / dropout, FC4 (four units at a time), the output unit (and the SUMS fold).
+// Two block barriers per 16 samples.  fp32 multiply-add on the matrix cores (no reduced precision; on gfx950 the same rate as
+// the vector unit: what is saved is the LDS traffic and the per-unit reductions).  n3 <= 16, FC3 weights 8-byte aligned.
 // ---------------------------------------------------------------------------------------------
 #ifndef MFG_RN_MFMA
 #define MFG_RN_MFMA 1
@@ -776,13 +782,6 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
   // has one sample per wave, so the prologue is on the critical path -- with the parameter copies, the conv-weight gather
   // and the SUMS table each waiting for their own loads it took 10 800 of the kernel's 31 000 cycles)
   constexpr int NW1 = K1 * K1;
-  // the conv weights are read through the scalar cache at the top of every pass: touch their cache lines now, under the
-  // other loads of the prologue (cold, the first pass waited ~2 000 cycles for them with nothing else to do)
-  {
-    RnConstF p1 = (RnConstF)a.c1w, p2 = (RnConstF)a.c2w, p3 = (RnConstF)a.c1b, p4 = (RnConstF)a.c2b;
-    const float warm = p1[0] + p1[15] + p1[NW1 - 1] + p2[0] + p2[F2 * K2 * K2 - 1] + p3[0] + p4[F2 - 1];
-    asm volatile("" ::"s"(warm));
-  }
   // the small parameters and the SUMS table are the same for every wave: wave 0 fetches them, the others take them from LDS
   constexpr int Qs = D * (D + 1) / 2, Fs = Qs + D + 1, FO = Fs + 3, NPL = (FO + WAVE - 1) / WAVE;
   const int nw4 = n4 * nin;  // <= 32 * 37
@@ -1151,15 +1150,14 @@ static int launch_reward_net_mfma(const RewardNetArgs& a, bool want_sums, int64_
   if (grid > 256) grid = 256;  // one 16-wave block per CU (LDS: 137 KB at d = 21)
   const bool sums = want_sums && grid <= max_rows;
   const size_t lds = Gm::lds_floats(a.n3, a.n4, sums) * 4;
-  static bool attr_set = false;  // (dynamic LDS above 64 KB)
-  if (!attr_set) {
+  static std::once_flag attr_once;  // (dynamic LDS above 64 KB; one GPU per process)
+  std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
-    attr_set = true;
-  }
+  });
   if (sums) {
     hipLaunchKernelGGL((k_reward_net_mfma<D, RUN, RPR, P1, true>), dim3((unsigned)grid), dim3(RM_BLOCK), lds, st, a);
     *rows_out = (int)grid;
