@@ -778,9 +778,9 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
       else w3r[u] = w3r[0];
     }
   }
-  // ALL global reads of the prologue are issued before the first use (one round trip: a launch of the per-step IRL update
-  // has one sample per wave, so the prologue is on the critical path -- with the parameter copies, the conv-weight gather
-  // and the SUMS table each waiting for their own loads it took 10 800 of the kernel's 31 000 cycles)
+  // (All global reads of the prologue are issued before the first use of any: a launch of the per-step IRL update has one
+  //  sample per wave, so the prologue is on the critical path -- with the parameter copies, a conv-weight gather and the SUMS
+  //  table each waiting for their own loads it took 10 800 of the kernel's 31 000 cycles.)
   constexpr int NW1 = K1 * K1;
   // the small parameters and the SUMS table are the same for every wave: wave 0 fetches them, the others take them from LDS
   constexpr int Qs = D * (D + 1) / 2, Fs = Qs + D + 1, FO = Fs + 3, NPL = (FO + WAVE - 1) / WAVE;
@@ -808,9 +808,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
     if (lane == 0) s_bo[0] = pbo;
     if (lane < n3) s_b3[lane] = pb3;
   }
-  // LDS initialisation (independent of the loads): the padded k's of every activation row stay zero (a row's real entries
-  // are rewritten per group; the rows of samples beyond B hold whatever LDS held -- row m of A only reaches row m of the
-  // product); zero halos of the tiles (interiors are rewritten)
+  // the weight pieces -> scratch rows [unit][KW + 2] in the wave's tile region -> NSTEP operand registers (wave-local)
   float wreg[NSTEP];
   {
     if (w3j < J4) {
@@ -829,6 +827,9 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
   }
+  // LDS initialisation: zero halos of the tile (interiors are rewritten per group); the padded k's of every activation row
+  // stay zero (a row's real entries are rewritten per group; the rows of samples beyond B hold whatever LDS held -- row m of
+  // A only reaches row m of the product)
   for (int k = lane; k < Gm::TS; k += WAVE) tin[k] = 0.0f;
   for (int k = tid; k < RM_WAVES * (PITCH - KK); k += RM_BLOCK) acts[(k / (PITCH - KK)) * PITCH + KK + k % (PITCH - KK)] = 0.0f;
   RN_STAMP(1)
