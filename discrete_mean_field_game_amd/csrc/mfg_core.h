@@ -1490,7 +1490,10 @@ inline int core_grid(int64_t work_items, int per_block, int blocks_per_cu, int n
   return (int)g;
 }
 
-template <bool FAST>
+// RSEL selects the instantiations a translation unit carries: 0 all R, 1 only R = 2 and 4 (d = 128 / 256: the C3 and C5
+// shapes -- built with LLVM's iterative ILP scheduler, which gains 1.8 % at d = 256 and crashes the register allocator on
+// another R), 2 all the others.
+template <bool FAST, int RSEL = 0>
 inline int launch_core_large_impl(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st) {
   const int d = a.d;
   const int R = (d + WAVE - 1) / WAVE;
@@ -1502,20 +1505,25 @@ inline int launch_core_large_impl(const CoreArgs& a, bool sample, bool td, int n
   if (sample && td) { if (full) MFG_CORE_LARGE_GO(RR, true, true, true); else MFG_CORE_LARGE_GO(RR, true, true, false); }   \
   else if (sample) { if (full) MFG_CORE_LARGE_GO(RR, true, false, true); else MFG_CORE_LARGE_GO(RR, true, false, false); }  \
   else MFG_CORE_LARGE_GO(RR, false, true, false);
-  const bool full = (d == R * WAVE);
-  switch (R) {
-    case 2: MFG_CORE_LARGE_MODE(2) break;
-    case 3: MFG_CORE_LARGE_MODE(3) break;
-    case 4: MFG_CORE_LARGE_MODE(4) break;
-    case 5: MFG_CORE_LARGE_MODE(5) break;
-    case 6: MFG_CORE_LARGE_MODE(6) break;
-    case 7: MFG_CORE_LARGE_MODE(7) break;
-    case 8: MFG_CORE_LARGE_MODE(8) break;
-    default: return MFG_EUNSUPPORTED;
+#define MFG_CORE_LARGE_CASE(RR)                                                              \
+  if constexpr (RSEL == 0 || (RSEL == 1) == ((RR) == 2 || (RR) == 4)) {                      \
+    if (R == (RR)) {                                                                         \
+      MFG_CORE_LARGE_MODE(RR)                                                                \
+      return MFG_OK;                                                                         \
+    }                                                                                        \
   }
+  const bool full = (d == R * WAVE);
+  MFG_CORE_LARGE_CASE(2)
+  MFG_CORE_LARGE_CASE(3)
+  MFG_CORE_LARGE_CASE(4)
+  MFG_CORE_LARGE_CASE(5)
+  MFG_CORE_LARGE_CASE(6)
+  MFG_CORE_LARGE_CASE(7)
+  MFG_CORE_LARGE_CASE(8)
+#undef MFG_CORE_LARGE_CASE
 #undef MFG_CORE_LARGE_GO
 #undef MFG_CORE_LARGE_MODE
-  return MFG_OK;
+  return MFG_EUNSUPPORTED;
 }
 
 }  // namespace mfg

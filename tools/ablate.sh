@@ -10,7 +10,8 @@ if [ "$1" = build ]; then
     ( ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -Wno-pass-failed -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp -DMFG_ABL_$a -c -o $V/abl_$a.o $C/mfg_core_small.hip 2>/dev/null ||
         /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -Wno-pass-failed -fno-slp-vectorize -DMFG_ABL_$a -c -o $V/abl_$a.o $C/mfg_core_small.hip ) &&
       /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -Wno-pass-failed -fno-slp-vectorize -DMFG_ABL_$a -c -o $V/abll_$a.o $C/mfg_core_large_mixed.hip &&
-      /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $V/libabl_$a.so $C/mfg_kernels.o $V/abl_$a.o $C/mfg_core_large_f64.o $V/abll_$a.o $C/mfg_reward_net.o ) &
+      /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -Wno-pass-failed -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp -DMFG_ABL_$a -c -o $V/ablli_$a.o $C/mfg_core_large_mixed_ilp.hip &&
+      /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $V/libabl_$a.so $C/mfg_kernels.o $V/abl_$a.o $C/mfg_core_large_f64.o $V/abll_$a.o $V/ablli_$a.o $C/mfg_reward_net.o ) &
     if (( $(jobs -r | wc -l) >= 5 )); then wait -n; fi
   done
   wait
