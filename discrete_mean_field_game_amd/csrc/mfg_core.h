@@ -330,6 +330,55 @@ __device__ __forceinline__ void sample_elems(const CoreArgs& a, double theta, co
   }
 }
 
+// The ONE trailing element of a row whose length is 1 mod 4 (d = 21): its Philox block feeds a Box-Muller PAIR and the
+// element needs one normal.  The pair is keyed by the EVEN step (step & ~1): the even step takes the cosine normal and the
+// first acceptance integer -- exactly what sample_elems<1> draws -- and leaves the sine normal and the second integer in
+// (cxn, ckf) for the odd step that follows, which then skips the block, the field extraction and the radius / angle
+// (~65 of the ~140 instructions of this element, every second step).  A launch that STARTS on an odd step has nothing
+// carried and recomputes the even step's block: the trajectories do not depend on how a rollout is cut into launches.
+// The element's own continuation draws (exact acceptance, small shapes) are keyed by its id and the real step as before.
+template <bool TD, bool FAST, bool SEP>
+__device__ __forceinline__ void sample_tail1(const CoreArgs& a, double theta, const ThetaSplit& ts, float pj, float ej, float pai,
+                                             float Fi, uint32_t elem, uint32_t step, uint64_t traj, bool& have, float& cxn,
+                                             float& ckf, float& y, typename PolicyTerms<FAST>::T& al,
+                                             typename PolicyTerms<FAST>::T& ad, typename PolicyTerms<FAST>::T& gt) {
+  PolicyElem<FAST> pe;
+  if constexpr (SEP) policy_setup_sep<true, TD>(pe, a, ts, pj, ej, pai, Fi);
+  else policy_setup<true, TD, FAST>(pe, a, theta, ts, pj, pai);
+  const bool odd = (step & 1u) != 0;  // (wave-uniform)
+  float xn, kf;
+  if (odd && have) {
+    xn = cxn;
+    kf = ckf;
+    have = false;
+  } else {
+    QuadRand q;
+    quad_rand(q, a.seed, elem, step & ~1u, traj);
+    const float rad = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(q.radu[0]));
+    const float xc = rad * __builtin_amdgcn_cosf(q.ang[0]), xs = rad * __builtin_amdgcn_sinf(q.ang[0]);
+    xn = odd ? xs : xc;
+    kf = odd ? q.kf[1] : q.kf[0];
+    cxn = xs;
+    ckf = q.kf[1];
+    have = !odd;
+  }
+  static_assert(quad_kbits(0) == 16 && quad_kbits(1) == 16, "both integers of the first pair are 16-bit");
+  uint64_t cm;
+  float v = gamma_try_mask<16>(pe.gs, xn, kf, cm);
+  y = pe.gs.dd * v;
+  if (__builtin_expect(cm != 0, 0)) {
+    bool sure = true;
+    (void)gamma_try<16>(pe.gs, xn, kf, sure);
+    if (!sure || pe.gs.small) y = gamma_fix(pe.gs, xn, kf, TryConst<16>::kscale, sure, v, a.seed, elem, step, traj);
+  }
+  if (TD) {
+    const PolicyTerms<FAST> t = policy_terms<true, FAST>(pe, a.htab, ts.th, y);
+    al = t.al;
+    ad = t.ad;
+    gt = t.gt;
+  }
+}
+
 // V(pi) = phi(pi).w, one wavefront per trajectory, lanes own columns c, rows i <= c.  For fixed i the
 // weights w[k(i,c)] are contiguous in c, so the loads are coalesced (w is L2 resident).
 __device__ __forceinline__ double value_wave(const float* pis, const double* __restrict__ w, int d, int lane) {
@@ -512,6 +561,9 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
     // (V of the start state: evaluated inside step 0 next to V of the next state -- as a prologue it cost three barriers,
     //  two LDS round trips and a serial sum BEFORE any sampling could start: 3 500 of the 20 000 cycles of a T = 1 launch.
     //  GIVEN mode evaluates it inside its single step as before.)
+    // (the Box-Muller partner of the row's trailing element, carried from an even step to the odd one behind it: sample_tail1)
+    bool tail_have = false;
+    float tail_xn = 0.0f, tail_kf = 0.0f;
     MFG_STAMP0(10)
     for (int s = 0; s < T; ++s) {
       MFG_STAMP(0)
@@ -623,8 +675,8 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
             TT as = 0, ds = 0, gs = 0;
             const int rem = d - dq;
             if (rem == 1)
-              sample_elems<1, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pas, Fi, erow + (uint32_t)dq, step, traj, y,
-                                             ys, as, ds, gs);
+              sample_tail1<TD, FAST, sep>(a, theta, ts, pav[dq], ev[dq], pas, Fi, erow + (uint32_t)dq, step, traj, tail_have, tail_xn,
+                                          tail_kf, y[0], as, ds, gs), ys = y[0];
             else if (rem == 2)
               sample_elems<2, TD, FAST, sep>(a, theta, ts, pav + dq, ev + dq, pas, Fi, erow + (uint32_t)dq, step, traj, y,
                                              ys, as, ds, gs);

@@ -457,6 +457,38 @@ def test_step_given_P_misaligned_pointers(dev, d, B, off):
     np.testing.assert_allclose(got_pi.cpu().numpy(), ref_pi, rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize('precision', ['mixed', 'f64'])
+@pytest.mark.parametrize('first_step', [0, 1, 6, 7])
+@pytest.mark.parametrize('d,B', [(21, 300), (5, 257), (15, 260), (9, 64)])
+def test_rollout_does_not_depend_on_how_it_is_cut_into_launches(dev, d, B, first_step, precision):
+    """A T-step sampled rollout equals the chain of T one-step launches fed forward (first_step + s), bit for bit, from even
+    AND odd first steps.  Rows of length 1 mod 4 (d = 21, 5, 9) draw their trailing element from a Box-Muller pair keyed by
+    the EVEN step and carry its partner to the odd step behind it (sample_tail1): a launch that starts on an odd step has
+    nothing carried and must recompute the pair."""
+    o_ = ops()
+    rs = np.random.RandomState(d + B + first_step)
+    pi = t32(rs.dirichlet(np.ones(d), size=B), dev)
+    th = t64([8.64], dev)
+    T = 5
+    whole = o_.rollout(pi, T, th, 0.16, 12000.0, seed=11, first_step=first_step, traj_offset=5, td=False, write_P=True,
+                       precision=precision)
+    Pw = whole['P'].view(B, T, d, d)
+    cur = pi
+    for s in range(T):
+        one = o_.rollout(cur, 1, th, 0.16, 12000.0, seed=11, first_step=first_step + s, traj_offset=5, td=False, write_P=True,
+                         precision=precision)
+        assert torch.equal(one['P'].view(B, d, d), Pw[:, s]), (s, first_step)
+        cur = one['pi_last'].contiguous()
+    assert torch.equal(cur, whole['pi_last'])
+    # ... and a cut in the middle, at an odd and at an even step
+    for cut in (2, 3):
+        a1 = o_.rollout(pi, cut, th, 0.16, 12000.0, seed=11, first_step=first_step, traj_offset=5, td=False, write_P=True,
+                        precision=precision)
+        a2 = o_.rollout(a1['pi_last'].contiguous(), T - cut, th, 0.16, 12000.0, seed=11, first_step=first_step + cut,
+                        traj_offset=5, td=False, write_P=True, precision=precision)
+        assert torch.equal(a1['P'].view(B, cut, d, d), Pw[:, :cut]) and torch.equal(a2['P'].view(B, T - cut, d, d), Pw[:, cut:])
+
+
 @pytest.mark.parametrize('d,B', [(21, 100), (15, 64), (47, 9), (100, 5), (4, 33)])
 @pytest.mark.parametrize('precision,gtol', [('f64', 1e-9), ('mixed', 1e-5)])
 def test_external_reward_step_equals_two_pass_step(dev, d, B, precision, gtol):
