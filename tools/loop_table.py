@@ -92,7 +92,7 @@ def main():
     print('besides, per quad: %d scalar / branch instructions (loop control, the exact-path masks), %d LDS instructions (4 reads, 2 writes), %d h-table loads'
           % (sum(v for k, v in hist.items() if k.startswith('s_')), sum(v for k, v in hist.items() if k.startswith('ds_')),
              sum(v for k, v in hist.items() if k.startswith('global_'))))
-    print('per matrix row of d = 21: 5 quads = %d VALU instructions here, + the trailing single element (its own Philox block, ~80), + the per-row and'
+    print('per matrix row of d = 21: 5 quads = %d VALU instructions here, + the trailing single element (~140 instructions on even steps, ~75 on odd ones: its Box-Muller pair is keyed by the even step, the partner normal carried -- sample_tail1), + the per-row and'
           ' per-step pieces of the ablation table (E / F staging 22 per row, epilogue, column pass, sums, value).' % (5 * nv))
     print('round 3 (same method, listing of commit 33c6160): 273 VALU per quad.')
 
