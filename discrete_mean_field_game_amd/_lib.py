@@ -18,6 +18,7 @@ REWARD_MFG_AC2, REWARD_SYNTHETIC, REWARD_EXTERNAL = 0, 1, 2
 ROLLOUT_WRITE_P, ROLLOUT_TD, ROLLOUT_DISCOUNT_POW, ROLLOUT_F64, TRAIN_APPLY = 1, 2, 4, 8, 16
 PRECISION_F64, PRECISION_MIXED = 0, 1
 STATUS_MIXED_RANGE = 1
+RN_TRAIN_MAX_TRAJ = 64          # MFG_RN_TRAIN_MAX_TRAJ
 PRECISIONS = {'f64': PRECISION_F64, 'mixed': PRECISION_MIXED, 0: 0, 1: 1}
 
 
@@ -86,6 +87,13 @@ SIGNATURES = {
     'mfg_backward_value': (_i32, [_p, _i64, _i32, _i32, _p, _p, _p, _p]),
     'mfg_reward_net_forward': (_i32, [_p, _p, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                      _p, C.c_float, _u64, _u64, _p, _p]),
+    'mfg_reward_net_num_params': (_i64, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    'mfg_reward_net_param_offsets': (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, C.POINTER(C.c_int64)]),
+    'mfg_reward_net_train_workspace_bytes': (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i64]),
+    'mfg_reward_net_train_step': (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p, C.POINTER(C.c_int32), _i32, _p, _p,
+                                        C.POINTER(C.c_int32), _i32, _i32, _i32, C.c_float, _i32, _u64, _f64, _f64, _f64, _f64, _i64,
+                                        _i32, _p, _p, _p, _sz, _p]),
+    'mfg_reward_net_adam': (_i32, [_p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _i64, _p]),
 }
 
 

@@ -28,6 +28,7 @@ from . import ops
 from .mfg_ac2 import EPISODE_STEPS, actor_critic
 from .networks import RewardNet, maxent_irl_loss
 from .parallel import all_reduce_gradients_, all_reduce_mean_flat_, broadcast_seed, current_shard, lr_scales
+from .reward_learning import RewardTrainer, TrajectoryStore
 
 
 class AC_IRL(actor_critic):
@@ -54,6 +55,14 @@ class AC_IRL(actor_critic):
         else:
             self.mat_pi0_test = self.mat_pi0.copy()
         self.num_start_samples_test = self.mat_pi0_test.shape[0]
+        # device-resident demonstrations / D_samp (reward_learning.TrajectoryStore); the list attributes below are views
+        self._demo_store = TrajectoryStore(d, EPISODE_STEPS, self.device)
+        self._gen_store = TrajectoryStore(d, EPISODE_STEPS, self.device)
+        self._demo_list = []
+        self._eval_demo_override = None
+        self._eval_gen_override = None
+        self._trainer = None
+        self._stats_host = None
         if demonstrations is not None:
             self.list_demonstrations = demonstrations
         elif os.path.isdir('./actions_2') and os.path.isdir('./train_normalized_round2'):
@@ -66,8 +75,7 @@ class AC_IRL(actor_critic):
             self.list_demonstrations_test = self.read_demonstrations('./test_normalized_round2', './actions_test_2', 20, 22)
         else:
             self.list_demonstrations_test = []
-        self.list_eval_demo_transitions = [pair for traj in self.list_demonstrations for pair in traj]
-        self.list_generated = []                         # D_samp of the IRL algorithm (ac_irl.py:79)
+        # list_eval_demo_transitions (ac_irl.py:77) / list_generated = D_samp (:79): properties over the stores, see below
         self.num_demo_samples = 5
         self.num_gen_samples = 5
         self.num_sampled_trajectories = self.num_gen_samples
@@ -75,6 +83,7 @@ class AC_IRL(actor_critic):
         self.reward_update_count = 0
         self._reward_calls = 0                           # number of reward() calls so far (dropout-mask counter)
         self._reward_sample_offset = 0                   # global index of the first sample of the next reward() call
+        self._reward_train_calls = 0                     # update_reward calls so far (dropout-mask key of the training batches)
         self.reward_net = None
         if use_tf:
             self.create_network()
@@ -112,12 +121,84 @@ class AC_IRL(actor_critic):
         """One (s,a) per trajectory: index = trajectory index mod 15 (ac_irl.py:203-219)."""
         return [traj[idx % 15] for idx, traj in enumerate(list_trajectories)]
 
+    # ------------------------------------------------------------------ list views of the device stores
+    @property
+    def list_demonstrations(self):
+        """Expert trajectories (ac_irl.py:69).  Assigning a list uploads it once to the device store."""
+        return self._demo_list
+
+    @list_demonstrations.setter
+    def list_demonstrations(self, trajs):
+        self._demo_list = trajs
+        self._demo_store.assign_list(trajs)
+        self._eval_demo_override = None
+
+    @property
+    def list_generated(self):
+        """D_samp (ac_irl.py:79, :927-932) as the reference's list[n] of list[15] of (pi, P): built from the device store when
+        read (cached until D_samp changes).  Assign a whole list to replace D_samp; in-place edits of the returned list are
+        not seen by the device store."""
+        return self._gen_store.to_list()
+
+    @list_generated.setter
+    def list_generated(self, trajs):
+        if trajs is not self._gen_store._list or trajs is None:
+            self._gen_store.assign_list(trajs if trajs is not None else [])
+            self._gen_store._list = trajs if trajs else None       # keep the caller's objects as the list view
+        self._eval_gen_override = None
+
+    def _is_all_pairs(self, pairs, store, trajs):
+        """True if `pairs` is the flattened view [pair for traj in trajs for pair in traj] of the store's current list."""
+        n = len(store) * store.steps
+        return (trajs is not None and len(pairs) == n and (n == 0 or (pairs[0] is trajs[0][0] and pairs[-1] is trajs[-1][-1])))
+
+    @property
+    def list_eval_demo_transitions(self):
+        if self._eval_demo_override is not None:
+            return self._eval_demo_override
+        return [pair for traj in self._demo_list for pair in traj]
+
+    @list_eval_demo_transitions.setter
+    def list_eval_demo_transitions(self, pairs):
+        self._eval_demo_override = None if self._is_all_pairs(pairs, self._demo_store, self._demo_list) else pairs
+
+    @property
+    def list_eval_gen_transitions(self):
+        if self._eval_gen_override is not None:
+            return self._eval_gen_override
+        return [pair for traj in self.list_generated for pair in traj]
+
+    @list_eval_gen_transitions.setter
+    def list_eval_gen_transitions(self, pairs):
+        self._eval_gen_override = None if self._is_all_pairs(pairs, self._gen_store, self._gen_store._list) else pairs
+
+    # loss / first / second term of the last update_reward (ac_irl.py:846): left on the device by the training kernel, read
+    # (one 16-byte copy) only when somebody looks at them
+    def _stat(self, k):
+        if self._stats_host is None:
+            self._stats_host = self._trainer.stats.cpu().numpy().astype(np.float64) if self._trainer is not None else np.zeros(4)
+        return float(self._stats_host[k])
+
+    def _set_stat(self, k, value):
+        if self._stats_host is None:
+            self._stats_host = np.zeros(4)
+        self._stats_host[k] = float(value)
+
+    loss_val = property(lambda self: self._stat(0), lambda self, v: self._set_stat(0, v))
+    first_term_val = property(lambda self: self._stat(1), lambda self, v: self._set_stat(1, v))
+    second_term_val = property(lambda self: self._stat(2), lambda self, v: self._set_stat(2, v))
+
     # ------------------------------------------------------------------ reward network (ac_irl.py:232-267, :382-427)
     def create_network(self):
         self.reward_net = RewardNet(d=self.d, reg=self.reg, f1=1, k1=5, f2=2, k2=3, n_fc3=self.n_fc3,
                                     n_fc4=self.n_fc4).to(self.device)
 
     def create_training_method(self):
+        """Loss + Adam of ac_irl.py:382-418.  On the GPU (network inside the HIP kernels' range) the whole update is
+        mfg_reward_net_train_step on flat parameter / moment buffers (reward_learning.RewardTrainer); `self.optimizer`
+        (torch Adam) serves only shapes outside that range."""
+        if ops.reward_net_supported(self.reward_net):
+            self._trainer = RewardTrainer(self.reward_net, self.lr_reward)
         self.optimizer = torch.optim.Adam(self.reward_net.parameters(), lr=self.lr_reward)
 
     def _pairs_to_tensors(self, pairs):
@@ -331,16 +412,23 @@ class AC_IRL(actor_critic):
                     pi, _r = ops.step_given_P(pi, P, want_reward=False)
                 out.append(traj)
             return out
-        # start states drawn on the device like train()'s (mfg_draw_start keyed by seed / step / trajectory id): every rank of
-        # a multi-GPU job generates the identical D_samp without sharing a host RNG stream
+        pis, Ps = self._generate_device(n, mat_dev)
+        pis = pis.cpu().numpy().astype(np.float64)
+        Ps = Ps.cpu().numpy().astype(np.float64)
+        return [[(pis[b, t], Ps[b, t]) for t in range(T)] for b in range(n)]
+
+    def _generate_device(self, n, mat_dev=None):
+        """generate_trajectories without the host copy: (pi_traj [n,16,d], P [n,15,d,d]) device tensors straight from
+        mfg_rollout(WRITE_P).  Start states drawn on the device like train()'s (mfg_draw_start keyed by seed / step /
+        trajectory id): every rank of a multi-GPU job generates the identical D_samp without sharing a host RNG stream."""
+        mat_dev = self._mat_pi0_dev if mat_dev is None else mat_dev
+        T = EPISODE_STEPS
         off = self._gen_offset(n)
         _, pi0 = ops.draw_start(mat_dev, n, self.seed, self._rng_step, off)
         r = ops.rollout(pi0, T, self._theta, self.shift, self.alpha_scale, seed=self.seed, first_step=self._rng_step,
                         traj_offset=off, td=False, write_P=True, precision=self.precision)
         self._rng_step += T
-        pis = r['pi_traj'].cpu().numpy().astype(np.float64)
-        Ps = r['P'].cpu().numpy().astype(np.float64)
-        return [[(pis[b, t], Ps[b, t]) for t in range(T)] for b in range(n)]
+        return r['pi_traj'], r['P']
 
     def _gen_offset(self, n):
         off = getattr(self, '_gen_traj_counter', 1 << 40)       # disjoint from the training trajectory ids
@@ -353,8 +441,11 @@ class AC_IRL(actor_critic):
         outer loop (the reference only saves the TF reward net, ac_irl.py:948)."""
         st = super().state_dict()
         ver, internal, gauss = random.getstate()
-        gen_pi = [[np.asarray(p[0], dtype=np.float64) for p in traj] for traj in self.list_generated]
-        gen_P = [[np.asarray(p[1], dtype=np.float64) for p in traj] for traj in self.list_generated]
+        if len(self._gen_store):
+            gs, ga = self._gen_store.gather()
+            gen_pi, gen_P = gs.cpu().double(), ga.cpu().double()
+        else:
+            gen_pi = gen_P = None
         st.update({'reward_net': self.reward_net.state_dict(), 'optimizer': self.optimizer.state_dict(),
                    'list_policies': [float(np.ravel(t)[0]) for t in self.list_policies],
                    'theta_initial': float(np.ravel(self.theta_initial)[0]),
@@ -362,8 +453,10 @@ class AC_IRL(actor_critic):
                    'reward_calls': int(self._reward_calls),
                    'gen_traj_counter': int(getattr(self, '_gen_traj_counter', 1 << 40)),
                    # D_samp (ac_irl.py:79, :927-932) as two tensors [M,15,d], [M,15,d,d]
-                   'list_generated_pi': torch.as_tensor(np.array(gen_pi)) if gen_pi else torch.zeros(0),
-                   'list_generated_P': torch.as_tensor(np.array(gen_P)) if gen_P else torch.zeros(0),
+                   'list_generated_pi': gen_pi if gen_pi is not None else torch.zeros(0),
+                   'list_generated_P': gen_P if gen_P is not None else torch.zeros(0),
+                   'reward_trainer': self._trainer.state_dict() if self._trainer is not None else {},
+                   'reward_train_calls': int(self._reward_train_calls),
                    # host RNG streams a resumed run consumes: Python `random` (update_reward's random.sample) and
                    # torch's CPU / device generators (dropout in the training-mode reward net)
                    'py_random_version': int(ver), 'py_random_state': torch.tensor(internal, dtype=torch.int64),
@@ -381,12 +474,15 @@ class AC_IRL(actor_critic):
         self._gen_traj_counter = int(state['gen_traj_counter'])
         self.theta_initial = state.get('theta_initial', self.theta_initial)
         self._reward_calls = int(state.get('reward_calls', 0))
-        if 'list_generated_pi' in state and state['list_generated_pi'].numel():
-            gp, gP = state['list_generated_pi'].numpy(), state['list_generated_P'].numpy()
-            self.list_generated = [[(gp[m, t], gP[m, t]) for t in range(gp.shape[1])] for m in range(gp.shape[0])]
-        elif 'list_generated_pi' in state:
-            self.list_generated = []
-        self.list_eval_gen_transitions = [pair for traj in self.list_generated for pair in traj]   # as outerloop keeps it (:934)
+        if self._trainer is not None and state.get('reward_trainer'):
+            self._trainer.load_state_dict(state['reward_trainer'])
+        self._reward_train_calls = int(state.get('reward_train_calls', 0))
+        self._stats_host = None
+        if 'list_generated_pi' in state:
+            self._gen_store.clear()
+            if state['list_generated_pi'].numel():
+                self._gen_store.push(state['list_generated_pi'], state['list_generated_P'])
+            self._eval_gen_override = None                       # all of D_samp, as outerloop keeps it (:934)
         if restore_np_random and 'py_random_state' in state:
             random.setstate((int(state['py_random_version']), tuple(int(v) for v in state['py_random_state']),
                              state['py_random_gauss']))
@@ -419,21 +515,45 @@ class AC_IRL(actor_critic):
 
     # ------------------------------------------------------------------ reward learning (ac_irl.py:804-897)
     def update_reward(self, summary=False, iteration=0):
-        if len(self.list_demonstrations) >= self.num_demo_samples:
-            demo_sampled = random.sample(self.list_demonstrations, self.num_demo_samples)
+        """One gradient step on the reward network (ac_irl.py:804-846).  The batch is drawn with the reference's
+        `random.sample` calls -- on INDEX ranges: random.sample(population, k) picks positions from len(population) alone, so
+        the same trajectories are chosen and the host stream advances identically -- and the update itself is
+        mfg_reward_net_train_step on the device stores: two launches, nothing copied, no synchronisation."""
+        nd_all, ng_all = len(self._demo_store), len(self._gen_store)
+        if nd_all >= self.num_demo_samples:
+            demo_idx = random.sample(range(nd_all), self.num_demo_samples)
         else:
-            demo_sampled = self.list_demonstrations[:]
-        if len(self.list_generated) >= self.num_gen_samples:
-            gen_sampled = random.sample(self.list_generated, self.num_gen_samples)
+            demo_idx = list(range(nd_all))
+        if ng_all >= self.num_gen_samples:
+            gen_idx = random.sample(range(ng_all), self.num_gen_samples)
         else:
-            gen_sampled = self.list_generated[:]
-        ds, da = self._pairs_to_tensors([pair for traj in demo_sampled for pair in traj])
-        gs, ga = self._pairs_to_tensors([pair for traj in gen_sampled for pair in traj])
+            gen_idx = list(range(ng_all))
+        self._reward_train_calls += 1
+        if self._trainer is not None and len(demo_idx) <= L.RN_TRAIN_MAX_TRAJ and len(gen_idx) <= L.RN_TRAIN_MAX_TRAJ:
+            key = ((self.seed + 0x7EA1) ^ (self._reward_train_calls * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+            dist = torch.distributed
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+            self._trainer.step(self._demo_store, [self._demo_store.rows[i] for i in demo_idx], self._gen_store,
+                               [self._gen_store.rows[i] for i in gen_idx], self.num_demo_samples, key, grad_only=multi)
+            if multi:
+                # replicated reward network (SURVEY.md 8e): ONE all-reduce of the flat gradient, averaged; the ranks train on
+                # identical batches (_sync_host_sampler), so this only keeps them in lock-step
+                all_reduce_mean_flat_([self._trainer.grad], self.group)
+                self._trainer.apply_grad()
+            self._stats_host = None
+            return
+        self._update_reward_torch(demo_idx, gen_idx)
+
+    def _update_reward_torch(self, demo_idx, gen_idx):
+        """update_reward through PyTorch autograd: only for reward networks outside the range of the HIP kernels (d > 32, ...)."""
+        demos, gens = self._demo_list, self.list_generated
+        ds, da = self._pairs_to_tensors([pair for i in demo_idx for pair in demos[i]])
+        gs, ga = self._pairs_to_tensors([pair for i in gen_idx for pair in gens[i]])
         self.reward_net.train()
         r_demo = self.reward_net(ds, da)
         r_gen = self.reward_net(gs, ga)
         reg = self.reward_net.regularization() if self.reward_net.use_l1l2 else None
-        loss, first, second = maxent_irl_loss(r_demo, r_gen, self.num_demo_samples, len(gen_sampled), reg)
+        loss, first, second = maxent_irl_loss(r_demo, r_gen, self.num_demo_samples, len(gen_idx), reg)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self._all_reduce_reward_grads()
@@ -460,6 +580,27 @@ class AC_IRL(actor_critic):
         random.seed(s)
         torch.manual_seed(s)
 
+    def _eval_transitions(self, override, store):
+        """(states [N,d], actions [N,d,d]) device tensors of an evaluation set: the whole store unless the caller assigned
+        its own list of pairs (e.g. get_eval_transitions)."""
+        if override is not None:
+            return self._pairs_to_tensors(override)
+        st, ac = store.gather()
+        return st.reshape(-1, self.d), ac.reshape(-1, self.d, self.d)
+
+    def _eval_reward_averages(self):
+        """Mean reward over the demonstration / generated evaluation transitions (ac_irl.py:868-883): two forward launches
+        and ONE host read for both numbers."""
+        ds, da = self._eval_transitions(self._eval_demo_override, self._demo_store)
+        gs, ga = self._eval_transitions(self._eval_gen_override, self._gen_store)
+        self._reward_sample_offset = 0
+        with torch.no_grad():
+            rd = self.reward(ds, da) if ds.shape[0] else torch.zeros(1, device=self.device)
+            rg = self.reward(gs, ga) if gs.shape[0] else torch.zeros(1, device=self.device)
+            sums = torch.stack([rd.double().sum(), rg.double().sum()]).cpu().numpy()
+        nd, ng = ds.shape[0], gs.shape[0]
+        return (float(sums[0]) / nd if nd else float('nan')), (float(sums[1]) / ng if ng else float('nan'))
+
     def reward_iteration(self, max_iterations=500, stop_criteria=0.01, iter_check=10):
         prev_reward_demo_avg = -100
         self._sync_host_sampler()
@@ -472,11 +613,7 @@ class AC_IRL(actor_critic):
                 self.update_reward(summary=False)
                 continue
             self.update_reward(summary=False, iteration=self.reward_update_count)
-            ds, da = self._pairs_to_tensors(self.list_eval_demo_transitions)
-            gs, ga = self._pairs_to_tensors(self.list_eval_gen_transitions)
-            with torch.no_grad():
-                reward_demo_avg = float(self.reward_net(ds, da).sum().cpu()) / len(self.list_eval_demo_transitions)
-                reward_gen_avg = float(self.reward_net(gs, ga).sum().cpu()) / len(self.list_eval_gen_transitions)
+            reward_demo_avg, reward_gen_avg = self._eval_reward_averages()
             if self.verbose:
                 print('Reward iteration %d' % it)
                 print('Reward demo avg %f | Reward gen avg %f' % (reward_demo_avg, reward_gen_avg))
@@ -502,8 +639,13 @@ class AC_IRL(actor_critic):
         and the CSV log of the checkpointed run are kept.  outerloop(n) == outerloop(k, final_training=False) ->
         save / load -> outerloop(n, first_iteration=k), bit for bit."""
         write = 1 if os.path.isdir('results') else 0
+        on_device = self.rng == 'philox'                    # D_samp filled straight from mfg_rollout(WRITE_P), no host copy
         if first_iteration == 0:
-            self.list_generated = self.generate_trajectories(num_gen_from_policy * self.num_policies)
+            if on_device:
+                self._gen_store.clear()
+                self._gen_store.push(*self._generate_device(num_gen_from_policy * self.num_policies))
+            else:
+                self.list_generated = self.generate_trajectories(num_gen_from_policy * self.num_policies)
             self.reward_update_count = 0
             if write:
                 with open('results/reward_training.csv', 'w') as f:
@@ -511,9 +653,12 @@ class AC_IRL(actor_critic):
         for it in range(first_iteration, num_iterations):
             if self.verbose:
                 print('########## Outerloop iteration %d ##########' % it)
-            list_generated = self.generate_trajectories(num_gen_from_policy)
-            self.list_generated = (self.list_generated + list_generated)[num_gen_from_policy:]
-            self.list_eval_gen_transitions = [pair for traj in self.list_generated for pair in traj]
+            if on_device:
+                self._gen_store.push(*self._generate_device(num_gen_from_policy), drop=num_gen_from_policy)
+            else:
+                list_generated = self.generate_trajectories(num_gen_from_policy)
+                self.list_generated = (self.list_generated + list_generated)[num_gen_from_policy:]
+            self._eval_gen_override = None                   # list_eval_gen_transitions = every pair of D_samp (:934)
             self.reward_iteration(max_iterations=max_reward_iterations, stop_criteria=0.0001, iter_check=10)
             self.theta = self.theta_initial
             self.train(max_forward_episodes, -1, gamma, constant, lr_critic, lr_actor, consecutive=100,

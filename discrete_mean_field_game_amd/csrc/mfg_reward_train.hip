@@ -1,0 +1,577 @@
+// Reward-network TRAINING step of the max-ent IRL experiments on the device (gfx950).
+//
+// Replaces, for one call of AC_IRL.update_reward (reference ac_irl.py:804-846): the batch assembly from the Python lists
+// of (state, action) pairs, `sess.run(r_train_op)` = forward of networks.py:46-81 over the sampled demonstration and
+// generated transitions, the guided-cost-learning loss of ac_irl.py:390-413
+//     L = -(1/N_demo) sum r_demo  +  log( (1/M) sum_traj exp( sum_t r_gen ) )  [+ l1_l2(fc3_w) + l1_l2(fc4_w)],
+// its gradient, and one tf.train.AdamOptimizer step (ac_irl.py:417-418).
+//
+// The batch is tiny (5 + 5 trajectories x 15 transitions in the reference) and the step is latency bound, so the design
+// minimises dependent launches and host work instead of per-sample throughput:
+//   * the trajectories live in device-resident stores ([n,15,d] states, [n,15,d,d] actions); a batch is a list of store
+//     rows passed BY VALUE in the kernel arguments -- no gather kernel, no index upload;
+//   * launch 1 (k_rn_train_sample, one 256-thread block per transition): forward with every activation kept in LDS /
+//     registers, then the backward pass of THAT sample for d r / d params.  The loss couples samples only through the scalar
+//     dL/dr_n (the soft-max over the generated trajectories), and the gradient is linear in it:
+//         dL/dp = sum_n c_n  d r_n / d p,   c_n = -1/N_demo (demo),  softmax_j(S)_traj(n) (generated),
+//     so the per-sample Jacobian row needs no second pass over the network.  fc3_w (97 % of the parameters) is kept
+//     factored: the block stores its fc3 input a2 [2 d^2] and dz3 [n3], not their outer product;
+//   * launch 2 (k_rn_train_combine, one thread per parameter): c_n from the 150 rewards, the weighted sum over samples (for
+//     fc3_w the small GEMM  sum_n (c_n dz3_n[k]) a2_n[i]), the l1_l2 gradient, and the Adam update in place; block 0 writes
+//     [loss, first, second, reg] to a device slot that the host reads only when it prints them.
+// Multi-GPU (replicated reward net): launch 2 stops at the gradient (MFG_RN_TRAIN_GRAD_ONLY), the caller
+// all-reduces it and calls mfg_reward_net_adam.
+//
+// fp32 like the TF graph.  Dropout masks: the counter-based draw of the forward kernel (Philox key = seed, counter =
+// (unit, layer 3 | 4, sample index n within the batch, block 0)), so the NumPy restatement can replay them.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/mfg_hip.h"
+#include "mfg_core.h"
+
+namespace mfg {
+
+constexpr int RT_BLOCK = 256, RT_WAVES = RT_BLOCK / WAVE;
+constexpr int RT_MAX_TRAJ = MFG_RN_TRAIN_MAX_TRAJ;  // per batch half (demonstrations / generated)
+constexpr int RT_MAXN = 32;                          // n3, n4
+constexpr int RT_PP = 4;                             // pixels per thread, d <= 32
+constexpr int RT_QA = 8;                             // fc3 inputs per thread, f2 d^2 <= 2048
+
+struct RtLayout {
+  int o_c1w, o_c1b, o_c2w, o_c2b, o_w3, o_b3, o_w4, o_b4, o_wo, o_bo, np;
+  int a2;  // fc3 inputs = f2 d^2
+  int ns;  // parameters outside fc3_w
+};
+__host__ __device__ inline RtLayout rt_layout(int d, int k1, int f2, int k2, int n3, int n4) {
+  RtLayout L;
+  L.a2 = f2 * d * d;
+  L.o_c1w = 0;
+  L.o_c1b = L.o_c1w + k1 * k1;
+  L.o_c2w = L.o_c1b + 1;
+  L.o_c2b = L.o_c2w + f2 * k2 * k2;
+  L.o_w3 = L.o_c2b + f2;
+  L.o_b3 = L.o_w3 + n3 * L.a2;
+  L.o_w4 = L.o_b3 + n3;
+  L.o_b4 = L.o_w4 + n4 * (n3 + d);
+  L.o_wo = L.o_b4 + n4;
+  L.o_bo = L.o_wo + n4;
+  L.np = L.o_bo + 1;
+  L.ns = L.np - n3 * L.a2;
+  return L;
+}
+// index of parameter p (outside fc3_w) in a sample's small Jacobian row
+__device__ __forceinline__ int rt_small(const RtLayout& L, int p) { return p < L.o_w3 ? p : p - (L.o_b3 - L.o_w3); }
+
+struct RtArgs {
+  const float* params;
+  int d, k1, f2, k2, n3, n4;
+  const float *demo_state, *demo_action, *gen_state, *gen_action;
+  int steps, n_demo, n_gen;
+  float keep_prob;
+  int l1l2;
+  uint64_t seed;
+  float *r, *a2, *dz3, *js, *reg;  // workspace: [N], [N][a2], [N][n3], [N][ns], [1]
+  int32_t rows[2 * RT_MAX_TRAJ];   // store rows of the batch: demonstrations, then generated
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launch 1: one block per transition
+// ---------------------------------------------------------------------------------------------------------------------
+// K1 / K2 / F2 > 0: compile-time conv geometry (the reference's 5 / 3 / 2: taps unroll, weights come as scalar loads,
+// the weight-gradient accumulators stay in registers); 0 = run-time geometry, tap by tap (any odd k <= 7, f2 <= 2).
+template <int K1, int K2, int F2>
+__global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float red[RT_WAVES][64];
+  __shared__ float s_h3[RT_MAXN], s_h4[RT_MAXN], s_dz3[RT_MAXN], s_dz4[RT_MAXN], s_state[32], s_dzo;
+  const int d = a.d, dd = d * d, n3 = a.n3, n4 = a.n4;
+  const int k1 = K1 ? K1 : a.k1, k2 = K2 ? K2 : a.k2, f2 = F2 ? F2 : a.f2;
+  const int h1 = k1 / 2, h2 = k2 / 2, W1 = d + 2 * h1, W2 = d + 2 * h2;
+  const RtLayout L = rt_layout(d, k1, f2, k2, n3, n4);
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  const int n = blockIdx.x;
+  // which transition: trajectory j of the batch, step t
+  const int j = n / a.steps, t = n - j * a.steps;
+  const bool demo = j < a.n_demo;
+  const int64_t tr = (int64_t)a.rows[demo ? j : RT_MAX_TRAJ + (j - a.n_demo)] * a.steps + t;
+  const float* state = (demo ? a.demo_state : a.gen_state) + tr * d;
+  const float* act = (demo ? a.demo_action : a.gen_action) + tr * dd;
+  const float* P = a.params;
+  // LDS carve: padded input | padded conv1 map | conv2 map (NHWC flat) | f2 padded dz2 maps
+  float* tin = smem;
+  float* a1p = tin + W1 * W1;
+  float* a2s = a1p + W2 * W2;
+  float* dz2p = a2s + L.a2;
+  const int lds_n = W1 * W1 + W2 * W2 + L.a2 + f2 * W2 * W2;
+  for (int k = tid; k < lds_n; k += RT_BLOCK) smem[k] = 0.0f;
+  if (tid < d) s_state[tid] = state[tid];
+  __syncthreads();
+  int py[RT_PP], px[RT_PP];
+#pragma unroll
+  for (int q = 0; q < RT_PP; ++q) {
+    const int p = tid + q * RT_BLOCK;
+    const int pc = p < dd ? p : 0;
+    py[q] = pc / d;
+    px[q] = pc - py[q] * d;
+    if (p < dd) tin[(py[q] + h1) * W1 + px[q] + h1] = act[p];
+  }
+  __syncthreads();
+  // ---- forward: conv1 + ReLU
+  float a1v[RT_PP];
+#pragma unroll
+  for (int q = 0; q < RT_PP; ++q) {
+    a1v[q] = 0.0f;
+    if (tid + q * RT_BLOCK < dd) {
+      float s = P[L.o_c1b];
+      const float* tp = tin + py[q] * W1 + px[q];
+#pragma unroll
+      for (int dy = 0; dy < (K1 ? K1 : k1); ++dy)
+#pragma unroll
+        for (int dx = 0; dx < (K1 ? K1 : k1); ++dx) s = fmaf(tp[dy * W1 + dx], P[L.o_c1w + dy * k1 + dx], s);
+      a1v[q] = fmaxf(s, 0.0f);
+      a1p[(py[q] + h2) * W2 + px[q] + h2] = a1v[q];
+    }
+  }
+  __syncthreads();
+  // ---- conv2 + ReLU -> NHWC flat
+#pragma unroll
+  for (int q = 0; q < RT_PP; ++q) {
+    const int p = tid + q * RT_BLOCK;
+    if (p < dd) {
+      const float* tp = a1p + py[q] * W2 + px[q];
+#pragma unroll
+      for (int c = 0; c < (F2 ? F2 : 2); ++c) {
+        if (c < f2) {
+          float s = P[L.o_c2b + c];
+#pragma unroll
+          for (int dy = 0; dy < (K2 ? K2 : k2); ++dy)
+#pragma unroll
+            for (int dx = 0; dx < (K2 ? K2 : k2); ++dx)
+              s = fmaf(tp[dy * W2 + dx], P[L.o_c2w + c * k2 * k2 + dy * k2 + dx], s);
+          a2s[p * f2 + c] = fmaxf(s, 0.0f);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- fc3: thread owns inputs i = tid + 256 q
+  float a2v[RT_QA];
+#pragma unroll
+  for (int q = 0; q < RT_QA; ++q) {
+    const int i = tid + q * RT_BLOCK;
+    a2v[q] = i < L.a2 ? a2s[i] : 0.0f;
+  }
+  const float* W3 = P + L.o_w3;
+  for (int k = 0; k < n3; ++k) {
+    float s = 0.0f;
+#pragma unroll
+    for (int q = 0; q < RT_QA; ++q) {
+      const int i = tid + q * RT_BLOCK;
+      if (i < L.a2) s = fmaf(a2v[q], W3[(int64_t)k * L.a2 + i], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wv][k] = s;
+  }
+  __syncthreads();
+  const bool drop = a.keep_prob < 1.0f;
+  const float inv_keep = drop ? 1.0f / a.keep_prob : 1.0f;
+  if (tid < n3) {
+    float z = P[L.o_b3 + tid];
+#pragma unroll
+    for (int w = 0; w < RT_WAVES; ++w) z += red[w][tid];
+    float h = fmaxf(z, 0.0f);
+    if (drop) {
+      const u32x4 r = philox_elem(a.seed, (uint32_t)tid, 3u, (uint64_t)n, 0);
+      h = (u01(r.x) <= a.keep_prob) ? h * inv_keep : 0.0f;
+    }
+    s_h3[tid] = h;
+  }
+  __syncthreads();
+  // ---- fc4 over [h3, state] (networks.py:72)
+  const int in4 = n3 + d;
+  if (tid < n4) {
+    const float* w = P + L.o_w4 + tid * in4;
+    float z = P[L.o_b4 + tid];
+    for (int k = 0; k < n3; ++k) z = fmaf(s_h3[k], w[k], z);
+    for (int k = 0; k < d; ++k) z = fmaf(s_state[k], w[n3 + k], z);
+    float h = fmaxf(z, 0.0f);
+    if (drop) {
+      const u32x4 r = philox_elem(a.seed, (uint32_t)tid, 4u, (uint64_t)n, 0);
+      h = (u01(r.x) <= a.keep_prob) ? h * inv_keep : 0.0f;
+    }
+    s_h4[tid] = h;
+  }
+  __syncthreads();
+  float* js = a.js + (int64_t)n * L.ns;
+  if (tid == 0) {
+    float z = P[L.o_bo];
+    for (int m = 0; m < n4; ++m) z = fmaf(s_h4[m], P[L.o_wo + m], z);
+    const float r = tanhf(z);
+    a.r[n] = r;
+    const float dzo = 1.0f - r * r;  // d r / d z_out
+    s_dzo = dzo;
+    js[rt_small(L, L.o_bo)] = dzo;
+  }
+  __syncthreads();
+  // ---- backward of THIS sample's reward (dL/dr = 1; the combine kernel scales the row)
+  const float dzo = s_dzo;
+  if (tid < n4) {
+    const float dz = s_h4[tid] > 0.0f ? dzo * P[L.o_wo + tid] * inv_keep : 0.0f;  // h4 > 0 <=> pre-activation > 0 and unit kept
+    s_dz4[tid] = dz;
+    js[rt_small(L, L.o_wo + tid)] = dzo * s_h4[tid];
+    js[rt_small(L, L.o_b4 + tid)] = dz;
+  }
+  __syncthreads();
+  for (int e = tid; e < n4 * in4; e += RT_BLOCK) {
+    const int m = e / in4, k = e - m * in4;
+    js[rt_small(L, L.o_w4 + e)] = s_dz4[m] * (k < n3 ? s_h3[k] : s_state[k - n3]);
+  }
+  if (tid < n3) {
+    float dh = 0.0f;
+    for (int m = 0; m < n4; ++m) dh = fmaf(s_dz4[m], P[L.o_w4 + m * in4 + tid], dh);
+    const float dz = s_h3[tid] > 0.0f ? dh * inv_keep : 0.0f;
+    s_dz3[tid] = dz;
+    js[rt_small(L, L.o_b3 + tid)] = dz;
+    a.dz3[(int64_t)n * n3 + tid] = dz;
+  }
+  __syncthreads();
+  // ---- fc3 backward: d a2, stored factored (a2, dz3) for the combine kernel; dz2 into the padded maps
+  float gb2[2] = {0.0f, 0.0f};
+#pragma unroll
+  for (int q = 0; q < RT_QA; ++q) {
+    const int i = tid + q * RT_BLOCK;
+    if (i < L.a2) {
+      float da = 0.0f;
+      for (int k = 0; k < n3; ++k) da = fmaf(s_dz3[k], W3[(int64_t)k * L.a2 + i], da);
+      a.a2[(int64_t)n * L.a2 + i] = a2v[q];
+      const float dz = a2v[q] > 0.0f ? da : 0.0f;
+      const int pix = i / f2, c = i - pix * f2;
+      const int y = pix / d, x = pix - y * d;
+      dz2p[c * W2 * W2 + (y + h2) * W2 + x + h2] = dz;
+      gb2[c] += dz;
+    }
+  }
+  __syncthreads();
+  // ---- conv2 weight gradients, d a1, conv1 weight gradients
+  if constexpr (K1 > 0) {
+    constexpr int NW2 = F2 * K2 * K2, NW1 = K1 * K1, NACC = NW2 + F2 + NW1 + 1;
+    static_assert(NACC <= 64, "reduction scratch");
+    float acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < F2; ++c) acc[NW2 + c] = gb2[c];
+#pragma unroll
+    for (int q = 0; q < RT_PP; ++q) {
+      if (tid + q * RT_BLOCK < dd) {
+        const int y = py[q], x = px[q];
+        float da1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < F2; ++c) {
+          const float* zc = dz2p + c * W2 * W2;
+          const float dzc = zc[(y + h2) * W2 + x + h2];
+          const float* ap = a1p + y * W2 + x;
+#pragma unroll
+          for (int dy = 0; dy < K2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < K2; ++dx) {
+              acc[c * K2 * K2 + dy * K2 + dx] = fmaf(dzc, ap[dy * W2 + dx], acc[c * K2 * K2 + dy * K2 + dx]);
+              // a1[y,x] feeds a2[c, y - dy + h2, x - dx + h2] through tap (dy, dx)
+              da1 = fmaf(P[L.o_c2w + c * K2 * K2 + dy * K2 + dx], zc[(y - dy + 2 * h2) * W2 + (x - dx + 2 * h2)], da1);
+            }
+        }
+        const float dz1 = a1v[q] > 0.0f ? da1 : 0.0f;
+        const float* tp = tin + y * W1 + x;
+#pragma unroll
+        for (int dy = 0; dy < K1; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < K1; ++dx) acc[NW2 + F2 + dy * K1 + dx] = fmaf(dz1, tp[dy * W1 + dx], acc[NW2 + F2 + dy * K1 + dx]);
+        acc[NW2 + F2 + NW1] += dz1;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+      const float s = wave_sum(acc[k]);
+      if (lane == 0) red[wv][k] = s;
+    }
+    __syncthreads();
+    if (tid < NACC) {
+      float s = 0.0f;
+#pragma unroll
+      for (int w = 0; w < RT_WAVES; ++w) s += red[w][tid];
+      // acc order: conv2_w | conv2_b | conv1_w | conv1_b  ->  parameter order conv1_w | conv1_b | conv2_w | conv2_b
+      const int p = tid < NW2 + F2 ? L.o_c2w + tid : L.o_c1w + (tid - NW2 - F2);
+      js[rt_small(L, p)] = s;
+    }
+  } else {
+    // run-time geometry: one block reduction per tap
+    float dz1v[RT_PP];
+#pragma unroll
+    for (int q = 0; q < RT_PP; ++q) {
+      dz1v[q] = 0.0f;
+      if (tid + q * RT_BLOCK < dd) {
+        const int y = py[q], x = px[q];
+        float da1 = 0.0f;
+        for (int c = 0; c < f2; ++c)
+          for (int dy = 0; dy < k2; ++dy)
+            for (int dx = 0; dx < k2; ++dx)
+              da1 = fmaf(P[L.o_c2w + c * k2 * k2 + dy * k2 + dx],
+                         dz2p[c * W2 * W2 + (y - dy + 2 * h2) * W2 + (x - dx + 2 * h2)], da1);
+        dz1v[q] = a1v[q] > 0.0f ? da1 : 0.0f;
+      }
+    }
+    const int nw2 = f2 * k2 * k2, nw1 = k1 * k1, ntap = nw2 + f2 + nw1 + 1;
+    for (int e0 = 0; e0 < ntap; e0 += 64) {
+      const int ne = ntap - e0 < 64 ? ntap - e0 : 64;
+      for (int ee = 0; ee < ne; ++ee) {
+        const int e = e0 + ee;
+        float s = 0.0f;
+        if (e >= nw2 && e < nw2 + f2) s = gb2[e - nw2];
+        else {
+#pragma unroll
+          for (int q = 0; q < RT_PP; ++q) {
+            if (tid + q * RT_BLOCK < dd) {
+              const int y = py[q], x = px[q];
+              if (e < nw2) {
+                const int c = e / (k2 * k2), tp = e - c * k2 * k2, dy = tp / k2, dx = tp - dy * k2;
+                s = fmaf(dz2p[c * W2 * W2 + (y + h2) * W2 + x + h2], a1p[(y + dy) * W2 + x + dx], s);
+              } else if (e < nw2 + f2 + nw1) {
+                const int tp = e - nw2 - f2, dy = tp / k1, dx = tp - dy * k1;
+                s = fmaf(dz1v[q], tin[(y + dy) * W1 + x + dx], s);
+              } else s += dz1v[q];
+            }
+          }
+        }
+        s = wave_sum(s);
+        if (lane == 0) red[wv][ee] = s;
+      }
+      __syncthreads();
+      if (tid < ne) {
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < RT_WAVES; ++w) s += red[w][tid];
+        const int e = e0 + tid;
+        const int p = e < nw2 + f2 ? L.o_c2w + e : L.o_c1w + (e - nw2 - f2);
+        js[rt_small(L, p)] = s;
+      }
+      __syncthreads();
+    }
+  }
+  // ---- block 0 also leaves the regulariser's value (weights are read-only in this launch)
+  if (blockIdx.x == 0) {
+    float s = 0.0f;
+    if (a.l1l2) {
+      for (int p = L.o_w3 + tid; p < L.o_b3; p += RT_BLOCK) s += fabsf(P[p]) + 0.5f * P[p] * P[p];
+      for (int p = L.o_w4 + tid; p < L.o_b4; p += RT_BLOCK) s += fabsf(P[p]) + 0.5f * P[p] * P[p];
+    }
+    __syncthreads();
+    s = wave_sum(s);
+    if (lane == 0) red[wv][0] = s;
+    __syncthreads();
+    if (tid == 0) a.reg[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launch 2: coefficients, gradient, Adam
+// ---------------------------------------------------------------------------------------------------------------------
+struct RtCombineArgs {
+  float* params;
+  float *m, *v;  // Adam moments [np]
+  float* grad;   // [np] out (may be NULL when the update is applied here)
+  float* stats;  // [4] loss, first, second, reg (may be NULL)
+  const float *r, *a2, *dz3, *js, *reg;
+  int d, k1, f2, k2, n3, n4;
+  int steps, n_demo, n_gen;
+  float demo_scale;  // 1 / num_demo_samples (ac_irl.py:390)
+  int l1l2, apply;
+  float lr_t, beta1, beta2, eps;  // lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t)  (tf.train.AdamOptimizer)
+};
+
+__device__ __forceinline__ float adam_param(float p, float g, float& m, float& v, float lr_t, float b1, float b2, float eps) {
+  m = fmaf(b1, m, (1.0f - b1) * g);
+  v = fmaf(b2, v, (1.0f - b2) * g * g);
+  return p - lr_t * m / (sqrtf(v) + eps);
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_rn_train_combine(RtCombineArgs a) {
+  __shared__ float s_c[2 * RT_MAX_TRAJ];  // dL/dr per trajectory: demonstrations, then generated
+  __shared__ float s_S[RT_MAX_TRAJ];
+  __shared__ float s_stat[2];
+  const RtLayout L = rt_layout(a.d, a.k1, a.f2, a.k2, a.n3, a.n4);
+  const int tid = threadIdx.x;
+  const int nd = a.n_demo, ng = a.n_gen, T = a.steps;
+  if (tid < ng) {
+    float s = 0.0f;
+    for (int t = 0; t < T; ++t) s += a.r[(nd + tid) * T + t];
+    s_S[tid] = s;
+  }
+  if (tid < nd) s_c[tid] = -a.demo_scale;
+  __syncthreads();
+  if (tid == 0) {
+    float mx = -INFINITY;
+    for (int jj = 0; jj < ng; ++jj) mx = fmaxf(mx, s_S[jj]);
+    float z = 0.0f;
+    for (int jj = 0; jj < ng; ++jj) z += expf(s_S[jj] - mx);
+    for (int jj = 0; jj < ng; ++jj) s_c[nd + jj] = ng ? expf(s_S[jj] - mx) / z : 0.0f;
+    s_stat[0] = ng ? mx + logf(z / (float)ng) : 0.0f;  // = log( 1/M sum exp S_j )
+  }
+  __syncthreads();
+  const int N = (nd + ng) * T;
+  const int p = blockIdx.x * RT_BLOCK + tid;
+  if (p < L.np) {
+    // the sum over the batch runs in fp64: its terms (demonstrations -, generated +) cancel to a small net value, and an
+    // fp32 running sum would leave ~1e-7 of the LARGEST partial sum in it
+    double gs = 0.0;
+    if (p >= L.o_w3 && p < L.o_b3) {
+      const int k = (p - L.o_w3) / L.a2, i = (p - L.o_w3) - k * L.a2;
+      for (int n = 0; n < N; ++n) gs = fma((double)(s_c[n / T] * a.dz3[n * a.n3 + k]), (double)a.a2[(int64_t)n * L.a2 + i], gs);
+    } else {
+      const int ps = rt_small(L, p);
+      for (int n = 0; n < N; ++n) gs = fma((double)s_c[n / T], (double)a.js[(int64_t)n * L.ns + ps], gs);
+    }
+    const float w = a.params[p];
+    if (a.l1l2 && ((p >= L.o_w3 && p < L.o_b3) || (p >= L.o_w4 && p < L.o_b4)))
+      gs += (double)((w > 0.0f ? 1.0f : (w < 0.0f ? -1.0f : 0.0f)) + w);  // d/dw (|w| + w^2 / 2)
+    const float g = (float)gs;
+    if (a.grad) a.grad[p] = g;
+    if (a.apply) {
+      float m = a.m[p], v = a.v[p];
+      a.params[p] = adam_param(w, g, m, v, a.lr_t, a.beta1, a.beta2, a.eps);
+      a.m[p] = m;
+      a.v[p] = v;
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0 && a.stats) {
+    float sd = 0.0f;
+    for (int n = 0; n < nd * T; ++n) sd += a.r[n];
+    const float first = -a.demo_scale * sd, second = s_stat[0], reg = a.l1l2 ? a.reg[0] : 0.0f;
+    a.stats[0] = first + second + reg;
+    a.stats[1] = first;
+    a.stats[2] = second;
+    a.stats[3] = reg;
+  }
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_rn_adam(float* params, float* m, float* v, const float* grad, int64_t n, float lr_t,
+                                                      float b1, float b2, float eps) {
+  const int64_t p = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+  if (p < n) {
+    float mm = m[p], vv = v[p];
+    params[p] = adam_param(params[p], grad[p], mm, vv, lr_t, b1, b2, eps);
+    m[p] = mm;
+    v[p] = vv;
+  }
+}
+
+static bool rt_shape_ok(int d, int k1, int f2, int k2, int n3, int n4) {
+  return d >= 1 && d <= 32 && f2 >= 1 && f2 <= 2 && n3 >= 1 && n3 <= RT_MAXN && n4 >= 1 && n4 <= RT_MAXN && (k1 & 1) && (k2 & 1) &&
+         k1 >= 1 && k1 <= 7 && k2 >= 1 && k2 <= 7;
+}
+static float adam_lr_t(double lr, double b1, double b2, int64_t step) {
+  return (float)(lr * sqrt(1.0 - pow(b2, (double)step)) / (1.0 - pow(b1, (double)step)));
+}
+
+}  // namespace mfg
+
+using namespace mfg;
+
+extern "C" {
+
+int64_t mfg_reward_net_num_params(int d, int k1, int f2, int k2, int n3, int n4) {
+  if (d < 1 || k1 < 1 || f2 < 1 || k2 < 1 || n3 < 1 || n4 < 1) return -1;
+  return rt_layout(d, k1, f2, k2, n3, n4).np;
+}
+
+int mfg_reward_net_param_offsets(int d, int k1, int f2, int k2, int n3, int n4, int64_t* offsets_host) {
+  if (!offsets_host || d < 1 || k1 < 1 || f2 < 1 || k2 < 1 || n3 < 1 || n4 < 1)
+    return set_error(MFG_EINVAL, "reward_net_param_offsets: bad argument");
+  const RtLayout L = rt_layout(d, k1, f2, k2, n3, n4);
+  const int o[11] = {L.o_c1w, L.o_c1b, L.o_c2w, L.o_c2b, L.o_w3, L.o_b3, L.o_w4, L.o_b4, L.o_wo, L.o_bo, L.np};
+  for (int k = 0; k < 11; ++k) offsets_host[k] = o[k];
+  return MFG_OK;
+}
+
+size_t mfg_reward_net_train_workspace_bytes(int d, int k1, int f2, int k2, int n3, int n4, int64_t n_transitions) {
+  if (d < 1 || k1 < 1 || f2 < 1 || k2 < 1 || n3 < 1 || n4 < 1 || n_transitions < 0) return 0;
+  const RtLayout L = rt_layout(d, k1, f2, k2, n3, n4);
+  return (size_t)(n_transitions * (1 + L.a2 + n3 + L.ns) + 4) * sizeof(float);
+}
+
+int mfg_reward_net_train_step(float* params, float* adam_m, float* adam_v, int d, int k1, int f2, int k2, int n3, int n4,
+                              const float* demo_state, const float* demo_action, const int32_t* demo_rows_host, int n_demo,
+                              const float* gen_state, const float* gen_action, const int32_t* gen_rows_host, int n_gen, int steps,
+                              int demo_divisor, float keep_prob, int l1l2, uint64_t seed, double lr, double beta1, double beta2,
+                              double eps, int64_t adam_step, int flags, float* grad, float* stats, void* workspace,
+                              size_t workspace_bytes, mfg_stream_t stream) {
+  if (!params || !workspace || n_demo < 0 || n_gen < 0 || steps < 1 || demo_divisor < 1 || (n_demo && (!demo_state || !demo_action || !demo_rows_host)) ||
+      (n_gen && (!gen_state || !gen_action || !gen_rows_host)))
+    return set_error(MFG_EINVAL, "reward_net_train_step: null pointer / bad count");
+  const bool apply = !(flags & MFG_RN_TRAIN_GRAD_ONLY);
+  if (apply && (!adam_m || !adam_v || adam_step < 1)) return set_error(MFG_EINVAL, "reward_net_train_step: Adam state missing / step < 1");
+  if (!apply && !grad) return set_error(MFG_EINVAL, "reward_net_train_step: MFG_RN_TRAIN_GRAD_ONLY needs grad");
+  if (!(keep_prob > 0.0f && keep_prob <= 1.0f)) return set_error(MFG_EINVAL, "reward_net_train_step: keep_prob must be in (0,1]");
+  if (!rt_shape_ok(d, k1, f2, k2, n3, n4))
+    return set_error(MFG_EUNSUPPORTED, "reward_net_train_step: supported d <= 32, f2 <= 2, n_fc <= 32, odd kernels <= 7");
+  if (n_demo > RT_MAX_TRAJ || n_gen > RT_MAX_TRAJ)
+    return set_error(MFG_EUNSUPPORTED, "reward_net_train_step: at most MFG_RN_TRAIN_MAX_TRAJ trajectories per batch half");
+  const int64_t N = (int64_t)(n_demo + n_gen) * steps;
+  if (N == 0) return set_error(MFG_EINVAL, "reward_net_train_step: empty batch");
+  if (workspace_bytes < mfg_reward_net_train_workspace_bytes(d, k1, f2, k2, n3, n4, N))
+    return set_error(MFG_EWORKSPACE, "reward_net_train_step: workspace too small (mfg_reward_net_train_workspace_bytes)");
+  const RtLayout L = rt_layout(d, k1, f2, k2, n3, n4);
+  RtArgs a{};
+  a.params = params;
+  a.d = d; a.k1 = k1; a.f2 = f2; a.k2 = k2; a.n3 = n3; a.n4 = n4;
+  a.demo_state = demo_state; a.demo_action = demo_action; a.gen_state = gen_state; a.gen_action = gen_action;
+  a.steps = steps; a.n_demo = n_demo; a.n_gen = n_gen;
+  a.keep_prob = keep_prob;
+  a.l1l2 = l1l2 ? 1 : 0;
+  a.seed = seed;
+  float* ws = (float*)workspace;
+  a.reg = ws;          // [4] (16-byte slot)
+  a.r = ws + 4;
+  a.dz3 = a.r + N;
+  a.js = a.dz3 + N * n3;
+  a.a2 = a.js + N * L.ns;
+  for (int k = 0; k < n_demo; ++k) {
+    if (demo_rows_host[k] < 0) return set_error(MFG_EINVAL, "reward_net_train_step: negative store row");
+    a.rows[k] = demo_rows_host[k];
+  }
+  for (int k = 0; k < n_gen; ++k) {
+    if (gen_rows_host[k] < 0) return set_error(MFG_EINVAL, "reward_net_train_step: negative store row");
+    a.rows[RT_MAX_TRAJ + k] = gen_rows_host[k];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int h1 = k1 / 2, h2 = k2 / 2, W1 = d + 2 * h1, W2 = d + 2 * h2;
+  const size_t lds = (size_t)(W1 * W1 + W2 * W2 + L.a2 + f2 * W2 * W2) * sizeof(float);
+  if (k1 == 5 && k2 == 3 && f2 == 2)
+    hipLaunchKernelGGL((k_rn_train_sample<5, 3, 2>), dim3((unsigned)N), dim3(RT_BLOCK), lds, st, a);
+  else
+    hipLaunchKernelGGL((k_rn_train_sample<0, 0, 0>), dim3((unsigned)N), dim3(RT_BLOCK), lds, st, a);
+  RtCombineArgs c{};
+  c.params = params; c.m = adam_m; c.v = adam_v; c.grad = grad; c.stats = stats;
+  c.r = a.r; c.a2 = a.a2; c.dz3 = a.dz3; c.js = a.js; c.reg = a.reg;
+  c.d = d; c.k1 = k1; c.f2 = f2; c.k2 = k2; c.n3 = n3; c.n4 = n4;
+  c.steps = steps; c.n_demo = n_demo; c.n_gen = n_gen;
+  c.demo_scale = 1.0f / (float)demo_divisor;
+  c.l1l2 = a.l1l2;
+  c.apply = apply ? 1 : 0;
+  if (apply) c.lr_t = adam_lr_t(lr, beta1, beta2, adam_step);
+  c.beta1 = (float)beta1; c.beta2 = (float)beta2; c.eps = (float)eps;
+  hipLaunchKernelGGL(k_rn_train_combine, dim3((unsigned)((L.np + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, st, c);
+  return hipGetLastError() == hipSuccess ? MFG_OK : set_error(MFG_ELAUNCH, "reward_net_train_step: launch failed");
+}
+
+int mfg_reward_net_adam(float* params, float* adam_m, float* adam_v, const float* grad, int64_t n, double lr, double beta1,
+                        double beta2, double eps, int64_t adam_step, mfg_stream_t stream) {
+  if (!params || !adam_m || !adam_v || !grad || n < 0 || adam_step < 1) return set_error(MFG_EINVAL, "reward_net_adam: bad argument");
+  if (n == 0) return MFG_OK;
+  hipLaunchKernelGGL(k_rn_adam, dim3((unsigned)((n + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, (hipStream_t)stream, params, adam_m,
+                     adam_v, grad, n, adam_lr_t(lr, beta1, beta2, adam_step), (float)beta1, (float)beta2, (float)eps);
+  return hipGetLastError() == hipSuccess ? MFG_OK : set_error(MFG_ELAUNCH, "reward_net_adam: launch failed");
+}
+
+}  // extern "C"

@@ -274,6 +274,42 @@ int mfg_reward_net_forward(const float* state, const float* action, int64_t B, i
                            const float* fc4_b, const float* out_w, const float* out_b, float keep_prob, uint64_t seed,
                            uint64_t sample_offset, float* reward, mfg_stream_t stream);
 
+/* f1 (IRL), reward learning on the device: ONE call = one AC_IRL.update_reward (ac_irl.py:804-846) -- batch assembly,
+ * forward of networks.py:46-81 over the sampled demonstration and generated transitions, the max-ent loss of
+ * ac_irl.py:390-413
+ *     L = -(1/demo_divisor) sum r_demo + log( (1/n_gen) sum_traj exp( sum_t r_gen ) ) [+ l1_l2(fc3_w) + l1_l2(fc4_w)],
+ * its gradient and one tf.train.AdamOptimizer step (ac_irl.py:417-418;  lr_t = lr sqrt(1-beta2^t)/(1-beta1^t),
+ * m = beta1 m + (1-beta1) g, v = beta2 v + (1-beta2) g^2, p -= lr_t m / (sqrt v + eps)), in two launches and no host
+ * synchronisation.
+ *   params / adam_m / adam_v [NP] fp32: ONE flat buffer per quantity, tensors in the order
+ *     conv1_w [k1*k1] | conv1_b [1] | conv2_w [f2][k2*k2] | conv2_b [f2] | fc3_w [n3][f2*d*d] | fc3_b [n3] |
+ *     fc4_w [n4][n3+d] | fc4_b [n4] | out_w [n4] | out_b [1]      (layouts of mfg_reward_net_forward;
+ *     mfg_reward_net_param_offsets gives the 10 start offsets and NP as offsets_host[0..10]).
+ *   The trajectories live in device-resident stores: *_state [rows, steps, d], *_action [rows, steps, d, d] fp32; the
+ *   batch is the store rows demo_rows_host[n_demo] and gen_rows_host[n_gen] (HOST arrays, copied into the kernel
+ *   arguments: no index upload; each <= MFG_RN_TRAIN_MAX_TRAJ).  Transition n of the batch (demonstrations first, row
+ *   major over (trajectory, step)) draws its dropout masks from Philox key `seed`, counter (unit, 3 | 4, n, block 0) when
+ *   keep_prob < 1, like mfg_reward_net_forward with sample_offset 0.
+ *   flags & MFG_RN_TRAIN_GRAD_ONLY: stop at the gradient (grad [NP], required) -- the multi-GPU form: all-reduce grad,
+ *   then mfg_reward_net_adam.  grad may also be given without the flag (gradient written AND update applied).
+ *   stats (may be NULL) [4] <- loss, first term, second term, regulariser, evaluated at the weights BEFORE the update
+ *   (what sess.run([r_train_op, loss, ...]) returns, ac_irl.py:846).
+ *   workspace: mfg_reward_net_train_workspace_bytes(..., (n_demo + n_gen) * steps); contents are scratch.
+ * Supported shapes as mfg_reward_net_forward. */
+#define MFG_RN_TRAIN_MAX_TRAJ 64
+enum { MFG_RN_TRAIN_GRAD_ONLY = 1 };
+int64_t mfg_reward_net_num_params(int d, int k1, int f2, int k2, int n3, int n4);
+int mfg_reward_net_param_offsets(int d, int k1, int f2, int k2, int n3, int n4, int64_t* offsets_host);
+size_t mfg_reward_net_train_workspace_bytes(int d, int k1, int f2, int k2, int n3, int n4, int64_t n_transitions);
+int mfg_reward_net_train_step(float* params, float* adam_m, float* adam_v, int d, int k1, int f2, int k2, int n3, int n4,
+                              const float* demo_state, const float* demo_action, const int32_t* demo_rows_host, int n_demo,
+                              const float* gen_state, const float* gen_action, const int32_t* gen_rows_host, int n_gen, int steps,
+                              int demo_divisor, float keep_prob, int l1l2, uint64_t seed, double lr, double beta1, double beta2,
+                              double eps, int64_t adam_step, int flags, float* grad, float* stats, void* workspace,
+                              size_t workspace_bytes, mfg_stream_t stream);
+int mfg_reward_net_adam(float* params, float* adam_m, float* adam_v, const float* grad, int64_t n, double lr, double beta1,
+                        double beta2, double eps, int64_t adam_step, mfg_stream_t stream);
+
 /* f3: backward value recursion of the mfg_synthetic variant: V^n = r^n + P^n V^{n+1}, r^n_i = -1/2 ||P^n_i||^2,
  * V^T = 0 (mfg_synthetic.py:768-774) for P[B,T,d,d] -> V[B,T+1,d] (fp64), plus per (b,n) the consistency
  * metrics of evaluate_synthetic (diff_l1 = sum_ij |P_ij - value_ij|, :776-790) and, if diff_jsd != NULL, of

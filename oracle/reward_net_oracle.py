@@ -100,3 +100,110 @@ def params_from_torch(net):
         'fc4_w': g(net.fc4.weight).T, 'fc4_b': g(net.fc4.bias),
         'out_w': g(net.out.weight).T, 'out_b': g(net.out.bias),
     }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Training step (ac_irl.py:382-418 loss + tf.train.AdamOptimizer, :804-846 update_reward), fp64.  PARITY UNPINNED like the
+# forward pass: this is the hand-derived gradient of the restated graph, checked against PyTorch autograd of
+# networks.RewardNet and against central differences in tests/test_reward_net.py.
+# ---------------------------------------------------------------------------------------------------------------------
+def forward_cache(params, state, action, masks=None):
+    """forward() that also returns what backward() needs.  masks = (m3 [N,n3], m4 [N,n4]) of 0 / (1/keep) or None."""
+    N, d = state.shape
+    x0 = action.reshape(N, d, d, 1).astype(np.float64)
+    a1 = np.maximum(conv2d_same(x0, params['conv1_w'], params['conv1_b']), 0)
+    a2 = np.maximum(conv2d_same(a1, params['conv2_w'], params['conv2_b']), 0)
+    flat = a2.reshape(N, -1)
+    h3 = np.maximum(flat.dot(params['fc3_w']) + params['fc3_b'], 0)
+    if masks is not None:
+        h3 = h3 * masks[0]
+    in4 = np.concatenate([h3, state.astype(np.float64)], axis=1)
+    h4 = np.maximum(in4.dot(params['fc4_w']) + params['fc4_b'], 0)
+    if masks is not None:
+        h4 = h4 * masks[1]
+    r = np.tanh(h4.dot(params['out_w']) + params['out_b'])
+    return r, dict(x0=x0, a1=a1, a2=a2, flat=flat, h3=h3, in4=in4, h4=h4, r=r, masks=masks)
+
+
+def _conv_backward(x, w, dz):
+    """Gradients of z = conv2d_same(x, w, b) given dz [N,H,W,Cout]: (dx, dw, db)."""
+    N, H, W, Cin = x.shape
+    kh, kw, _, Cout = w.shape
+    ph, pw = kh // 2, kw // 2
+    xp = np.zeros((N, H + 2 * ph, W + 2 * pw, Cin))
+    xp[:, ph:ph + H, pw:pw + W] = x
+    dxp = np.zeros_like(xp)
+    dw = np.zeros_like(w, dtype=np.float64)
+    for u in range(kh):
+        for v in range(kw):
+            dw[u, v] = np.einsum('nhwc,nhwo->co', xp[:, u:u + H, v:v + W], dz)
+            dxp[:, u:u + H, v:v + W] += np.einsum('nhwo,co->nhwc', dz, w[u, v])
+    return dxp[:, ph:ph + H, pw:pw + W], dw, dz.sum(axis=(0, 1, 2))
+
+
+def backward(params, cache, dr):
+    """d (sum_n dr_n r_n) / d params for dr [N,1]; TF layouts like `params`."""
+    m = cache['masks']
+    dzo = dr * (1.0 - cache['r'] ** 2)
+    g = {'out_w': cache['h4'].T.dot(dzo), 'out_b': dzo.sum(0)}
+    dh4 = dzo.dot(params['out_w'].T)
+    dz4 = dh4 * (cache['h4'] > 0) * (m[1] if m is not None else 1.0)
+    g['fc4_w'] = cache['in4'].T.dot(dz4)
+    g['fc4_b'] = dz4.sum(0)
+    n3 = params['fc3_w'].shape[1]
+    dh3 = dz4.dot(params['fc4_w'].T)[:, :n3]
+    dz3 = dh3 * (cache['h3'] > 0) * (m[0] if m is not None else 1.0)
+    g['fc3_w'] = cache['flat'].T.dot(dz3)
+    g['fc3_b'] = dz3.sum(0)
+    da2 = dz3.dot(params['fc3_w'].T).reshape(cache['a2'].shape)
+    dz2 = da2 * (cache['a2'] > 0)
+    da1, g['conv2_w'], g['conv2_b'] = _conv_backward(cache['a1'], params['conv2_w'], dz2)
+    dz1 = da1 * (cache['a1'] > 0)
+    _, g['conv1_w'], g['conv1_b'] = _conv_backward(cache['x0'], params['conv1_w'], dz1)
+    return g
+
+
+def irl_loss_and_grad(params, demo_state, demo_action, gen_state, gen_action, n_demo_div, n_traj, l1l2=False, steps=15,
+                      masks=None):
+    """Loss of ac_irl.py:390-413 and its gradient for one update_reward batch.  masks: (m3, m4) over the concatenated batch
+    (demonstrations first) or None.  Returns ((loss, first, second, reg), grads dict, rewards [N,1])."""
+    nd = demo_state.shape[0]
+    state = np.concatenate([demo_state, gen_state], 0)
+    action = np.concatenate([demo_action, gen_action], 0)
+    r, cache = forward_cache(params, state, action, masks)
+    reg = l1_l2(params) if l1l2 else 0.0
+    loss, first, second = irl_loss(r[:nd], r[nd:], n_demo_div, n_traj, reg, steps)
+    S = r[nd:].reshape(n_traj, steps).sum(1)
+    soft = np.exp(S - S.max())
+    soft = soft / soft.sum()
+    dr = np.concatenate([np.full((nd, 1), -1.0 / n_demo_div), np.repeat(soft, steps)[:, None]], 0)
+    g = backward(params, cache, dr)
+    if l1l2:
+        for k in ('fc3_w', 'fc4_w'):
+            g[k] = g[k] + np.sign(params[k]) + params[k]
+    return (loss, first, second, reg), g, r
+
+
+def adam_tf(p, g, m, v, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8):
+    """tf.train.AdamOptimizer (ac_irl.py:417): lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t); m, v exponential averages;
+    p -= lr_t m / (sqrt(v) + eps).  Returns (p, m, v)."""
+    lr_t = lr * np.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    return p - lr_t * m / (np.sqrt(v) + eps), m, v
+
+
+FLAT_ORDER = ('conv1_w', 'conv1_b', 'conv2_w', 'conv2_b', 'fc3_w', 'fc3_b', 'fc4_w', 'fc4_b', 'out_w', 'out_b')
+
+
+def flatten_like_kernel(tf_arrays):
+    """TF-layout dict -> the flat parameter order of mfg_reward_net_train_step (PyTorch layouts: conv OIHW, dense [out, in])."""
+    out = []
+    for k in FLAT_ORDER:
+        a = np.asarray(tf_arrays[k], dtype=np.float64)
+        if a.ndim == 4:
+            a = a.transpose(3, 2, 0, 1)
+        elif a.ndim == 2:
+            a = a.T
+        out.append(a.reshape(-1))
+    return np.concatenate(out)
