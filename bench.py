@@ -54,6 +54,7 @@ def parse():
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
                     help="collective backend; 'gloo' (+ --share-gpu) only exists to smoke-test the N>1 path on a 1-GPU box")
     ap.add_argument('--share-gpu', action='store_true', help='debug: all ranks use GPU 0')
+    ap.add_argument('--c5-batch', type=int, default=131072, help='GLOBAL batch of the c5_strong leg (N > 1); tests shrink it')
     ap.add_argument('--force-dist', action='store_true',
                     help='debug: take the process-group / all-reduce path even with one rank (RCCL smoke test on a 1-GPU box)')
     return ap.parse_args()
@@ -312,9 +313,9 @@ def main():
                  'value': world * Bo * T * args.steps / eo, 'ms_per_step': eo / args.steps * 1e3, 'unit': 'env-steps/s'}
         del ac
         # BASELINE config 5: d=256, T=40, global batch 131072 sharded over the ranks
-        B5 = 131072 // world
+        B5 = max(1, args.c5_batch // world)
         e5, _, ac = training_leg(256, 40, B5, 2, 1)
-        c5 = {'workload': 'C5 d=256 T=40 global batch 131072 split over %d GPUs' % world, 'batch_per_gpu': B5,
+        c5 = {'workload': 'C5 d=256 T=40 global batch %d split over %d GPUs' % (B5 * world, world), 'batch_per_gpu': B5,
               'value': world * B5 * 40 * 2 / e5, 'ms_per_step': e5 / 2 * 1e3, 'unit': 'env-steps/s', 'steps': 2}
         del ac
 
@@ -401,6 +402,8 @@ def main():
                                                      ws=wsf, out=bf), n=10, warm=3)
                 fused = {'kernel': ('k_core_small' if d <= 64 else 'k_core_large') + '<SAMPLE,TD,MIXED> + k_grad + k_reduce_partials',
                          'bound': 'valu/transcendental+rng (P stays on chip)', 'avg_launch_ms': t_f * 1e3,
+                         'avg_launch_note': 'separate 10-launch probe of ops.rollout (rollout + batch sums, no update) after the timed '
+                                            'region, not a share of ms_per_step: run-to-run scatter of ~2 % can put it above the headline',
                          'env_steps_per_s': B * T / t_f, 'hbm_algorithmic_GBs': B * T * bytes_per_step / t_f / 1e9}
                 fused.update(pmc_sq('k_core_', d, T, B))
                 # host-boundness of the class API: the same updates issued by one native call, GPU time from events
@@ -522,6 +525,49 @@ def other_configs(training_leg, native_leg, given_p_leg, d0, T0, B0, args):
                         'ms_per_episode': dt / episodes * 1e3})
     except Exception as exc:
         out.append({'config': 'C4', 'error': repr(exc)})
+    # C4, the IRL experiment itself: AC_IRL.outerloop (ac_irl.py:900-954, what gridsearch.py:21-23 runs) = per iteration
+    # [generate 5 trajectories into D_samp | reward_iteration(100 reward updates, eval every 10) | train(200 episodes)] with the
+    # reference's defaults, 21 synthetic demonstrations; wall-time split (synchronised around each phase)
+    try:
+        import random as _random
+        from discrete_mean_field_game_amd.ac_irl import AC_IRL
+        rs = np.random.RandomState(0)
+        mat = rs.dirichlet(np.ones(21), size=64)
+        demos = [[(rs.dirichlet(np.ones(21)), rs.dirichlet(np.ones(21), size=21)) for _ in range(15)] for _ in range(21)]
+        for mode in ('step', 'rollout'):
+            np.random.seed(5); torch.manual_seed(5); _random.seed(5)
+            ac = AC_IRL(theta=8.64, shift=0.0, alpha_scale=1e4, d=21, pi0=mat, demonstrations=demos, batch=4096, seed=3,
+                        update_every=mode, verbose=0)
+            split = {'generate': 0.0, 'reward_iteration': 0.0, 'train': 0.0}
+
+            def timed(name, fn):
+                def wrapped(*a, **k):
+                    torch.cuda.synchronize(); t0 = _t.perf_counter()
+                    r = fn(*a, **k)
+                    torch.cuda.synchronize(); split[name] += _t.perf_counter() - t0
+                    return r
+                return wrapped
+            ac._generate_device = timed('generate', ac._generate_device)
+            ac.reward_iteration = timed('reward_iteration', ac.reward_iteration)
+            ac.train = timed('train', ac.train)
+            ac.outerloop(num_iterations=1, final_training=False)                    # warm-up iteration (untimed)
+            for k in split:
+                split[k] = 0.0
+            iters = 2
+            torch.cuda.synchronize(); t0 = _t.perf_counter()
+            ac.outerloop(num_iterations=iters, final_training=False)
+            torch.cuda.synchronize(); dt = _t.perf_counter() - t0
+            n_upd = ac.reward_update_count / iters
+            out.append({'config': 'C4 AC_IRL.outerloop (reward learning + forward solve on the device), update per %s' % mode,
+                        'd': 21, 'T': 15, 'batch': 4096, 'outer_iterations': iters, 'ms_per_outer_iteration': dt / iters * 1e3,
+                        'split_ms': {k: v / iters * 1e3 for k, v in split.items()},
+                        'reward_updates_per_iteration': n_upd, 'us_per_reward_update': split['reward_iteration'] / iters / max(n_upd, 1) * 1e6,
+                        'forward_episodes_per_iteration': 200,
+                        'env_steps_per_s_whole_loop': 4096 * 15 * 200 * iters / dt,
+                        'reward_iteration_share': split['reward_iteration'] / max(dt, 1e-12),
+                        'loss': ac.loss_val, 'theta_end': float(np.ravel(ac.theta)[0])})
+    except Exception as exc:
+        out.append({'config': 'C4 outerloop', 'error': repr(exc)})
     return out
 
 

@@ -77,6 +77,7 @@ SIGNATURES = {
                                           _i32, _u64, _u32, _u64, _i32, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     'mfg_train_episodes': (_i32, [_p, _i64, _p, _p, _i64, _i32, _i32, _i64, _i64, _i32, _p, _f64, _f64, _p, _f64, _i32, _u64, _u32,
                                   _u64, _i32, _f64, _f64, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    'mfg_dist_available': (_i32, []),
     'mfg_dist_unique_id': (_i32, [_p]),
     'mfg_dist_init': (_i32, [_p, _i32, _i32, C.POINTER(C.c_void_p)]),
     'mfg_dist_destroy': (_i32, [_p]),

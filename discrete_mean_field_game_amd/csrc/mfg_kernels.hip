@@ -2410,12 +2410,17 @@ static int status_error(unsigned bits) {
   return fail(MFG_ERANGE, "device status word = 0x%x", bits);
 }
 
+// mfg_train_rollouts_dist: the sticky status word is read ONCE in front of the episode loop and once behind it, not per
+// enqueue -- the host read races the device by a different number of episodes on every rank, and a rank that stops
+// enqueueing leaves its peers' all-reduces without a partner (the private communicator has no watchdog).
+static thread_local bool g_status_check_deferred = false;
+
 static int launch_core(const CoreArgs& a_in, bool sample, bool td, int precision, hipStream_t st) {
   CoreArgs a = a_in;
   {
     const StatusWord sw = status_word();
     if (!sw.host) return fail(MFG_ELAUNCH, "%s", "status word allocation failed");
-    const unsigned bits = *(volatile unsigned*)sw.host;
+    const unsigned bits = g_status_check_deferred ? 0u : *(volatile unsigned*)sw.host;
     // sticky until mfg_clear_status() -- for the launches the condition concerns: MFG_STATUS_MIXED_RANGE is a property of
     // mixed-precision SAMPLING (theta beyond the range of its fp32 factors); strict-precision launches and launches on given
     // actions have no such limit and go ahead whatever another instance / thread on this device ran into
@@ -3155,6 +3160,7 @@ struct RcclApi {
   int (*GetUniqueId)(void*) = nullptr;
   int (*CommInitRank)(void**, int, mfg_rccl_id_t, int) = nullptr;   // ncclUniqueId is passed BY VALUE (128 bytes)
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommAbort)(void*) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
@@ -3170,6 +3176,7 @@ const RcclApi& rccl() {
     a.GetUniqueId = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclGetUniqueId"));
     a.CommInitRank = reinterpret_cast<int (*)(void**, int, mfg_rccl_id_t, int)>(dlsym(h, "ncclCommInitRank"));
     a.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommDestroy"));
+    a.CommAbort = reinterpret_cast<int (*)(void*)>(dlsym(h, "ncclCommAbort"));
     a.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(h, "ncclAllReduce"));
     a.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(h, "ncclGetErrorString"));
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce;
@@ -3184,6 +3191,8 @@ int rccl_fail(const char* what, int rc) {
 constexpr int RCCL_SUM = 0, RCCL_FLOAT64 = 8;  // ncclSum, ncclFloat64 (rccl.h)
 }  // namespace
 extern "C" {
+
+int mfg_dist_available(void) { return rccl().ok ? 1 : 0; }
 
 int mfg_dist_unique_id(mfg_rccl_id_t* id_host) {
   REQUIRE(id_host, "null pointer");
@@ -3236,6 +3245,20 @@ int mfg_train_rollouts_dist(void* comm, const float* mat_pi0, int64_t num_start,
   if (episodes == 0) return MFG_OK;
   const int64_t F = mfg_num_features(d);
   hipStream_t st = S(stream);
+  // Every rank must enqueue the SAME number of all-reduces.  The sticky status word is therefore examined here, before the
+  // first enqueue (a condition raised by an earlier call: every rank that shares the history refuses alike), and again
+  // behind the loop; inside the loop launches go ahead whatever the device reports meanwhile (the outputs of a launch in the
+  // reported condition are NaN on every rank alike, theta is replicated).  A rank-local failure inside the loop (a launch
+  // error) aborts the communicator, so the peers' pending collectives fail instead of waiting for this rank for ever.
+  {
+    const bool mixed = !(flags & MFG_ROLLOUT_F64);
+    unsigned bits = 0;
+    if (mfg_status(&bits) != MFG_OK && mixed && (bits & MFG_STATUS_MIXED_RANGE)) return MFG_ERANGE;
+  }
+  struct DeferGuard {
+    DeferGuard() { g_status_check_deferred = true; }
+    ~DeferGuard() { g_status_check_deferred = false; }
+  } defer_guard;
   double *tc = theta, *wc = w, *tn = theta_alt, *wn = w_alt;   // current / next parameter set
   double plc = 0.0, pla = 0.0;
   double* pacc = nullptr;
@@ -3245,13 +3268,19 @@ int mfg_train_rollouts_dist(void* comm, const float* mat_pi0, int64_t num_start,
     int rc = train_rollout_impl(mat_pi0, num_start, nullptr, B, d, T, tc, shift, alpha_scale, wc, gamma, reward_kind, seed,
                                 first_step + (uint32_t)(k * T), traj_offset, flags, 0.0, 0.0, pi_traj, pi_last, reward, delta, g, G,
                                 nullptr, workspace, workspace_bytes, st, pending ? &du : nullptr);
-    if (rc != MFG_OK) return rc;
+    if (rc != MFG_OK) {
+      if (r.CommAbort) (void)r.CommAbort(comm);   // (the communicator is unusable afterwards: the caller drops it)
+      return rc;
+    }
     if (pending) {  // the rollout left the updated parameters in the other set
       double* t = tc; tc = tn; tn = t;
       t = wc; wc = wn; wn = t;
     }
     rc = r.AllReduce(G, G, (size_t)(F + 3), RCCL_FLOAT64, RCCL_SUM, comm, st);   // the ONE exchange of the update
-    if (rc != 0) return rccl_fail("ncclAllReduce", rc);
+    if (rc != 0) {
+      if (r.CommAbort) (void)r.CommAbort(comm);
+      return rccl_fail("ncclAllReduce", rc);
+    }
     double sc, sa;
     lr_schedule(first_episode + k, constant, &sc, &sa);
     plc = lr_critic * sc;
@@ -3266,7 +3295,13 @@ int mfg_train_rollouts_dist(void* comm, const float* mat_pi0, int64_t num_start,
         hipMemcpyAsync(w, wc, (size_t)F * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
       return fail(MFG_ELAUNCH, "%s", "train_rollouts_dist: parameter copy failed");
   }
-  return check_launch("train_rollouts_dist");
+  const int lrc = check_launch("train_rollouts_dist");
+  if (lrc != MFG_OK) return lrc;
+  if (!(flags & MFG_ROLLOUT_F64)) {   // what the device has reported so far (everything is enqueued: symmetric by construction)
+    unsigned bits = 0;
+    if (mfg_status(&bits) != MFG_OK && (bits & MFG_STATUS_MIXED_RANGE)) return MFG_ERANGE;
+  }
+  return MFG_OK;
 }
 
 int mfg_grad_accumulate(const float* pi, int64_t stride_b, double* delta, const double* g, const float* reward, int64_t B,

@@ -1151,14 +1151,24 @@ static int launch_reward_net_mfma(const RewardNetArgs& a, bool want_sums, int64_
   if (grid > 256) grid = 256;  // one 16-wave block per CU (LDS: 137 KB at d = 21)
   const bool sums = want_sums && grid <= max_rows;
   const size_t lds = Gm::lds_floats(a.n3, a.n4, sums) * 4;
-  static std::once_flag attr_once;  // (dynamic LDS above 64 KB; one GPU per process)
-  std::call_once(attr_once, [] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, false>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-  });
+  // dynamic LDS above 64 KB needs the attribute, which applies to the CURRENT device: once per device, result kept --
+  // a device where it failed takes the run-mapped kernels (return 1: the caller falls through)
+  static std::mutex attr_mu;
+  static signed char attr_state[64] = {0};   // 0 = not tried, 1 = ok, -1 = failed
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+    std::lock_guard<std::mutex> lock(attr_mu);
+    if (attr_state[dev] == 0) {
+      const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_state[dev] = (e1 == hipSuccess && e2 == hipSuccess) ? 1 : -1;
+      (void)hipGetLastError();
+    }
+    if (attr_state[dev] < 0) return 1;
+  }
   if (sums) {
     hipLaunchKernelGGL((k_reward_net_mfma<D, RUN, RPR, P1, true>), dim3((unsigned)grid), dim3(RM_BLOCK), lds, st, a);
     *rows_out = (int)grid;
@@ -1227,13 +1237,18 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
   const bool want_sums = sums && sums->delta0 && sums->g && sums->delta_out && sums->part_rows && grid <= sums->max_rows;
   const bool sums_ptrs = sums && sums->delta0 && sums->g && sums->delta_out && sums->part_rows;
   const bool mfma_ok = MFG_RN_MFMA && ref_geom && n3 <= 16 && (d == 21 || d == 15) && (((uintptr_t)fc3_w & 7) == 0);
+  bool mfma_done = false;
   if (mfma_ok) {
     int rows = 0;
-    if (d == 21) launch_reward_net_mfma<21, 7, 3, MFG_RM_P21>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st);
-    else launch_reward_net_mfma<15, 5, 3, MFG_RM_P15>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st);
-    if (rows_out) *rows_out = rows;
-  } else
-  if (runs_ok && d == 21) {
+    const int rc = d == 21 ? launch_reward_net_mfma<21, 7, 3, MFG_RM_P21>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st)
+                           : launch_reward_net_mfma<15, 5, 3, MFG_RM_P15>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st);
+    if (rc == 0) {
+      mfma_done = true;
+      if (rows_out) *rows_out = rows;
+    }
+  }
+  if (mfma_done) {
+  } else if (runs_ok && d == 21) {
     using Gm = RunsGeom<21, 7, 3, MFG_RN_P21, MFG_RN_P21>;
     if (want_sums) {
       hipLaunchKernelGGL((k_reward_net_runs<21, 7, 3, MFG_RN_P21, MFG_RN_P21, true>), dim3((unsigned)grid), dim3(RN_BLOCK),

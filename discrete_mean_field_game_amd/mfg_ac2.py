@@ -84,7 +84,7 @@ class actor_critic:
         self._w_alt = self._theta_alt = None
         # several GPUs over RCCL: a communicator owned by the HIP library, so that train() issues the one all-reduce per update
         # natively.  Created HERE (a one-time collective hand-shake of the ranks), not inside train().
-        self._dist_comm = native_comm(group, torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device()))
+        self._dist_comm = native_comm(group, self.device) if self.device.type == 'cuda' else None
         self._theta = torch.zeros(1, dtype=torch.float64, device=self.device)
         self._theta_is_array = False
         self.theta = theta
@@ -396,6 +396,9 @@ class actor_critic:
         # return; rollout mode: the mean over the B*T transitions of the one update, times T below)
         ep_reward = torch.zeros(max(num_episodes, 1), dtype=torch.float64, device=self.device)
         ep_base = ep_reward.data_ptr()
+        # a pending multi-rank update (self._pending) carries a raw address into ep_reward: the tensor must outlive this call
+        # if train() unwinds with the update still pending (flushed later by a read of theta / w / state_dict)
+        self._ep_reward_keepalive = ep_reward
         ret_scale = float(T) if self.update_every == 'rollout' else 1.0
         window_start = 0
         pi = None

@@ -114,40 +114,63 @@ def native_comm(group=None, device=None, allow_single=False):
     """Address of an RCCL communicator owned by the HIP library for `group` (None where it cannot be had): the multi-GPU
     episode loop then issues its one all-reduce per update itself (mfg_train_rollouts_dist) instead of returning to Python
     and torch.distributed for every episode.  Rank 0 obtains an ncclUniqueId from the library, it is broadcast through the
-    existing process group, every rank initialises the communicator on its current device.  Only for jobs whose process
-    group runs on RCCL ('nccl' backend: one GPU per rank); created once per group and kept for the life of the process."""
+    existing process group, every rank initialises the communicator on `device`.  Only for jobs whose process group runs on
+    RCCL ('nccl' backend: one GPU per rank); created once per group and kept for the life of the process.
+
+    OPT-IN (MFG_NATIVE_RCCL=1): the native loop has only ever run with one rank (no multi-GPU node was available to the
+    builds so far; RCCL refuses two ranks on one GPU), so by default the exchange stays in torch.distributed, whose
+    watchdog covers a rank that stops issuing collectives.
+
+    ncclCommInitRank is a blocking collective, so nothing rank-local may fail between "everybody agreed to try" and the
+    call: every step before it ends in an agreement (all-reduce MIN through the process group, which has the job's timeout)
+    -- symbol lookup + unique id on rank 0, then "my library resolved RCCL" on every rank -- and the call itself is bounded
+    by MFG_DIST_INIT_TIMEOUT seconds (default 60) in a helper thread; a rank that times out reports 0 in the final
+    agreement and every rank falls back to torch.distributed (the stuck thread is left behind: it holds no lock of ours)."""
     import ctypes as C
+    import threading
     from . import _lib as L
-    if not (dist.is_available() and dist.is_initialized()) or os.environ.get('MFG_NATIVE_RCCL', '1') == '0':
-        return None                                  # MFG_NATIVE_RCCL=0: keep the exchange in torch.distributed (every rank)
+    if not (dist.is_available() and dist.is_initialized()) or os.environ.get('MFG_NATIVE_RCCL', '0') != '1':
+        return None                                  # default: keep the exchange in torch.distributed (every rank)
     world = dist.get_world_size(group)
     if dist.get_backend(group) != 'nccl' or (world == 1 and not allow_single):
         return None
     key = (id(group), world)
     if key in _NATIVE_COMMS:
         return _NATIVE_COMMS[key]
+    device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
     lib = L.lib()
     rank = dist.get_rank(group)
-    buf = (C.c_char * 128)()
-    ok = torch.ones(1, dtype=torch.int32, device=device)
-    if rank == 0 and lib.mfg_dist_unique_id(buf) != 0:
-        ok.zero_()                                                   # no RCCL in this process: tell everybody
-    t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone().to(device)
     src = dist.get_global_rank(group, 0) if group is not None else 0
-    dist.broadcast(ok, src=src, group=group)
-    dist.broadcast(t, src=src, group=group)
+
+    def agree(flag):
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        return int(t.cpu()[0]) == 1
+
     comm = None
-    if int(ok.cpu()[0]) == 1:
-        idb = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
-        out = C.c_void_p()
-        torch.cuda.synchronize(device)
-        if lib.mfg_dist_init(idb, world, rank, C.byref(out)) == 0 and out.value:
-            comm = out.value
-    # a rank that failed must not leave the others using a communicator it is not part of
-    flag = torch.tensor([1 if comm else 0], dtype=torch.int32, device=device)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.cpu()[0]) == 0:
-        comm = None
+    with torch.cuda.device(device):                                     # ncclCommInitRank binds to the CURRENT device
+        buf = (C.c_char * 128)()
+        # 1. every rank's library can resolve RCCL (rank 0: and hand out an id) -- a rank that cannot says so BEFORE anybody blocks
+        mine = lib.mfg_dist_unique_id(buf) == 0 if rank == 0 else lib.mfg_dist_available() == 1
+        if agree(mine):
+            t = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone().to(device)
+            dist.broadcast(t, src=src, group=group)
+            idb = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+            out = C.c_void_p()
+            result = {}
+
+            def init():
+                with torch.cuda.device(device):
+                    result['rc'] = lib.mfg_dist_init(idb, world, rank, C.byref(out))
+            torch.cuda.synchronize(device)
+            th = threading.Thread(target=init, daemon=True)
+            th.start()
+            th.join(float(os.environ.get('MFG_DIST_INIT_TIMEOUT', '60')))
+            if not th.is_alive() and result.get('rc') == 0 and out.value:
+                comm = out.value
+            # 2. a rank that failed or timed out must not leave the others using a communicator it is not part of
+            if not agree(comm is not None):
+                comm = None
     _NATIVE_COMMS[key] = comm
     return comm
 

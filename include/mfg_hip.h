@@ -250,6 +250,7 @@ int mfg_train_rollout_deferred(const float* mat_pi0, int64_t num_start, const in
  *     trajectory id, G / count summed over the ranks) plus the second parameter set (theta_alt, w_alt) the updates
  *     ping-pong through; on return the parameters are in (theta, w) and identical on every rank. */
 typedef struct mfg_rccl_id { char bytes[128]; } mfg_rccl_id_t; /* ncclUniqueId */
+int mfg_dist_available(void); /* 1 if librccl's entry points resolve in this process, else 0 (no error recorded) */
 int mfg_dist_unique_id(mfg_rccl_id_t* id_host);
 int mfg_dist_init(const mfg_rccl_id_t* id_host, int nranks, int rank, void** comm_out);
 int mfg_dist_destroy(void* comm);

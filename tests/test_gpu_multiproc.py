@@ -109,3 +109,65 @@ def test_class_train_two_ranks_on_one_gpu(kind, mode, d, B, tmp_path):
     assert float(a[0]['theta']) != (8.86349 if kind == 'ac' else 8.64)
     assert abs(float(a[0]['theta']) - theta1) <= 1e-12 * abs(theta1)
     assert np.max(np.abs(a[0]['w'] - w1)) <= 1e-12 * np.max(np.abs(w1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Reward learning with two ranks (replicated reward network, ONE all-reduce of its flat gradient per update)
+# ---------------------------------------------------------------------------------------------------------------------
+def _irl_reward_learning(world_seed):
+    """outerloop of AC_IRL (device D_samp, HIP training step) on this rank; returns (flat reward-net parameters, theta)."""
+    sys.path.insert(0, ROOT)
+    import random
+    import torch
+    from discrete_mean_field_game_amd.ac_irl import AC_IRL
+    d = 15
+    rs = np.random.RandomState(4)
+    mat = rs.dirichlet(np.ones(d), size=6)
+    demos = [[(rs.dirichlet(np.ones(d)), rs.dirichlet(np.ones(d), size=d)) for _ in range(15)] for _ in range(7)]
+    np.random.seed(11); torch.manual_seed(11)               # identical initial weights on every rank
+    ac = AC_IRL(d=d, pi0=mat, demonstrations=demos, batch=24, num_policies=2, seed=5, reg='dropout_l1l2', verbose=0)
+    random.seed(world_seed)                                  # DIFFERENT host sampler states: _sync_host_sampler must align them
+    ac.outerloop(num_iterations=2, num_gen_from_policy=3, max_reward_iterations=12, max_forward_episodes=2, final_training=False)
+    return ac._trainer.flat.cpu().numpy().copy(), float(np.ravel(ac.theta)[0]), int(ac._trainer.step_count)
+
+
+def _child_irl(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        flat, theta, steps = _irl_reward_learning(1000 + 31 * rank)
+        np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), flat=flat, theta=theta, steps=steps)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_irl_reward_learning_two_ranks_stay_replicated(tmp_path):
+    """Two ranks, different host `random` states: after the seed hand-shake of reward_iteration they draw the same batches,
+    the gradient-only launch + all-reduce(mean) + mfg_reward_net_adam leaves bit-identical reward networks on both, and the
+    forward solves that follow (sharded batch, replicated update) end at the same theta."""
+    if not torch.cuda.is_available():
+        pytest.fail('-m gpu tests need a GPU')
+    import torch.multiprocessing as mp
+    out_dir = str(tmp_path / 'irl2')
+    os.makedirs(out_dir)
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    procs = [ctx.Process(target=_child_irl, args=(r, 2, port, out_dir)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            pytest.fail('child rank did not finish')
+        assert p.exitcode == 0
+    a, b = [np.load(os.path.join(out_dir, 'rank%d.npz' % r)) for r in range(2)]
+    assert int(a['steps']) == int(b['steps']) == 24
+    assert np.array_equal(a['flat'], b['flat']) and float(a['theta']) == float(b['theta'])
+    assert np.all(np.isfinite(a['flat']))
