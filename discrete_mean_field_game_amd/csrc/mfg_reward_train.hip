@@ -38,6 +38,7 @@ constexpr int RT_MAX_TRAJ = MFG_RN_TRAIN_MAX_TRAJ;  // per batch half (demonstra
 constexpr int RT_MAXN = 32;                          // n3, n4
 constexpr int RT_PP = 4;                             // pixels per thread, d <= 32
 constexpr int RT_QA = 8;                             // fc3 inputs per thread, f2 d^2 <= 2048
+constexpr int RT_KC = 8;                             // fc3 units whose weight columns a thread holds in registers
 
 struct RtLayout {
   int o_c1w, o_c1b, o_c2w, o_c2b, o_w3, o_b3, o_w4, o_b4, o_wo, o_bo, np;
@@ -79,6 +80,8 @@ struct RtArgs {
 // ---------------------------------------------------------------------------------------------------------------------
 // launch 1: one block per transition
 // ---------------------------------------------------------------------------------------------------------------------
+__device__ void rn_train_reg_block(const struct RtArgs& a, const RtLayout& L);
+
 // K1 / K2 / F2 > 0: compile-time conv geometry (the reference's 5 / 3 / 2: taps unroll, weights come as scalar loads,
 // the weight-gradient accumulators stay in registers); 0 = run-time geometry, tap by tap (any odd k <= 7, f2 <= 2).
 template <int K1, int K2, int F2>
@@ -92,6 +95,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
   const RtLayout L = rt_layout(d, k1, f2, k2, n3, n4);
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
   const int n = blockIdx.x;
+  if (n == (a.n_demo + a.n_gen) * a.steps) {  // the extra block
+    rn_train_reg_block(a, L);
+    return;
+  }
   // which transition: trajectory j of the batch, step t
   const int j = n / a.steps, t = n - j * a.steps;
   const bool demo = j < a.n_demo;
@@ -99,37 +106,61 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
   const float* state = (demo ? a.demo_state : a.gen_state) + tr * d;
   const float* act = (demo ? a.demo_action : a.gen_action) + tr * dd;
   const float* P = a.params;
-  // LDS carve: padded input | padded conv1 map | conv2 map (NHWC flat) | f2 padded dz2 maps
+  // LDS carve: padded input | padded conv1 map | conv2 map (NHWC flat) | f2 padded dz2 maps | every weight except fc3_w
   float* tin = smem;
   float* a1p = tin + W1 * W1;
   float* a2s = a1p + W2 * W2;
   float* dz2p = a2s + L.a2;
   const int lds_n = W1 * W1 + W2 * W2 + L.a2 + f2 * W2 * W2;
+  float* sw = smem + lds_n;  // small weights, indexed by rt_small(parameter)
+  // Every global read of this block is issued HERE, before the first use (the step is a chain of short dependent phases:
+  // a read issued where it is needed costs its full ~1 us latency every time -- the first version of this kernel spent 30 us
+  // that way, 20 of them in the two fc3 loops and in fc4 reading weights one by one from L2):
+  //   * the fc3 weight columns of this thread's inputs go to registers, RT_KC units at a time (kept for the backward pass
+  //     when n3 <= RT_KC; their latency hides behind the convolutions);
+  //   * all other weights (~180 floats) go to LDS.
+  const float* W3 = P + L.o_w3;
+  float w3r[RT_KC][RT_QA];
+#pragma unroll
+  for (int kk = 0; kk < RT_KC; ++kk)
+#pragma unroll
+    for (int q = 0; q < RT_QA; ++q) {
+      const int i = tid + q * RT_BLOCK;
+      w3r[kk][q] = (kk < n3 && i < L.a2) ? W3[(int64_t)kk * L.a2 + i] : 0.0f;
+    }
+  for (int k = tid; k < L.ns; k += RT_BLOCK) sw[k] = P[k < L.o_w3 ? k : k + (L.o_b3 - L.o_w3)];
   for (int k = tid; k < lds_n; k += RT_BLOCK) smem[k] = 0.0f;
   if (tid < d) s_state[tid] = state[tid];
-  __syncthreads();
   int py[RT_PP], px[RT_PP];
+  float actv[RT_PP];
 #pragma unroll
   for (int q = 0; q < RT_PP; ++q) {
     const int p = tid + q * RT_BLOCK;
     const int pc = p < dd ? p : 0;
     py[q] = pc / d;
     px[q] = pc - py[q] * d;
-    if (p < dd) tin[(py[q] + h1) * W1 + px[q] + h1] = act[p];
+    actv[q] = p < dd ? act[p] : 0.0f;
   }
   __syncthreads();
+#pragma unroll
+  for (int q = 0; q < RT_PP; ++q)
+    if (tid + q * RT_BLOCK < dd) tin[(py[q] + h1) * W1 + px[q] + h1] = actv[q];
+  __syncthreads();
+  // weights of the convolutions from LDS (uniform addresses: broadcast reads)
+  const float* c1w = sw + L.o_c1w;
+  const float* c2w = sw + L.o_c2w;
   // ---- forward: conv1 + ReLU
   float a1v[RT_PP];
 #pragma unroll
   for (int q = 0; q < RT_PP; ++q) {
     a1v[q] = 0.0f;
     if (tid + q * RT_BLOCK < dd) {
-      float s = P[L.o_c1b];
+      float s = sw[L.o_c1b];
       const float* tp = tin + py[q] * W1 + px[q];
 #pragma unroll
       for (int dy = 0; dy < (K1 ? K1 : k1); ++dy)
 #pragma unroll
-        for (int dx = 0; dx < (K1 ? K1 : k1); ++dx) s = fmaf(tp[dy * W1 + dx], P[L.o_c1w + dy * k1 + dx], s);
+        for (int dx = 0; dx < (K1 ? K1 : k1); ++dx) s = fmaf(tp[dy * W1 + dx], c1w[dy * k1 + dx], s);
       a1v[q] = fmaxf(s, 0.0f);
       a1p[(py[q] + h2) * W2 + px[q] + h2] = a1v[q];
     }
@@ -144,12 +175,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
 #pragma unroll
       for (int c = 0; c < (F2 ? F2 : 2); ++c) {
         if (c < f2) {
-          float s = P[L.o_c2b + c];
+          float s = sw[L.o_c2b + c];
 #pragma unroll
           for (int dy = 0; dy < (K2 ? K2 : k2); ++dy)
 #pragma unroll
             for (int dx = 0; dx < (K2 ? K2 : k2); ++dx)
-              s = fmaf(tp[dy * W2 + dx], P[L.o_c2w + c * k2 * k2 + dy * k2 + dx], s);
+              s = fmaf(tp[dy * W2 + dx], c2w[c * k2 * k2 + dy * k2 + dx], s);
           a2s[p * f2 + c] = fmaxf(s, 0.0f);
         }
       }
@@ -163,22 +194,41 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
     const int i = tid + q * RT_BLOCK;
     a2v[q] = i < L.a2 ? a2s[i] : 0.0f;
   }
-  const float* W3 = P + L.o_w3;
-  for (int k = 0; k < n3; ++k) {
-    float s = 0.0f;
+  // units in chunks of RT_KC: chunk 0 is already in registers; the sums of a chunk are reduced together (independent chains)
+  for (int k0 = 0; k0 < n3; k0 += RT_KC) {
+    float part[RT_KC];
 #pragma unroll
-    for (int q = 0; q < RT_QA; ++q) {
-      const int i = tid + q * RT_BLOCK;
-      if (i < L.a2) s = fmaf(a2v[q], W3[(int64_t)k * L.a2 + i], s);
+    for (int kk = 0; kk < RT_KC; ++kk) {
+      float sacc = 0.0f;
+      if (k0 == 0) {
+#pragma unroll
+        for (int q = 0; q < RT_QA; ++q) sacc = fmaf(a2v[q], w3r[kk][q], sacc);
+      } else if (k0 + kk < n3) {
+        float wv[RT_QA];
+#pragma unroll
+        for (int q = 0; q < RT_QA; ++q) {
+          const int i = tid + q * RT_BLOCK;
+          wv[q] = i < L.a2 ? W3[(int64_t)(k0 + kk) * L.a2 + i] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < RT_QA; ++q) sacc = fmaf(a2v[q], wv[q], sacc);
+      }
+      part[kk] = sacc;
     }
-    s = wave_sum(s);
-    if (lane == 0) red[wv][k] = s;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int kk = 0; kk < RT_KC; ++kk) part[kk] += __shfl_xor(part[kk], off, WAVE);
+    if (lane == 0)
+#pragma unroll
+      for (int kk = 0; kk < RT_KC; ++kk)
+        if (k0 + kk < n3) red[wv][k0 + kk] = part[kk];
   }
   __syncthreads();
   const bool drop = a.keep_prob < 1.0f;
   const float inv_keep = drop ? 1.0f / a.keep_prob : 1.0f;
   if (tid < n3) {
-    float z = P[L.o_b3 + tid];
+    float z = sw[rt_small(L, L.o_b3 + tid)];
 #pragma unroll
     for (int w = 0; w < RT_WAVES; ++w) z += red[w][tid];
     float h = fmaxf(z, 0.0f);
@@ -192,8 +242,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
   // ---- fc4 over [h3, state] (networks.py:72)
   const int in4 = n3 + d;
   if (tid < n4) {
-    const float* w = P + L.o_w4 + tid * in4;
-    float z = P[L.o_b4 + tid];
+    const float* w = sw + rt_small(L, L.o_w4) + tid * in4;
+    float z = sw[rt_small(L, L.o_b4 + tid)];
     for (int k = 0; k < n3; ++k) z = fmaf(s_h3[k], w[k], z);
     for (int k = 0; k < d; ++k) z = fmaf(s_state[k], w[n3 + k], z);
     float h = fmaxf(z, 0.0f);
@@ -206,8 +256,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
   __syncthreads();
   float* js = a.js + (int64_t)n * L.ns;
   if (tid == 0) {
-    float z = P[L.o_bo];
-    for (int m = 0; m < n4; ++m) z = fmaf(s_h4[m], P[L.o_wo + m], z);
+    float z = sw[rt_small(L, L.o_bo)];
+    for (int m = 0; m < n4; ++m) z = fmaf(s_h4[m], sw[rt_small(L, L.o_wo) + m], z);
     const float r = tanhf(z);
     a.r[n] = r;
     const float dzo = 1.0f - r * r;  // d r / d z_out
@@ -218,7 +268,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
   // ---- backward of THIS sample's reward (dL/dr = 1; the combine kernel scales the row)
   const float dzo = s_dzo;
   if (tid < n4) {
-    const float dz = s_h4[tid] > 0.0f ? dzo * P[L.o_wo + tid] * inv_keep : 0.0f;  // h4 > 0 <=> pre-activation > 0 and unit kept
+    const float dz = s_h4[tid] > 0.0f ? dzo * sw[rt_small(L, L.o_wo) + tid] * inv_keep : 0.0f;  // h4 > 0 <=> pre-activation > 0 and unit kept
     s_dz4[tid] = dz;
     js[rt_small(L, L.o_wo + tid)] = dzo * s_h4[tid];
     js[rt_small(L, L.o_b4 + tid)] = dz;
@@ -230,7 +280,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
   }
   if (tid < n3) {
     float dh = 0.0f;
-    for (int m = 0; m < n4; ++m) dh = fmaf(s_dz4[m], P[L.o_w4 + m * in4 + tid], dh);
+    for (int m = 0; m < n4; ++m) dh = fmaf(s_dz4[m], sw[rt_small(L, L.o_w4) + m * in4 + tid], dh);
     const float dz = s_h3[tid] > 0.0f ? dh * inv_keep : 0.0f;
     s_dz3[tid] = dz;
     js[rt_small(L, L.o_b3 + tid)] = dz;
@@ -244,7 +294,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
     const int i = tid + q * RT_BLOCK;
     if (i < L.a2) {
       float da = 0.0f;
-      for (int k = 0; k < n3; ++k) da = fmaf(s_dz3[k], W3[(int64_t)k * L.a2 + i], da);
+#pragma unroll
+      for (int kk = 0; kk < RT_KC; ++kk) da = fmaf(kk < n3 ? s_dz3[kk] : 0.0f, w3r[kk][q], da);
+      for (int k0 = RT_KC; k0 < n3; k0 += RT_KC) {   // (n3 > RT_KC: re-read, RT_KC loads in flight)
+        float wv[RT_KC];
+#pragma unroll
+        for (int kk = 0; kk < RT_KC; ++kk) wv[kk] = k0 + kk < n3 ? W3[(int64_t)(k0 + kk) * L.a2 + i] : 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < RT_KC; ++kk) da = fmaf(k0 + kk < n3 ? s_dz3[k0 + kk] : 0.0f, wv[kk], da);
+      }
       a.a2[(int64_t)n * L.a2 + i] = a2v[q];
       const float dz = a2v[q] > 0.0f ? da : 0.0f;
       const int pix = i / f2, c = i - pix * f2;
@@ -279,7 +337,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
             for (int dx = 0; dx < K2; ++dx) {
               acc[c * K2 * K2 + dy * K2 + dx] = fmaf(dzc, ap[dy * W2 + dx], acc[c * K2 * K2 + dy * K2 + dx]);
               // a1[y,x] feeds a2[c, y - dy + h2, x - dx + h2] through tap (dy, dx)
-              da1 = fmaf(P[L.o_c2w + c * K2 * K2 + dy * K2 + dx], zc[(y - dy + 2 * h2) * W2 + (x - dx + 2 * h2)], da1);
+              da1 = fmaf(c2w[c * K2 * K2 + dy * K2 + dx], zc[(y - dy + 2 * h2) * W2 + (x - dx + 2 * h2)], da1);
             }
         }
         const float dz1 = a1v[q] > 0.0f ? da1 : 0.0f;
@@ -317,7 +375,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
         for (int c = 0; c < f2; ++c)
           for (int dy = 0; dy < k2; ++dy)
             for (int dx = 0; dx < k2; ++dx)
-              da1 = fmaf(P[L.o_c2w + c * k2 * k2 + dy * k2 + dx],
+              da1 = fmaf(c2w[c * k2 * k2 + dy * k2 + dx],
                          dz2p[c * W2 * W2 + (y - dy + 2 * h2) * W2 + (x - dx + 2 * h2)], da1);
         dz1v[q] = a1v[q] > 0.0f ? da1 : 0.0f;
       }
@@ -359,19 +417,22 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
       __syncthreads();
     }
   }
-  // ---- block 0 also leaves the regulariser's value (weights are read-only in this launch)
-  if (blockIdx.x == 0) {
-    float s = 0.0f;
-    if (a.l1l2) {
-      for (int p = L.o_w3 + tid; p < L.o_b3; p += RT_BLOCK) s += fabsf(P[p]) + 0.5f * P[p] * P[p];
-      for (int p = L.o_w4 + tid; p < L.o_b4; p += RT_BLOCK) s += fabsf(P[p]) + 0.5f * P[p] * P[p];
-    }
-    __syncthreads();
-    s = wave_sum(s);
-    if (lane == 0) red[wv][0] = s;
-    __syncthreads();
-    if (tid == 0) a.reg[0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+}
+
+// the regulariser's value l1_l2(fc3_w) + l1_l2(fc4_w) (weights are read-only in launch 1): its own block, next to the samples
+__device__ void rn_train_reg_block(const RtArgs& a, const RtLayout& L) {
+  __shared__ float redr[RT_WAVES];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  const float* P = a.params;
+  float s = 0.0f;
+  if (a.l1l2) {
+    for (int p = L.o_w3 + tid; p < L.o_b3; p += RT_BLOCK) s += fabsf(P[p]) + 0.5f * P[p] * P[p];
+    for (int p = L.o_w4 + tid; p < L.o_b4; p += RT_BLOCK) s += fabsf(P[p]) + 0.5f * P[p] * P[p];
   }
+  s = wave_sum(s);
+  if (lane == 0) redr[wv] = s;
+  __syncthreads();
+  if (tid == 0) a.reg[0] = redr[0] + redr[1] + redr[2] + redr[3];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -396,19 +457,51 @@ __device__ __forceinline__ float adam_param(float p, float g, float& m, float& v
   return p - lr_t * m / (sqrtf(v) + eps);
 }
 
+// block = RT_CP consecutive parameters x RT_WAVES sample slices: wave s sums the samples n = s, s + 4, ... of the block's 64
+// parameters (coalesced: lane = parameter), RT_CU loads in flight per lane; the four slice sums meet in LDS and are added in
+// slice order (fixed association: bit-reproducible).  The first version ran one thread per parameter over all 150 samples
+// with a load and an integer division per iteration: 30 us, all of it L2 latency.
+constexpr int RT_CP = WAVE, RT_CU = 10;
 __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_combine(RtCombineArgs a) {
   __shared__ float s_c[2 * RT_MAX_TRAJ];  // dL/dr per trajectory: demonstrations, then generated
   __shared__ float s_S[RT_MAX_TRAJ];
   __shared__ float s_stat[2];
+  __shared__ double s_part[RT_WAVES][RT_CP];
+  extern __shared__ __attribute__((aligned(16))) float s_cn[];  // [N] dL/dr per sample | [N][n3] c_n dz3_n
   const RtLayout L = rt_layout(a.d, a.k1, a.f2, a.k2, a.n3, a.n4);
-  const int tid = threadIdx.x;
-  const int nd = a.n_demo, ng = a.n_gen, T = a.steps;
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
+  const int nd = a.n_demo, ng = a.n_gen, T = a.steps, n3 = a.n3;
+  const int N = (nd + ng) * T;
+  float* s_cdz = s_cn + N;
+  // issue the block's first loads before the coefficient phase needs anything
+  float r_mine[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int n = tid + u * RT_BLOCK;
+    r_mine[u] = n < N ? a.r[n] : 0.0f;
+  }
+  if (tid < ng) s_S[tid] = 0.0f;
+  __syncthreads();
+  // S_j = sum_t r[j, t]: one thread per generated trajectory would read 15 values one after the other; N <= 1920 = 8 x 256
+  // values are already in registers, so trajectory sums go through LDS in step order (fixed association per trajectory)
+#pragma unroll
+  for (int u = 0; u < 8; ++u) s_cn[(tid + u * RT_BLOCK) < N ? tid + u * RT_BLOCK : 0] = 0.0f;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (tid + u * RT_BLOCK < N) s_cn[tid + u * RT_BLOCK] = r_mine[u];
+  __syncthreads();
   if (tid < ng) {
-    float s = 0.0f;
-    for (int t = 0; t < T; ++t) s += a.r[(nd + tid) * T + t];
-    s_S[tid] = s;
+    float sacc = 0.0f;
+    for (int t = 0; t < T; ++t) sacc += s_cn[(nd + tid) * T + t];
+    s_S[tid] = sacc;
   }
   if (tid < nd) s_c[tid] = -a.demo_scale;
+  float sd = 0.0f;
+  if (tid == 64) {  // (another wave than the soft-max below) first term: sum of the demonstration rewards
+    for (int n = 0; n < nd * T; ++n) sd += s_cn[n];
+    s_stat[1] = sd;
+  }
   __syncthreads();
   if (tid == 0) {
     float mx = -INFINITY;
@@ -419,19 +512,42 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_combine(RtCombineArgs a) 
     s_stat[0] = ng ? mx + logf(z / (float)ng) : 0.0f;  // = log( 1/M sum exp S_j )
   }
   __syncthreads();
-  const int N = (nd + ng) * T;
-  const int p = blockIdx.x * RT_BLOCK + tid;
+  // per-sample coefficient, and c_n dz3_n for the factored fc3_w gradient
+  for (int n = tid; n < N; n += RT_BLOCK) s_cn[n] = s_c[n / T];
+  __syncthreads();
+  const int p0 = blockIdx.x * RT_CP;
+  const bool any_w3 = p0 + RT_CP > L.o_w3 && p0 < L.o_b3;
+  if (any_w3) {
+    for (int e = tid; e < N * n3; e += RT_BLOCK) s_cdz[e] = s_cn[e / n3] * a.dz3[e];
+    __syncthreads();
+  }
+  const int p = p0 + lane;
+  // the sum over the batch runs in fp64: its terms (demonstrations -, generated +) cancel to a small net value, and an
+  // fp32 running sum would leave ~1e-7 of the LARGEST partial sum in it
+  double gs = 0.0;
   if (p < L.np) {
-    // the sum over the batch runs in fp64: its terms (demonstrations -, generated +) cancel to a small net value, and an
-    // fp32 running sum would leave ~1e-7 of the LARGEST partial sum in it
-    double gs = 0.0;
-    if (p >= L.o_w3 && p < L.o_b3) {
-      const int k = (p - L.o_w3) / L.a2, i = (p - L.o_w3) - k * L.a2;
-      for (int n = 0; n < N; ++n) gs = fma((double)(s_c[n / T] * a.dz3[n * a.n3 + k]), (double)a.a2[(int64_t)n * L.a2 + i], gs);
-    } else {
-      const int ps = rt_small(L, p);
-      for (int n = 0; n < N; ++n) gs = fma((double)s_c[n / T], (double)a.js[(int64_t)n * L.ns + ps], gs);
+    const bool w3 = p >= L.o_w3 && p < L.o_b3;
+    const int k = w3 ? (p - L.o_w3) / L.a2 : 0;
+    const float* src = w3 ? a.a2 + ((p - L.o_w3) - k * L.a2) : a.js + rt_small(L, p);
+    const int64_t stride = w3 ? L.a2 : L.ns;
+    for (int n0 = wv; n0 < N; n0 += RT_WAVES * RT_CU) {
+      float x[RT_CU];
+#pragma unroll
+      for (int u = 0; u < RT_CU; ++u) {
+        const int n = n0 + u * RT_WAVES;
+        x[u] = n < N ? src[(int64_t)n * stride] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < RT_CU; ++u) {
+        const int n = n0 + u * RT_WAVES;
+        if (n < N) gs = fma((double)(w3 ? s_cdz[n * n3 + k] : s_cn[n]), (double)x[u], gs);
+      }
     }
+  }
+  s_part[wv][lane] = gs;
+  __syncthreads();
+  if (wv == 0 && p < L.np) {
+    gs = ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane];
     const float w = a.params[p];
     if (a.l1l2 && ((p >= L.o_w3 && p < L.o_b3) || (p >= L.o_w4 && p < L.o_b4)))
       gs += (double)((w > 0.0f ? 1.0f : (w < 0.0f ? -1.0f : 0.0f)) + w);  // d/dw (|w| + w^2 / 2)
@@ -445,9 +561,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_combine(RtCombineArgs a) 
     }
   }
   if (blockIdx.x == 0 && tid == 0 && a.stats) {
-    float sd = 0.0f;
-    for (int n = 0; n < nd * T; ++n) sd += a.r[n];
-    const float first = -a.demo_scale * sd, second = s_stat[0], reg = a.l1l2 ? a.reg[0] : 0.0f;
+    const float first = -a.demo_scale * s_stat[1], second = s_stat[0], reg = a.l1l2 ? a.reg[0] : 0.0f;
     a.stats[0] = first + second + reg;
     a.stats[1] = first;
     a.stats[2] = second;
@@ -546,11 +660,11 @@ int mfg_reward_net_train_step(float* params, float* adam_m, float* adam_v, int d
   }
   hipStream_t st = (hipStream_t)stream;
   const int h1 = k1 / 2, h2 = k2 / 2, W1 = d + 2 * h1, W2 = d + 2 * h2;
-  const size_t lds = (size_t)(W1 * W1 + W2 * W2 + L.a2 + f2 * W2 * W2) * sizeof(float);
+  const size_t lds = (size_t)(W1 * W1 + W2 * W2 + L.a2 + f2 * W2 * W2 + L.ns) * sizeof(float);
   if (k1 == 5 && k2 == 3 && f2 == 2)
-    hipLaunchKernelGGL((k_rn_train_sample<5, 3, 2>), dim3((unsigned)N), dim3(RT_BLOCK), lds, st, a);
+    hipLaunchKernelGGL((k_rn_train_sample<5, 3, 2>), dim3((unsigned)N + 1), dim3(RT_BLOCK), lds, st, a);
   else
-    hipLaunchKernelGGL((k_rn_train_sample<0, 0, 0>), dim3((unsigned)N), dim3(RT_BLOCK), lds, st, a);
+    hipLaunchKernelGGL((k_rn_train_sample<0, 0, 0>), dim3((unsigned)N + 1), dim3(RT_BLOCK), lds, st, a);
   RtCombineArgs c{};
   c.params = params; c.m = adam_m; c.v = adam_v; c.grad = grad; c.stats = stats;
   c.r = a.r; c.a2 = a.a2; c.dz3 = a.dz3; c.js = a.js; c.reg = a.reg;
@@ -561,7 +675,7 @@ int mfg_reward_net_train_step(float* params, float* adam_m, float* adam_v, int d
   c.apply = apply ? 1 : 0;
   if (apply) c.lr_t = adam_lr_t(lr, beta1, beta2, adam_step);
   c.beta1 = (float)beta1; c.beta2 = (float)beta2; c.eps = (float)eps;
-  hipLaunchKernelGGL(k_rn_train_combine, dim3((unsigned)((L.np + RT_BLOCK - 1) / RT_BLOCK)), dim3(RT_BLOCK), 0, st, c);
+  hipLaunchKernelGGL(k_rn_train_combine, dim3((unsigned)((L.np + RT_CP - 1) / RT_CP)), dim3(RT_BLOCK), (size_t)N * (1 + n3) * sizeof(float), st, c);
   return hipGetLastError() == hipSuccess ? MFG_OK : set_error(MFG_ELAUNCH, "reward_net_train_step: launch failed");
 }
 
