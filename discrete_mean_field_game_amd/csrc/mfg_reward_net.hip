@@ -15,6 +15,7 @@
 
 #include "../../include/mfg_hip.h"
 #include "mfg_core.h"
+#include "mfg_rn_common.h"
 
 namespace mfg {
 
@@ -38,7 +39,20 @@ struct RewardNetArgs {
   const double* gsc;
   double* delta_out;
   double* part_rows;  // [gridDim.x][F+3]
+  // states inside a rollout's pi_traj [B', T+1, d]: sample n = (b', t) reads row b' (T+1) + t (state_T = T; 0: plain [B,d])
+  int state_T;
+  // SUMS + in-kernel finish (matrix-core kernel): the last block to finish adds the partial rows in row order, writes G and
+  // applies the update (w += lr_c G_w / N, theta += lr_a G_theta / N, *reward_acc += sum r / N) -- the step is then two launches
+  unsigned* fin_counter;  // zero before the launch, reset by the finishing block; NULL: no finish
+  double* fin_G;          // [F+3]
+  double fin_lr_c, fin_lr_a;
+  double *fin_w, *fin_theta, *fin_reward_acc;
 };
+__device__ __forceinline__ int64_t rn_state_row(const RewardNetArgs& a, int64_t b) {
+  if (a.state_T <= 0) return b;
+  const int64_t q = b / a.state_T;
+  return q * (a.state_T + 1) + (b - q * a.state_T);
+}
 
 #ifndef MFG_RN_WAVES
 #define MFG_RN_WAVES 8
@@ -217,7 +231,7 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
       const int o = lane < n4 ? lane : 0;
       float s = s_b4[o];
       for (int k = 0; k < n3; ++k) s = fmaf(__shfl(h3_mine, k, WAVE), s_w4[o * (n3 + d) + k], s);
-      const float* st = a.state + b * d;
+      const float* st = a.state + rn_state_row(a, b) * d;
       for (int k = 0; k < d; ++k) s = fmaf(st[k], s_w4[o * (n3 + d) + n3 + k], s);
       h4 = fmaxf(s, 0.0f);
       if (drop) h4 = (__shfl(u_drop, 32 + o, WAVE) <= a.keep_prob) ? h4 * inv_keep : 0.0f;
@@ -241,51 +255,7 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net(RewardNetArgs a) {
 // the DPP path instead of ds_bpermute, and the conv weights sit in scalar registers.
 // ---------------------------------------------------------------------------------------------
 // (dpp_mov_f32 lives in mfg_device.h)
-__device__ __forceinline__ float wave_sum_f32_dpp(float v) {
-  v += dpp_mov_f32<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-  v += dpp_mov_f32<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-  v += dpp_mov_f32<0x141, 0xF>(v);  // row_half_mirror
-  v += dpp_mov_f32<0x140, 0xF>(v);  // row_mirror
-  v += dpp_mov_f32<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
-  v += dpp_mov_f32<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
-// Four wave sums advancing together: lane 63 ends up with the four totals.  One block of 24 DPP adds -- every step's four
-// instructions are independent and separate an instruction from the one that reads its result (the two wait states a DPP
-// source needs); the last two steps add lane 15 / 31 of the previous rows into rows {1, 3} / {2, 3} in place (as separate
-// move + add they are three instructions each).
-__device__ __forceinline__ void wave_sum4_to_lane63(float (&v)[4]) {
-  asm volatile(
-      "s_nop 1\n"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:0\n"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-      "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %2, %2, %2 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "v_add_f32_dpp %3, %3, %3 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-      "s_nop 1\n"
-      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
-}
-
+// (wave_sum_f32_dpp / wave_sum4_to_lane63: mfg_rn_common.h)
 template <int D, int RUN, int RPR, int P1, int P2>
 struct RunsGeom {
   static_assert(RUN * RPR == D && D * RPR <= WAVE, "runs must tile a row exactly and fit one wavefront");
@@ -432,7 +402,7 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
   double d0_next = 0.0, g_next = 0.0;
 #pragma unroll
   for (int q = 0; q < PP; ++q) av[q] = (b < a.B && lane + q * WAVE < DD) ? a.action[b * DD + lane + q * WAVE] : 0.0f;
-  if (b < a.B && lane >= n3 && lane < nin) st_mine = a.state[b * D + (lane - n3)];
+  if (b < a.B && lane >= n3 && lane < nin) st_mine = a.state[rn_state_row(a, b) * D + (lane - n3)];
   if (SUMS && b < a.B) {
     d0_next = a.delta0[b];
     g_next = a.gsc[b];
@@ -449,7 +419,7 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
       const int64_t bn = b + nw;
 #pragma unroll
       for (int q = 0; q < PP; ++q) av[q] = (bn < a.B && lane + q * WAVE < DD) ? a.action[bn * DD + lane + q * WAVE] : 0.0f;
-      if (bn < a.B && lane >= n3 && lane < nin) st_mine = a.state[bn * D + (lane - n3)];
+      if (bn < a.B && lane >= n3 && lane < nin) st_mine = a.state[rn_state_row(a, bn) * D + (lane - n3)];
       if (SUMS && bn < a.B) {
         d0_next = a.delta0[bn];
         g_next = a.gsc[bn];
@@ -611,8 +581,6 @@ __global__ __launch_bounds__(RN_BLOCK) void k_reward_net_runs(RewardNetArgs a) {
 #define MFG_RM_P15 21
 #endif
 constexpr int RM_WAVES = 16, RM_BLOCK = RM_WAVES * WAVE, RM_RED = 260;  // RM_RED: floats per wave's partial (= 4 mod 64 x 4)
-typedef float rn_v4f_t __attribute__((ext_vector_type(4)));
-typedef float rn_v2f_t __attribute__((ext_vector_type(2)));
 typedef float rn_v4f_u __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte global access at any 4-byte address
 
 // Entry k of the row [sum delta phi | sum delta g | sum r | count]: positions of its two factors in the line [state | 1]
@@ -678,20 +646,7 @@ struct MfmaGeom {
   }
 };
 
-typedef const __attribute__((address_space(4))) float* RnConstF;  // read-only global memory: uniform reads are scalar loads
-// max(x, 0) in ONE instruction (fmaxf first quiets a signalling NaN with a v_max_f32 x, x, x of its own)
-__device__ __forceinline__ float relu_f32(float x) {
-  float r;
-  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
-// wave shifts by one lane (DPP wave_shr:1 / wave_shl:1): lane l takes the value of lane l - 1 / l + 1
-__device__ __forceinline__ float lane_below(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float lane_above(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xF, 0xF, true));
-}
+// (RnConstF, relu_f32, lane_below / lane_above: mfg_rn_common.h)
 
 // Developer build (-DMFG_RN_STAMPS, tools/rn_stamps.py): shader-clock stamps of the phases of blocks 0 and 100, every wave,
 // first group; read back with mfg_debug_rn_stamps.
@@ -744,7 +699,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
       av[q] = ok ? v : 0.0f;
     }
     const bool st_ok = b < a.B && lane >= n3 && lane < nin;
-    const float sv = a.state[bc * D + (lane >= n3 && lane < nin ? lane - n3 : 0)];
+    const float sv = a.state[rn_state_row(a, bc) * D + (lane >= n3 && lane < nin ? lane - n3 : 0)];
     st_mine = st_ok ? sv : 0.0f;
     if constexpr (SUMS) {
       d0_next = a.delta0[bc];
@@ -901,7 +856,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
         const float* src = a.action + bn * DD;
 #pragma unroll
         for (int q = 0; q < PP; ++q) av[q] = src[(q + 1) * WAVE <= DD ? lane + q * WAVE : (ln + q * WAVE < DD ? lane + q * WAVE : 0)];
-        st_mine = a.state[bn * D + (ln >= n3 && ln < nin ? lane - n3 : 0)];
+        st_mine = a.state[rn_state_row(a, bn) * D + (ln >= n3 && ln < nin ? lane - n3 : 0)];
         if constexpr (SUMS) {
           d0_next = a.delta0[bn];
           g_next = a.gsc[bn];
@@ -1137,6 +1092,67 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
       for (int w_ = 1; w_ < RM_WAVES; ++w_) t += rows[w_ * FO + k];
       a.part_rows[(int64_t)blockIdx.x * FO + k] = t;
     }
+    if (a.fin_counter) {
+      // The last block to finish adds the rows (the separate row-reduction launch cost 5.3 us per env step for 512 KB of
+      // dependent L2 reads; here every one of a thread's <= 64 row reads is in flight at once, one latency in all).
+      // thread = (column k = tid % 256, slice q = tid / 256 of four): rows q, q + 4, ... in order, four running sums; the
+      // slices are combined in slice order: a fixed association, bit-reproducible.
+      static_assert(FO <= 256 && RM_BLOCK == 1024, "finish: one column per thread of a 256-thread slice");
+      __shared__ int s_last;
+      // ONE device-scope release per block, by the thread that signals (behind the barrier: the block's row is complete and
+      // ordered before it).  Every wave of every block fencing on its own -- 4 096 L2 write-backs across the eight XCDs --
+      // made this launch 89 us instead of 12.
+      __syncthreads();
+      if (tid == 0) {
+        __threadfence();
+        s_last = (atomicAdd(a.fin_counter, 1u) == gridDim.x - 1) ? 1 : 0;
+      }
+      __syncthreads();
+      if (s_last) {
+        __threadfence();
+        const int k = tid & 255, q = tid >> 8, nrows = (int)gridDim.x;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (k < FO) {
+          // (32 reads in flight per round: the block's 1 024 threads leave 128 registers each)
+#pragma unroll 1
+          for (int u0 = 0; u0 < 64; u0 += 32) {
+            double v[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+              const int r = q + 4 * (u0 + u);
+              v[u] = r < nrows ? a.part_rows[(int64_t)r * FO + k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 32; u += 4) {
+              s0 += v[u];
+              s1 += v[u + 1];
+              s2 += v[u + 2];
+              s3 += v[u + 3];
+            }
+          }
+        }
+        double* fin = rows;  // (the waves' rows were consumed above, behind the barriers)
+        fin[q * 256 + k] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        double* gk = fin + 1024;
+        if (tid < FO) {
+          const double tot = ((fin[tid] + fin[256 + tid]) + fin[512 + tid]) + fin[768 + tid];
+          a.fin_G[tid] = tot;
+          gk[tid] = tot;
+        }
+        __syncthreads();
+        const double count = gk[Fs + 2];
+        if (a.fin_w && count > 0.0) {
+          const double inv = 1.0 / count;
+          if (tid < Fs) a.fin_w[tid] = updated_param(a.fin_w[tid], a.fin_lr_c, gk[tid], inv);
+          if (tid == 0) {
+            if (a.fin_reward_acc) *a.fin_reward_acc += gk[Fs + 1] * inv;
+            *a.fin_theta = updated_param(*a.fin_theta, a.fin_lr_a, gk[Fs], inv);
+          }
+        }
+        if (tid == 0) *a.fin_counter = 0u;
+      }
+    }
   }
 #ifdef MFG_RN_STAMPS
   first_pass = true;
@@ -1145,7 +1161,8 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
 }
 
 template <int D, int RUN, int RPR, int P1>
-static int launch_reward_net_mfma(const RewardNetArgs& a, bool want_sums, int64_t max_rows, int* rows_out, hipStream_t st) {
+static int launch_reward_net_mfma(const RewardNetArgs& a, bool want_sums, int64_t max_rows, int* rows_out, hipStream_t st,
+                                  const RnFinish* fin = nullptr) {
   using Gm = MfmaGeom<D, RUN, RPR, P1>;
   int64_t grid = (a.B + RM_WAVES - 1) / RM_WAVES;
   if (grid > 256) grid = 256;  // one 16-wave block per CU (LDS: 137 KB at d = 21)
@@ -1161,17 +1178,27 @@ static int launch_reward_net_mfma(const RewardNetArgs& a, bool want_sums, int64_
     std::lock_guard<std::mutex> lock(attr_mu);
     if (attr_state[dev] == 0) {
       const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);  // (the SUMS variant also holds a few static bytes)
       const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);  // (the SUMS variant also holds a few static bytes)
       attr_state[dev] = (e1 == hipSuccess && e2 == hipSuccess) ? 1 : -1;
       (void)hipGetLastError();
     }
     if (attr_state[dev] < 0) return 1;
   }
   if (sums) {
-    hipLaunchKernelGGL((k_reward_net_mfma<D, RUN, RPR, P1, true>), dim3((unsigned)grid), dim3(RM_BLOCK), lds, st, a);
-    *rows_out = (int)grid;
+    RewardNetArgs af = a;
+    if (fin && fin->counter) {
+      af.fin_counter = fin->counter;
+      af.fin_G = fin->G;
+      af.fin_lr_c = fin->lr_c;
+      af.fin_lr_a = fin->lr_a;
+      af.fin_w = fin->w;
+      af.fin_theta = fin->theta;
+      af.fin_reward_acc = fin->reward_acc;
+    }
+    hipLaunchKernelGGL((k_reward_net_mfma<D, RUN, RPR, P1, true>), dim3((unsigned)grid), dim3(RM_BLOCK), lds, st, af);
+    *rows_out = (fin && fin->counter) ? -(int)grid : (int)grid;   // negative: rows reduced and applied by the launch itself
   } else {
     hipLaunchKernelGGL((k_reward_net_mfma<D, RUN, RPR, P1, false>), dim3((unsigned)grid), dim3(RM_BLOCK), lds, st, a);
   }
@@ -1189,7 +1216,7 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
                             const float* conv1_w, const float* conv1_b, const float* conv2_w, const float* conv2_b,
                             const float* fc3_w, const float* fc3_b, const float* fc4_w, const float* fc4_b,
                             const float* out_w, const float* out_b, float keep_prob, uint64_t seed, uint64_t sample_offset,
-                            float* reward, const RnSums* sums, int* rows_out, mfg_stream_t stream) {
+                            float* reward, const RnSums* sums, int* rows_out, mfg_stream_t stream, int state_T) {
   if (rows_out) *rows_out = 0;
   if (B < 0 || d < 1 || !state || !action || !reward || !conv1_w || !conv1_b || !conv2_w || !conv2_b || !fc3_w ||
       !fc3_b || !fc4_w || !fc4_b || !out_w || !out_b)
@@ -1201,6 +1228,8 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
   if (B == 0) return MFG_OK;
   RewardNetArgs a{state, action, B, d, k1, f2, k2, n3, n4, conv1_w, conv1_b, conv2_w, conv2_b, fc3_w, fc3_b,
                   fc4_w, fc4_b, out_w, out_b, keep_prob, seed, sample_offset, reward, 0, nullptr, nullptr, nullptr, nullptr};
+  a.fin_counter = nullptr;
+  a.state_T = state_T;
   if (sums) {
     a.delta0 = sums->delta0;
     a.gsc = sums->g;
@@ -1240,8 +1269,8 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
   bool mfma_done = false;
   if (mfma_ok) {
     int rows = 0;
-    const int rc = d == 21 ? launch_reward_net_mfma<21, 7, 3, MFG_RM_P21>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st)
-                           : launch_reward_net_mfma<15, 5, 3, MFG_RM_P15>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st);
+    const int rc = d == 21 ? launch_reward_net_mfma<21, 7, 3, MFG_RM_P21>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st, sums ? sums->finish : nullptr)
+                           : launch_reward_net_mfma<15, 5, 3, MFG_RM_P15>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st, sums ? sums->finish : nullptr);
     if (rc == 0) {
       mfma_done = true;
       if (rows_out) *rows_out = rows;
@@ -1282,7 +1311,7 @@ extern "C" int mfg_reward_net_forward(const float* state, const float* action, i
                                       const float* fc4_b, const float* out_w, const float* out_b, float keep_prob,
                                       uint64_t seed, uint64_t sample_offset, float* reward, mfg_stream_t stream) {
   return mfg::reward_net_forward_sums(state, action, B, d, k1, f2, k2, n3, n4, conv1_w, conv1_b, conv2_w, conv2_b, fc3_w, fc3_b,
-                                      fc4_w, fc4_b, out_w, out_b, keep_prob, seed, sample_offset, reward, nullptr, nullptr, stream);
+                                      fc4_w, fc4_b, out_w, out_b, keep_prob, seed, sample_offset, reward, nullptr, nullptr, stream, 0);
 }
 
 #ifdef MFG_RN_STAMPS
