@@ -357,9 +357,10 @@ def main():
                       'world': world, 'payload_bytes': (Fc + 3) * 8, 'all_reduce_us': t_ar * 1e6,
                       'all_reduce_plus_apply_update_us': t_upd * 1e6,
                       'native_all_reduce_us': (t_nat * 1e6 if t_nat is not None else None),
-                      'note': 'the timed training legs exchange G through the HIP library\'s own RCCL communicator '
-                              '(mfg_train_rollouts_dist: native episode loop, update applied inside the next rollout) when the '
-                              'backend is nccl; all_reduce_us is the same buffer through torch.distributed for comparison'}
+                      'note': 'the timed training legs exchange G through torch.distributed (one all-reduce per update, the update '
+                              'applied inside the next rollout kernel); MFG_NATIVE_RCCL=1 moves the exchange into the HIP library\'s '
+                              'own RCCL communicator (mfg_train_rollouts_dist, native episode loop) -- opt-in until a run with more '
+                              'than one rank has validated it; native_all_reduce_us is measured only then'}
 
     out = None
     if rank == 0:

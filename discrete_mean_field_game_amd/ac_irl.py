@@ -264,8 +264,15 @@ class AC_IRL(actor_critic):
             ebufs = {'pi_traj': torch.empty(Bl, T + 1, d, dtype=torch.float32, device=self.device),
                      'pi_last': torch.empty(Bl, d, dtype=torch.float32, device=self.device),
                      'P': torch.empty(Bl, T, d, d, dtype=torch.float32, device=self.device),
+                     'reward': torch.empty(Bl * T, dtype=torch.float32, device=self.device),
                      'delta': torch.empty(Bl, T, dtype=torch.float64, device=self.device),
                      'g': torch.empty(Bl, T, dtype=torch.float64, device=self.device)}
+        # ... and with the reward network's HIP kernel on one GPU the whole episode is ONE native call (mfg_train_rollout_irl:
+        # start states drawn inside the rollout kernel, the network reads its states in place from pi_traj, sums + update)
+        native_rollout = (fused_episode and shard.world == 1 and reward_fn is None and self.trace is None
+                          and self.reward_net is not None and ops.reward_net_supported(self.reward_net)
+                          and self._device_draw())
+        ep_acc = torch.zeros(max_episodes + 1, dtype=torch.float64, device=self.device) if native_rollout else None
         # per-step updates on one GPU with the reward network's HIP kernel: the whole episode (15 x [sample + transition +
         # score | reward net | batch sums + update]) is issued by native code (mfg_train_episode_irl)
         native_episode = (self.update_every == 'step' and self.rng == 'philox' and shard.world == 1 and reward_fn is None
@@ -279,13 +286,37 @@ class AC_IRL(actor_critic):
         pi = None
         device_draw = self._device_draw()       # batched Philox runs: start states drawn on the device (mfg_draw_start)
         for episode in range(1 + first_episode, first_episode + max_episodes + 1):
+            sc, sa = lr_scales(episode, constant)          # lr/(episode+1) with the 1-indexed episode (:700)
+            if native_rollout:
+                self._reward_calls += 1                    # the keys of ONE reward() call over the [B*T] transitions
+                key = ((self.seed + 0x5EED) ^ (self._reward_calls * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+                total_reward = ep_acc[episode - first_episode:episode - first_episode + 1]
+                ops.train_rollout_irl(self._mat_pi0_dev, None, T, self._theta, self.shift, self.alpha_scale, self._w, gamma,
+                                      lr_critic * sc, lr_actor * sa, self.reward_net, G, ws_ep, ebufs, seed=self.seed,
+                                      first_step=self._rng_step, traj_offset=shard.traj_offset, rn_key=key,
+                                      rn_sample_offset=shard.traj_offset * T, reward_acc=total_reward, precision=self.precision)
+                self._rng_step += T
+                self._reward_sample_offset = shard.traj_offset * T
+                self._theta_is_array = True
+                pi = ebufs['pi_last']
+                list_reward.append(total_reward)           # (mean reward per transition; scaled by T where it is reported)
+                if self.check_finite:
+                    self._raise_if_not_finite(pi, episode)
+                if episode % consecutive == 0:
+                    self._report_irl(list_reward, consecutive, pi, write_file, file_theta, file_pi, file_reward, scale=float(T))
+                    list_reward = []
+                if stop_criteria != -1:
+                    cur = float(self._theta.cpu()[0])
+                    if abs(cur - prev_theta) < stop_criteria:
+                        break
+                    prev_theta = cur
+                continue
             if device_draw:
                 _, pi = ops.draw_start(self._mat_pi0_dev, Bl, self.seed, self._rng_step, shard.traj_offset)
             else:
                 pi = ops.gather_start(self._mat_pi0_dev, self._draw_start(shard))       # ac_irl.py:655
             discount = 1.0
             total_reward = torch.zeros(1, dtype=torch.float64, device=self.device)
-            sc, sa = lr_scales(episode, constant)          # lr/(episode+1) with the 1-indexed episode (:700)
             if fused_episode:
                 # one update per episode: theta and w are fixed over the 15 steps, so the whole episode is THREE launches:
                 # the fused rollout (running discount gamma^t, P of every step materialised for the network), one
@@ -369,17 +400,8 @@ class AC_IRL(actor_critic):
             if self.check_finite:
                 self._raise_if_not_finite(pi, episode)
             if episode % consecutive == 0:
-                reward_avg = float(torch.cat(list_reward).sum().cpu()) / consecutive
+                self._report_irl(list_reward, consecutive, pi, write_file, file_theta, file_pi, file_reward)
                 list_reward = []
-                pi_host = pi[0].cpu().numpy().astype(np.float64)
-                if self.verbose:
-                    print('Theta\n', self.theta)
-                    print('pi\n', pi_host)
-                    print('Average reward during previous %d episodes: ' % consecutive, str(reward_avg))
-                if write_file:
-                    self.train_log(np.ravel(self.theta), file_theta, '%.5e')
-                    self.train_log(pi_host, file_pi, '%.3e')
-                    self.train_log(np.array([reward_avg]), file_reward, '%.3e')
             if stop_criteria != -1:
                 cur = float(self._theta.cpu()[0])
                 if abs(cur - prev_theta) < stop_criteria:
@@ -390,6 +412,19 @@ class AC_IRL(actor_critic):
         self._check_status()
         if self.verbose:
             print('----- Exiting train at episode %d with theta %f -----' % (episode, float(np.ravel(self.theta)[0])))
+
+    def _report_irl(self, list_reward, consecutive, pi, write_file, file_theta, file_pi, file_reward, scale=1.0):
+        """The `consecutive`-episode report of train() (ac_irl.py:714-724): average episode return, theta, one final state."""
+        reward_avg = float(torch.cat(list_reward).sum().cpu()) * scale / consecutive
+        pi_host = pi[0].cpu().numpy().astype(np.float64)
+        if self.verbose:
+            print('Theta\n', self.theta)
+            print('pi\n', pi_host)
+            print('Average reward during previous %d episodes: ' % consecutive, str(reward_avg))
+        if write_file:
+            self.train_log(np.ravel(self.theta), file_theta, '%.5e')
+            self.train_log(pi_host, file_pi, '%.3e')
+            self.train_log(np.array([reward_avg]), file_reward, '%.3e')
 
     # ------------------------------------------------------------------ a10
     def generate_trajectories(self, n, from_test=False):

@@ -15,10 +15,6 @@ namespace mfg {
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / WAVE;
 
-}  // namespace mfg
-#include "mfg_rn_fused.h"
-namespace mfg {
-
 struct CoreArgs {
   const float* pi0;         // [B,d]; or, with start_idx != NULL, the start-state table [num_start,d]
   const int32_t* start_idx; // [B] rows of the table (start-state gather folded into the kernel, mfg_ac2.py:466-469)
@@ -55,7 +51,6 @@ struct CoreArgs {
   double* w_out;
   double* theta_out;
   double* pend_reward_acc;
-  RnFusedArgs rn;  // IRL: the reward network evaluated inside the packed kernel (k_core_small<..., RN>; mfg_rn_fused.h)
 #ifdef MFG_TIMING
   unsigned long long* dbg;  // timing variant only (tools/phase_timing.py): s_memtime stamps of block 0, wave 0
 #endif
@@ -75,20 +70,12 @@ int set_error(int code, const char* msg);  // records mfg_last_error() (defined 
 
 // IRL env step: reward network + the batch sums of the TD update over the same samples in one launch
 // (mfg_reward_net.hip; used by mfg_train_episode_irl)
-// in-kernel finish of the SUMS launch (matrix-core kernel): the last block reduces the rows into G and applies the update
-struct RnFinish {
-  unsigned* counter;  // device word, zero before the launch (the workspace's control block)
-  double* G;
-  double lr_c, lr_a;
-  double *w, *theta, *reward_acc;
-};
 struct RnSums {
   const double* delta0;  // [B] discount V(pi') - V(pi) from the step kernel
   const double* g;       // [B] scores
   double* delta_out;     // [B] delta = delta0 + r (may alias delta0)
   double* part_rows;     // [max_rows][F+3]
   int64_t max_rows;
-  const RnFinish* finish;  // NULL: the caller reduces the rows (k_reduce_partials)
 };
 int reward_net_forward_sums(const float* state, const float* action, int64_t B, int d, int k1, int f2, int k2, int n3, int n4,
                             const float* conv1_w, const float* conv1_b, const float* conv2_w, const float* conv2_b,
@@ -98,7 +85,6 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
 
 // launchers defined in mfg_core_small.hip / mfg_core_large_*.hip; return 0 or MFG_EUNSUPPORTED
 int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st);
-void launch_core_small_rn(const CoreArgs& a, int num_cus, size_t lds, hipStream_t st);  // mfg_core_small_rn.hip (d = 21 / 15)
 int launch_core_large_f64(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st);
 int launch_core_large_mixed(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st);
 
@@ -426,13 +412,11 @@ __device__ __forceinline__ double value_wave(const float* pis, const double* __r
 // partial row in a.part_rows: the separate gradient kernel (a launch, a re-read of pi / delta / g / reward, a
 // fence-and-last-block finish: 10.6 us per env step at B = 4 096) shrinks to the row reduction.  Register budget of two
 // waves per SIMD (the three-wave cap spills 31 registers here); used while all tiles are resident at that occupancy.
-// RN (IRL, compile-time d = 21 / 15, reward_kind EXTERNAL): the wave evaluates the reward network on its own tiles behind the
-// column pass (mfg_rn_fused.h) and the reward joins delta in the same step; two-wave register budget like SUMS.
-template <bool SAMPLE, bool TD, bool FAST, int D, bool SUMS = false, bool RN = false>
+template <bool SAMPLE, bool TD, bool FAST, int D, bool SUMS = false>
 #ifndef MFG_CORE_SMALL_WAVES_F64
 #define MFG_CORE_SMALL_WAVES_F64 3  // strict precision: 227 registers wanted; at 168 the third wave still pays (5.95 -> 5.80 ms at the bench shape)
 #endif
-__global__ __launch_bounds__(BLOCK, (SUMS || RN) ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MFG_CORE_SMALL_WAVES_F64)) void k_core_small(CoreArgs a) {
+__global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MFG_CORE_SMALL_WAVES_F64)) void k_core_small(CoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   MFG_STAMP0(8)
   MFG_STAMPB(0)
@@ -466,11 +450,6 @@ __global__ __launch_bounds__(BLOCK, (SUMS || RN) ? 2 : (FAST ? MFG_CORE_SMALL_WA
   double* tot = scal + TB * 3;                           // [TB][8]: even / odd partial sums of the per-trajectory sums
   float* pst = reinterpret_cast<float*>(tot + TB * 8);   // [TB][pnw]: the rollout's START state (doubled for CIRC): its value is
                                                          // evaluated inside step 0, next to V of the next state
-  // RN: fc3_w | small weights | reward per trajectory of the tile | dropout uniforms per wave (16-byte aligned start)
-  float* rn_w3 = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(pst + TB * 2 * d) + 15) & ~(uintptr_t)15);
-  float* rn_sm = rn_w3 + ((RN ? (size_t)a.rn.n3 * 2 * d * d : 0) + 3 & ~(size_t)3);
-  float* rn_r = rn_sm + (RN ? rn_fused_small_floats(d, a.rn.n3, a.rn.n4) : 0);
-  float* rn_u = rn_r + ((TB + 3) & ~3);
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
   const int t = lane / d, i = lane - t * d;
   // deferred update of the previous episode (CoreArgs::pend_G): applied here, on the fly, with the arithmetic of
@@ -518,7 +497,6 @@ __global__ __launch_bounds__(BLOCK, (SUMS || RN) ? 2 : (FAST ? MFG_CORE_SMALL_WA
       if (pend && a.pend_reward_acc) *a.pend_reward_acc += a.pend_G[F + 1] * pinv;
     }
   }
-  if constexpr (RN && D > 0) rn_fused_stage<D, BLOCK>(a.rn, rn_w3, rn_sm, tid);
   // wl is staged block-wide but read by every wave; the per-step barriers below may be wave-local, so order the
   // staging against all later reads once, here (one block barrier per launch)
   __syncthreads();
@@ -836,23 +814,6 @@ __global__ __launch_bounds__(BLOCK, (SUMS || RN) ? 2 : (FAST ? MFG_CORE_SMALL_WA
         pi_n = a.pi_next_in ? pnv[i] : 0.0f;
         rcol = pid * racc;
       }
-      MFG_STAMP(6)
-      if constexpr (RN && SAMPLE && D > 0) {
-        // reward network on this wave's tiles (every lane takes part; trajectories beyond the batch are skipped wave-uniformly)
-        const uint64_t key = a.rn.seed ^ ((a.rn.call0 + 1ull + (uint64_t)s * (uint64_t)a.rn.call_stride) * 0x9E3779B97F4A7C15ull);
-        float* s_uw = rn_u + wv * WAVE;
-        if (a.rn.keep_prob < 1.0f) {
-          const uint64_t smp0 = a.rn.sample_offset + (uint64_t)(b0 + wv * G) * (uint64_t)a.rn.sample_stride_b +
-                                (uint64_t)s * (uint64_t)a.rn.sample_stride_s;
-          rn_fused_uniforms(a.rn, key, smp0, (uint64_t)a.rn.sample_stride_b, s_uw, lane);
-          __builtin_amdgcn_s_waitcnt(0xc07f);
-          __builtin_amdgcn_wave_barrier();
-        }
-        // lane (t, i) convolves the row it sampled; the wave's own tile rows double as scratch once they are in registers
-        const float inv_row = __int_as_float(__double2loint(reinterpret_cast<const double2*>(pis64)[tlc * d + i].y));
-        rn_fused_eval_wave<D>(tile + (size_t)(tlc * d + i) * dp, inv_row, valid, t, i, pis + tlc * d, rn_w3, rn_sm, s_uw,
-                              tile + (size_t)wv * G * d * dp, a.rn, rn_r + wv * G);
-      }
       MFG_STAMP(4)
       // Per-trajectory sums of the lane terms (reward, score, value): every lane parks its terms in an LDS line, lane 0
       // of the trajectory adds up reward and value, lane 1 the score -- two LDS round trips per step instead of the six
@@ -916,8 +877,7 @@ __global__ __launch_bounds__(BLOCK, (SUMS || RN) ? 2 : (FAST ? MFG_CORE_SMALL_WA
 #endif
         double r0 = 0.0, r1 = 0.0, v0 = 0.0, v1 = 0.0;
         if (ext) {
-          if constexpr (RN) r0 = (double)rn_r[tlc];
-          else r0 = a.reward_in ? (double)a.reward_in[b * T + s] : 0.0;
+          r0 = a.reward_in ? (double)a.reward_in[b * T + s] : 0.0;
         } else if (par) {
           r0 = totq[0];
           r1 = totq[1];
@@ -1068,11 +1028,7 @@ __global__ __launch_bounds__(BLOCK, (SUMS || RN) ? 2 : (FAST ? MFG_CORE_SMALL_WA
   }
 }
 
-inline size_t core_small_lds(int d, bool want_v, bool sample, const RnFusedArgs* rn = nullptr) {
-  if (rn && rn->on) {
-    const int G = WAVE / d, TB = WAVES * G;
-    return core_small_lds(d, want_v, sample) + 16 + rn_fused_lds_floats(d, rn->n3, rn->n4, TB, WAVES) * 4;
-  }
+inline size_t core_small_lds(int d, bool want_v, bool sample) {
   const int G = WAVE / d, TB = WAVES * G, dp = d | 1;
   const size_t F = (size_t)d * (d + 1) / 2 + d + 1;
   const size_t fl = (size_t)TB * d * dp + 5 * (size_t)TB * d;  // floats: tile, pis, pin (doubled), pal, pex

@@ -11,7 +11,7 @@ namespace mfg {
 // resident blocks): exactly-resident persistent grid 2.30 ms, x1.5 2.21, x2 2.14, x4 2.07, one tile per block 2.07 --
 // tiles do not take equal time (rejection retries), so the hardware dispatcher back-filling finished blocks beats
 // a static tile split.
-template <bool SAMPLE, bool TD, bool FAST, int D, bool SUMS = false, bool RN = false>
+template <bool SAMPLE, bool TD, bool FAST, int D, bool SUMS = false>
 static void go(const CoreArgs& a, int num_cus, size_t lds, hipStream_t st) {
   // occupancy of this instantiation at this LDS size, cached per device
   static std::atomic<size_t> cached_lds[64];
@@ -20,7 +20,7 @@ static void go(const CoreArgs& a, int num_cus, size_t lds, hipStream_t st) {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (cached_lds[dev].load() != lds + 1) {  // (+1: zero-initialised slots never match)
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_small<SAMPLE, TD, FAST, D, SUMS, RN>, BLOCK, lds) != hipSuccess || n < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_small<SAMPLE, TD, FAST, D, SUMS>, BLOCK, lds) != hipSuccess || n < 1)
       n = 1;
     cached_bpc[dev].store(n);
     cached_lds[dev].store(lds + 1);
@@ -29,19 +29,12 @@ static void go(const CoreArgs& a, int num_cus, size_t lds, hipStream_t st) {
   // (single-step launches: x2 -- a block's weight staging and first state load are then shared by ~3-4 tiles; measured
   //  1.64 -> 1.61 ms per 15-step episode of per-step updates at B = 65 536, x1 1.70, x4 1.62)
   const int grid = core_grid(a.B, TB, cached_bpc[dev].load() * (a.T == 1 ? 2 : MFG_CORE_OVERSUBSCRIBE), num_cus);
-  hipLaunchKernelGGL((k_core_small<SAMPLE, TD, FAST, D, SUMS, RN>), dim3(grid), dim3(BLOCK), lds, st, a);
+  hipLaunchKernelGGL((k_core_small<SAMPLE, TD, FAST, D, SUMS>), dim3(grid), dim3(BLOCK), lds, st, a);
 }
 
 template <int D>
 static void dispatch(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, size_t lds, hipStream_t st) {
   if constexpr (D > 0) {
-    // IRL: the reward network inside the step kernel (mixed precision; the caller checked rn_fused_supported).  Its
-    // instantiations live in their own translation unit (mfg_core_small_rn.hip): the ILP-maximising scheduler this unit is
-    // built with drives the register pressure of the network's straight-line convolutions far past the budget
-    if (a.rn.on && sample && td && fast) {
-      launch_core_small_rn(a, num_cus, lds, st);
-      return;
-    }
     // per-step updates: the variant that also leaves the tile's batch sums (launch_core_sums in mfg_kernels.hip)
     if (sample && td && a.part_rows) {
       if (fast) go<true, true, true, D, true>(a, num_cus, lds, st);
@@ -63,8 +56,7 @@ static void dispatch(const CoreArgs& a, bool sample, bool td, bool fast, int num
 int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st) {
   const int d = a.d;
   const bool want_v = td && a.w != nullptr;
-  if (a.rn.on && !((d == 21 || d == 15) && sample && td && fast && a.reward_kind == MFG_REWARD_EXTERNAL)) return MFG_EUNSUPPORTED;
-  const size_t lds = core_small_lds(d, want_v, sample, &a.rn);
+  const size_t lds = core_small_lds(d, want_v, sample);
   if (d == 21) dispatch<21>(a, sample, td, fast, num_cus, lds, st);
   else if (d == 15) dispatch<15>(a, sample, td, fast, num_cus, lds, st);
   else dispatch<0>(a, sample, td, fast, num_cus, lds, st);

@@ -2481,40 +2481,6 @@ static int reduce_core_sums(int d, int64_t B, double* G, int accumulate, void* w
   return check_launch("core_sums");
 }
 
-// reward network evaluated inside the packed step kernel (mfg_rn_fused.h): MFG_RN_FUSED=0 keeps the separate launches
-static bool rn_fused_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("MFG_RN_FUSED");
-    return e && e[0] == '1';   // opt-in: measured SLOWER than the separate launches, kept for the record
-  }();
-  return on;
-}
-// row reduction + update inside the reward network's SUMS launch (its last block): MFG_RN_FINISH=0 keeps the separate launch
-static bool rn_finish_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("MFG_RN_FINISH");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
-static RnFusedArgs rn_fused_args(const mfg_reward_net_t* net, uint64_t seed, uint64_t call0, int call_stride, uint64_t sample_offset,
-                                 int stride_b, int stride_s) {
-  RnFusedArgs r{};
-  r.on = 1;
-  r.n3 = net->n3;
-  r.n4 = net->n4;
-  r.keep_prob = net->keep_prob;
-  r.c1w = net->conv1_w; r.c1b = net->conv1_b; r.c2w = net->conv2_w; r.c2b = net->conv2_b;
-  r.w3 = net->fc3_w; r.b3 = net->fc3_b; r.w4 = net->fc4_w; r.b4 = net->fc4_b; r.wo = net->out_w; r.bo = net->out_b;
-  r.seed = seed;
-  r.call0 = call0;
-  r.call_stride = call_stride;
-  r.sample_offset = sample_offset;
-  r.sample_stride_b = stride_b;
-  r.sample_stride_s = stride_s;
-  return r;
-}
-
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
@@ -3464,6 +3430,63 @@ int mfg_train_episodes(const float* mat_pi0, int64_t num_start, float* pi_io, fl
   return MFG_OK;
 }
 
+int mfg_train_rollout_irl(const float* mat_pi0, int64_t num_start, const int32_t* idx, int64_t B, int d, int T, double* theta,
+                          double shift, double alpha_scale, double* w, double gamma, uint64_t seed, uint32_t first_step,
+                          uint64_t traj_offset, int flags, double lr_critic, double lr_actor, const mfg_reward_net_t* net,
+                          uint64_t rn_key, uint64_t rn_sample_offset, float* pi_traj, float* pi_last, float* P, float* reward,
+                          double* delta, double* g, double* G, double* reward_acc, void* workspace, size_t workspace_bytes,
+                          mfg_stream_t stream) {
+  CHECK_BD();
+  REQUIRE(T >= 1, "T < 1");
+  REQUIRE(mat_pi0 && num_start > 0 && num_start <= 0x7FFFFFFF, "null / empty / oversized start-state table");
+  REQUIRE(theta && w && net && pi_traj && P && reward && delta && g && G && workspace, "null pointer");
+  REQUIRE(B * (int64_t)T <= 0x7FFFFFFF, "B * T too large");
+  hipStream_t st = S(stream);
+  CoreArgs a{};
+  a.pi0 = mat_pi0;
+  a.start_idx = idx;
+  a.start_draw = idx ? 0 : 1;
+  a.num_start = num_start;
+  a.theta = theta;
+  a.w = w;
+  a.shift = shift;
+  a.alpha_scale = alpha_scale;
+  a.gamma = gamma;
+  a.B = B;
+  a.d = d;
+  a.T = T;
+  a.reward_kind = MFG_REWARD_EXTERNAL;  // delta = discount V(pi') - V(pi); the reward joins it in the gradient kernel
+  a.discount_pow = (flags & MFG_ROLLOUT_DISCOUNT_POW) ? 1 : 0;
+  a.seed = seed;
+  a.first_step = first_step;
+  a.traj_offset = traj_offset;
+  a.pi_traj = pi_traj;
+  a.pi_next_out = pi_last;
+  a.delta = delta;
+  a.g = g;
+  a.P_out = P;
+  const int precision = (flags & MFG_ROLLOUT_F64) ? MFG_PRECISION_F64 : MFG_PRECISION_MIXED;
+  int rc = launch_core(a, true, true, precision, st);
+  if (rc != MFG_OK) return rc;
+  // ONE reward-network pass over all B*T transitions; the states are read in place from pi_traj (rows b (T+1) + t)
+  rc = reward_net_forward_sums(pi_traj, P, B * (int64_t)T, d, net->k1, net->f2, net->k2, net->n3, net->n4, net->conv1_w, net->conv1_b,
+                               net->conv2_w, net->conv2_b, net->fc3_w, net->fc3_b, net->fc4_w, net->fc4_b, net->out_w, net->out_b,
+                               net->keep_prob, rn_key, rn_sample_offset, reward, nullptr, nullptr, stream, T);
+  if (rc != MFG_OK) return rc;
+  const ApplyArgs ap{lr_critic, lr_actor, w, theta, reward_acc};
+  const bool want_apply = (flags & MFG_TRAIN_APPLY) != 0;
+  bool applied = false;
+  rc = launch_grad(pi_traj, (int64_t)(T + 1) * d, delta, g, reward, B * T, T, d, G, 0, workspace, workspace_bytes, st,
+                   want_apply ? &ap : nullptr, &applied, true);
+  if (rc != MFG_OK) return rc;
+  if (want_apply && !applied) {
+    const int64_t F = mfg_num_features(d);
+    hipLaunchKernelGGL(k_apply_update, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, G, F, lr_critic, lr_actor, w, theta,
+                       reward_acc);
+  }
+  return check_launch("train_rollout_irl");
+}
+
 int mfg_train_episode_irl(float* pi_io, float* pi_scratch, int64_t B, int d, int T, double* theta, double shift,
                           double alpha_scale, double* w, double gamma, uint64_t seed, uint32_t first_step,
                           uint64_t traj_offset, int precision, double lr_critic, double lr_actor,
@@ -3478,11 +3501,6 @@ int mfg_train_episode_irl(float* pi_io, float* pi_scratch, int64_t B, int d, int
   float* cur = pi_io;
   float* nxt = pi_scratch;
   double discount = 1.0;  // running gamma^t of ac_irl.py:691, :710
-  // The network inside the step kernel (mfg_rn_fused.h): the reference geometry at d = 21 / 15, mixed precision.  P is then
-  // not materialised at all and an env step is two launches: [sample + transition + score + reward net + delta + tile sums]
-  // | [row reduction + update] (larger batches than the SUMS variant covers: the gradient kernel instead of the reduction).
-  const bool fused = rn_fused_enabled() && precision == MFG_PRECISION_MIXED &&
-                     rn_fused_supported(d, net->k1, net->f2, net->k2, net->n3, net->n4, net->fc3_w);
   for (int s = 0; s < T; ++s) {
     CoreArgs a{};
     a.pi0 = cur;
@@ -3501,32 +3519,6 @@ int mfg_train_episode_irl(float* pi_io, float* pi_scratch, int64_t B, int d, int
     a.pi_next_out = nxt;
     a.delta = delta;
     a.g = g;
-    if (fused) {
-      a.rn = rn_fused_args(net, rn_seed, rn_call0 + (uint64_t)s, 1, rn_sample_offset, 1, 0);
-      a.reward_out = reward;
-      const bool sums_in_core = core_sums_rows(d, B) > 0 && workspace_bytes >= (size_t)(core_sums_rows(d, B) * (mfg_num_features(d) + 3) * 8) + MFG_WS_CONTROL_BYTES;
-      if (sums_in_core) a.part_rows = reinterpret_cast<double*>((char*)workspace + MFG_WS_CONTROL_BYTES);
-      int rc = launch_core(a, true, true, precision, st);
-      if (rc != MFG_OK) return rc;
-      const ApplyArgs ap{lr_critic, lr_actor, w, theta, reward_acc};
-      if (sums_in_core) {
-        rc = reduce_core_sums(d, B, G, 0, workspace, &ap, st);
-      } else {
-        bool applied = false;
-        rc = launch_grad(cur, d, delta, g, reward, B, 1, d, G, 0, workspace, workspace_bytes, st, &ap, &applied, false);
-        if (rc == MFG_OK && !applied) {
-          const int64_t F = mfg_num_features(d);
-          hipLaunchKernelGGL(k_apply_update, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, st, G, F, lr_critic, lr_actor, w, theta,
-                             reward_acc);
-        }
-      }
-      if (rc != MFG_OK) return rc;
-      discount *= gamma;
-      float* t = cur;
-      cur = nxt;
-      nxt = t;
-      continue;
-    }
     a.P_out = P;
     int rc = launch_core(a, true, true, precision, st);
     if (rc != MFG_OK) return rc;
@@ -3535,10 +3527,7 @@ int mfg_train_episode_irl(float* pi_io, float* pi_scratch, int64_t B, int d, int
     // sums (one per block of eight samples), so the update is a row reduction instead of a gradient kernel
     const int64_t FO = mfg_num_features(d) + 3;
     const int64_t room = workspace_bytes > MFG_WS_CONTROL_BYTES ? (int64_t)((workspace_bytes - MFG_WS_CONTROL_BYTES) / (size_t)(FO * 8)) : 0;
-    // (the finish needs the control block's completion counter: the first word of the workspace, zero between launches)
-    const RnFinish fin{reinterpret_cast<unsigned*>(workspace), G, lr_critic, lr_actor, w, theta, reward_acc};
-    const RnSums sm{delta, g, delta, reinterpret_cast<double*>((char*)workspace + MFG_WS_CONTROL_BYTES), room,
-                    rn_finish_enabled() ? &fin : nullptr};
+    const RnSums sm{delta, g, delta, reinterpret_cast<double*>((char*)workspace + MFG_WS_CONTROL_BYTES), room};
     int rows = 0;
     rc = reward_net_forward_sums(cur, P, B, d, net->k1, net->f2, net->k2, net->n3, net->n4, net->conv1_w, net->conv1_b,
                                  net->conv2_w, net->conv2_b, net->fc3_w, net->fc3_b, net->fc4_w, net->fc4_b, net->out_w,
@@ -3546,10 +3535,7 @@ int mfg_train_episode_irl(float* pi_io, float* pi_scratch, int64_t B, int d, int
     if (rc != MFG_OK) return rc;
     const ApplyArgs ap{lr_critic, lr_actor, w, theta, reward_acc};
     bool applied = false;
-    if (rows < 0) {
-      applied = true;   // reduced and applied by the reward-network launch itself
-      rc = check_launch("irl_sums");
-    } else if (rows > 0) {
+    if (rows > 0) {
       ReduceApply rap{};
       rap.on = 1;
       rap.lr_c = lr_critic;

@@ -41,12 +41,6 @@ struct RewardNetArgs {
   double* part_rows;  // [gridDim.x][F+3]
   // states inside a rollout's pi_traj [B', T+1, d]: sample n = (b', t) reads row b' (T+1) + t (state_T = T; 0: plain [B,d])
   int state_T;
-  // SUMS + in-kernel finish (matrix-core kernel): the last block to finish adds the partial rows in row order, writes G and
-  // applies the update (w += lr_c G_w / N, theta += lr_a G_theta / N, *reward_acc += sum r / N) -- the step is then two launches
-  unsigned* fin_counter;  // zero before the launch, reset by the finishing block; NULL: no finish
-  double* fin_G;          // [F+3]
-  double fin_lr_c, fin_lr_a;
-  double *fin_w, *fin_theta, *fin_reward_acc;
 };
 __device__ __forceinline__ int64_t rn_state_row(const RewardNetArgs& a, int64_t b) {
   if (a.state_T <= 0) return b;
@@ -1092,67 +1086,6 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
       for (int w_ = 1; w_ < RM_WAVES; ++w_) t += rows[w_ * FO + k];
       a.part_rows[(int64_t)blockIdx.x * FO + k] = t;
     }
-    if (a.fin_counter) {
-      // The last block to finish adds the rows (the separate row-reduction launch cost 5.3 us per env step for 512 KB of
-      // dependent L2 reads; here every one of a thread's <= 64 row reads is in flight at once, one latency in all).
-      // thread = (column k = tid % 256, slice q = tid / 256 of four): rows q, q + 4, ... in order, four running sums; the
-      // slices are combined in slice order: a fixed association, bit-reproducible.
-      static_assert(FO <= 256 && RM_BLOCK == 1024, "finish: one column per thread of a 256-thread slice");
-      __shared__ int s_last;
-      // ONE device-scope release per block, by the thread that signals (behind the barrier: the block's row is complete and
-      // ordered before it).  Every wave of every block fencing on its own -- 4 096 L2 write-backs across the eight XCDs --
-      // made this launch 89 us instead of 12.
-      __syncthreads();
-      if (tid == 0) {
-        __threadfence();
-        s_last = (atomicAdd(a.fin_counter, 1u) == gridDim.x - 1) ? 1 : 0;
-      }
-      __syncthreads();
-      if (s_last) {
-        __threadfence();
-        const int k = tid & 255, q = tid >> 8, nrows = (int)gridDim.x;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        if (k < FO) {
-          // (32 reads in flight per round: the block's 1 024 threads leave 128 registers each)
-#pragma unroll 1
-          for (int u0 = 0; u0 < 64; u0 += 32) {
-            double v[32];
-#pragma unroll
-            for (int u = 0; u < 32; ++u) {
-              const int r = q + 4 * (u0 + u);
-              v[u] = r < nrows ? a.part_rows[(int64_t)r * FO + k] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < 32; u += 4) {
-              s0 += v[u];
-              s1 += v[u + 1];
-              s2 += v[u + 2];
-              s3 += v[u + 3];
-            }
-          }
-        }
-        double* fin = rows;  // (the waves' rows were consumed above, behind the barriers)
-        fin[q * 256 + k] = (s0 + s1) + (s2 + s3);
-        __syncthreads();
-        double* gk = fin + 1024;
-        if (tid < FO) {
-          const double tot = ((fin[tid] + fin[256 + tid]) + fin[512 + tid]) + fin[768 + tid];
-          a.fin_G[tid] = tot;
-          gk[tid] = tot;
-        }
-        __syncthreads();
-        const double count = gk[Fs + 2];
-        if (a.fin_w && count > 0.0) {
-          const double inv = 1.0 / count;
-          if (tid < Fs) a.fin_w[tid] = updated_param(a.fin_w[tid], a.fin_lr_c, gk[tid], inv);
-          if (tid == 0) {
-            if (a.fin_reward_acc) *a.fin_reward_acc += gk[Fs + 1] * inv;
-            *a.fin_theta = updated_param(*a.fin_theta, a.fin_lr_a, gk[Fs], inv);
-          }
-        }
-        if (tid == 0) *a.fin_counter = 0u;
-      }
-    }
   }
 #ifdef MFG_RN_STAMPS
   first_pass = true;
@@ -1161,8 +1094,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
 }
 
 template <int D, int RUN, int RPR, int P1>
-static int launch_reward_net_mfma(const RewardNetArgs& a, bool want_sums, int64_t max_rows, int* rows_out, hipStream_t st,
-                                  const RnFinish* fin = nullptr) {
+static int launch_reward_net_mfma(const RewardNetArgs& a, bool want_sums, int64_t max_rows, int* rows_out, hipStream_t st) {
   using Gm = MfmaGeom<D, RUN, RPR, P1>;
   int64_t grid = (a.B + RM_WAVES - 1) / RM_WAVES;
   if (grid > 256) grid = 256;  // one 16-wave block per CU (LDS: 137 KB at d = 21)
@@ -1187,18 +1119,8 @@ static int launch_reward_net_mfma(const RewardNetArgs& a, bool want_sums, int64_
     if (attr_state[dev] < 0) return 1;
   }
   if (sums) {
-    RewardNetArgs af = a;
-    if (fin && fin->counter) {
-      af.fin_counter = fin->counter;
-      af.fin_G = fin->G;
-      af.fin_lr_c = fin->lr_c;
-      af.fin_lr_a = fin->lr_a;
-      af.fin_w = fin->w;
-      af.fin_theta = fin->theta;
-      af.fin_reward_acc = fin->reward_acc;
-    }
-    hipLaunchKernelGGL((k_reward_net_mfma<D, RUN, RPR, P1, true>), dim3((unsigned)grid), dim3(RM_BLOCK), lds, st, af);
-    *rows_out = (fin && fin->counter) ? -(int)grid : (int)grid;   // negative: rows reduced and applied by the launch itself
+    hipLaunchKernelGGL((k_reward_net_mfma<D, RUN, RPR, P1, true>), dim3((unsigned)grid), dim3(RM_BLOCK), lds, st, a);
+    *rows_out = (int)grid;
   } else {
     hipLaunchKernelGGL((k_reward_net_mfma<D, RUN, RPR, P1, false>), dim3((unsigned)grid), dim3(RM_BLOCK), lds, st, a);
   }
@@ -1228,7 +1150,6 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
   if (B == 0) return MFG_OK;
   RewardNetArgs a{state, action, B, d, k1, f2, k2, n3, n4, conv1_w, conv1_b, conv2_w, conv2_b, fc3_w, fc3_b,
                   fc4_w, fc4_b, out_w, out_b, keep_prob, seed, sample_offset, reward, 0, nullptr, nullptr, nullptr, nullptr};
-  a.fin_counter = nullptr;
   a.state_T = state_T;
   if (sums) {
     a.delta0 = sums->delta0;
@@ -1269,8 +1190,8 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
   bool mfma_done = false;
   if (mfma_ok) {
     int rows = 0;
-    const int rc = d == 21 ? launch_reward_net_mfma<21, 7, 3, MFG_RM_P21>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st, sums ? sums->finish : nullptr)
-                           : launch_reward_net_mfma<15, 5, 3, MFG_RM_P15>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st, sums ? sums->finish : nullptr);
+    const int rc = d == 21 ? launch_reward_net_mfma<21, 7, 3, MFG_RM_P21>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st)
+                           : launch_reward_net_mfma<15, 5, 3, MFG_RM_P15>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st);
     if (rc == 0) {
       mfma_done = true;
       if (rows_out) *rows_out = rows;

@@ -425,6 +425,29 @@ def train_episode_irl(pi, T, theta, shift, alpha_scale, w, gamma, lr_critic, lr_
     return pi
 
 
+def train_rollout_irl(mat_pi0, idx, T, theta, shift, alpha_scale, w, gamma, lr_critic, lr_actor, net, G, ws, bufs, seed=0,
+                      first_step=0, traj_offset=0, rn_key=0, rn_sample_offset=0, reward_acc=None, discount_pow=True, apply=True,
+                      precision='mixed'):
+    """One IRL update per episode issued natively (mfg_train_rollout_irl): fused rollout (start states drawn in the kernel when
+    idx is None) | reward network over all B*T transitions | batch sums + update.  bufs: pi_traj [B,T+1,d], pi_last [B,d],
+    P [B,T,d,d], reward [B*T] f32, delta / g [B*T] f64."""
+    import ctypes as C
+    _chk_f32(mat_pi0, 'mat_pi0'); _chk_f64(theta, 'theta'); _chk_f64(w, 'w'); _chk_f64(G, 'G')
+    B, d = bufs['pi_traj'].shape[0], mat_pi0.shape[1]
+    flags = (L.ROLLOUT_DISCOUNT_POW if discount_pow else 0) | (L.TRAIN_APPLY if apply else 0)
+    if L.PRECISIONS[precision] == L.PRECISION_F64:
+        flags |= L.ROLLOUT_F64
+    st = reward_net_struct(net)
+    L.check(L.lib().mfg_train_rollout_irl(mat_pi0.data_ptr(), mat_pi0.shape[0], _ptr(idx), B, d, int(T), theta.data_ptr(),
+                                          float(shift), float(alpha_scale), w.data_ptr(), float(gamma), int(seed), int(first_step),
+                                          int(traj_offset), flags, float(lr_critic), float(lr_actor), C.byref(st),
+                                          int(rn_key) & 0xFFFFFFFFFFFFFFFF, int(rn_sample_offset), bufs['pi_traj'].data_ptr(),
+                                          bufs['pi_last'].data_ptr(), bufs['P'].data_ptr(), bufs['reward'].data_ptr(),
+                                          bufs['delta'].data_ptr(), bufs['g'].data_ptr(), G.data_ptr(), _ptr(reward_acc),
+                                          ws.data_ptr(), ws.numel() * 8, _stream()), 'mfg_train_rollout_irl')
+    return bufs
+
+
 def episode_buffers(B, d, device):
     return {'scratch': torch.empty(B, d, dtype=torch.float32, device=device),
             'reward': torch.empty(B, dtype=torch.float32, device=device),

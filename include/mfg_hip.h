@@ -382,6 +382,21 @@ int mfg_train_episode_irl(float* pi_io, float* pi_scratch, int64_t B, int d, int
                           float* P, float* reward, double* delta, double* g, double* G, double* reward_acc, void* workspace,
                           size_t workspace_bytes, mfg_stream_t stream);
 
+/* a9 (IRL flavour), one update per episode (the batched form of ac_irl.py:664-712 with theta, w fixed over the episode) on
+ * ONE GPU, issued natively: [fused T-step rollout: start states drawn in the kernel (idx == NULL) or gathered, actions
+ * materialised, delta0 = discount V(pi') - V(pi), scores] | [reward network over all B*T transitions, states read in place
+ * from pi_traj] | [batch sums with delta = delta0 + r folded in (+ row reduction)] (+ update with MFG_TRAIN_APPLY):
+ * 3-4 launches, no framework call in between.  flags: MFG_ROLLOUT_DISCOUNT_POW | MFG_ROLLOUT_F64 | MFG_TRAIN_APPLY.
+ * Dropout masks: Philox key rn_key, sample counter rn_sample_offset + b T + t (ONE mfg_reward_net_forward call over the
+ * [B*T] transitions).  pi_traj [B,T+1,d], P [B,T,d,d], reward [B*T] (the network's output), delta / g [B*T] (delta final),
+ * G [F+3]; workspace as for mfg_td_pg_accumulate(B*T).  *reward_acc += mean reward over the B*T transitions. */
+int mfg_train_rollout_irl(const float* mat_pi0, int64_t num_start, const int32_t* idx, int64_t B, int d, int T, double* theta,
+                          double shift, double alpha_scale, double* w, double gamma, uint64_t seed, uint32_t first_step,
+                          uint64_t traj_offset, int flags, double lr_critic, double lr_actor, const mfg_reward_net_t* net_host,
+                          uint64_t rn_key, uint64_t rn_sample_offset, float* pi_traj, float* pi_last, float* P, float* reward,
+                          double* delta, double* g, double* G, double* reward_acc, void* workspace, size_t workspace_bytes,
+                          mfg_stream_t stream);
+
 /* f1 (optional importance weights, ac_irl.py:270-289 calc_pdf_action, :324-379 calc_z): log-density of the
  * product-Dirichlet policy for N (state, action) pairs under K policies theta_k (device array):
  *   out[n*K + k] = sum_i log Dirichlet(P_n[i,:] ; a_i),  a_ij = max(alpha_floor, alpha_scale * softplus(theta_k x_ij)).

@@ -153,7 +153,8 @@ def test_native_rccl_episode_loop_equals_the_single_gpu_loop():
     Philox counter as the single-GPU run."""
     if not torch.cuda.is_available():
         pytest.fail('-m gpu tests need a GPU')
-    p = subprocess.run([sys.executable, '-c', _CHILD_NATIVE % {'root': ROOT}], cwd=ROOT, env=_env(), stdout=subprocess.PIPE,
+    # (the native loop is opt-in since round 5: no run with more than one rank has happened yet, parallel.native_comm)
+    p = subprocess.run([sys.executable, '-c', _CHILD_NATIVE % {'root': ROOT}], cwd=ROOT, env=dict(_env(), MFG_NATIVE_RCCL='1'), stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     z = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
