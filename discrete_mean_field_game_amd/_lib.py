@@ -45,6 +45,14 @@ SIGNATURES = {
     'mfg_init': (_i32, []),
     'mfg_status': (_i32, [C.POINTER(C.c_uint)]),
     'mfg_clear_status': (_i32, []),
+    'mfg_ctx_create': (_i32, [C.POINTER(C.c_void_p)]),
+    'mfg_ctx_destroy': (_i32, [_p]),
+    'mfg_ctx_bind': (_i32, [_p]),
+    'mfg_ctx_current': (_p, []),
+    'mfg_ctx_status': (_i32, [_p, C.POINTER(C.c_uint)]),
+    'mfg_ctx_clear_status': (_i32, [_p]),
+    'mfg_ctx_adopt_comm': (_i32, [_p, _p]),
+    'mfg_ctx_comm': (_p, [_p]),
     'mfg_device_info': (_i32, [C.POINTER(C.c_int), C.c_char_p, _i32]),
     'mfg_feature_index': (_i64, [_i32, _i32, _i32]),
     'mfg_num_features': (_i64, [_i32]),

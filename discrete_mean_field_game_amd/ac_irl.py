@@ -25,7 +25,7 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .mfg_ac2 import EPISODE_STEPS, actor_critic
+from .mfg_ac2 import EPISODE_STEPS, _with_ctx, actor_critic
 from .networks import RewardNet, maxent_irl_loss
 from .parallel import all_reduce_gradients_, all_reduce_mean_flat_, broadcast_seed, current_shard, lr_scales
 from .reward_learning import RewardTrainer, TrajectoryStore
@@ -206,6 +206,7 @@ class AC_IRL(actor_critic):
         a = torch.as_tensor(np.array([np.asarray(p[1], dtype=np.float32) for p in pairs]), device=self.device)
         return s, a
 
+    @_with_ctx
     def reward(self, pi, P):
         """r(pi, P) from the reward network: [B,d], [B,d,d] -> [B] (ac_irl.py:683)."""
         if ops.reward_net_supported(self.reward_net) and pi.is_cuda:
@@ -223,6 +224,7 @@ class AC_IRL(actor_critic):
         with torch.no_grad():
             return self.reward_net(pi, P).reshape(-1).float().contiguous()
 
+    @_with_ctx
     def calc_alpha_deriv(self, pi):
         """d alpha / d theta for state pi (ac_irl.py:573-588); stored like the reference."""
         pi_dev, single = self._pi_dev(pi)
@@ -232,6 +234,7 @@ class AC_IRL(actor_critic):
         return self._alpha_deriv_host
 
     # ------------------------------------------------------------------ a9 (IRL flavour)
+    @_with_ctx
     def train(self, max_episodes=4000, stop_criteria=0.01, gamma=1, constant=False, lr_critic=0.1, lr_actor=0.001,
               consecutive=100, file_theta='results/theta.csv', file_pi='results/pi.csv',
               file_reward='results/reward.csv', write_file=0, write_all=0, reward_fn=None, *, first_episode=0):
@@ -427,6 +430,7 @@ class AC_IRL(actor_critic):
             self.train_log(np.array([reward_avg]), file_reward, '%.3e')
 
     # ------------------------------------------------------------------ a10
+    @_with_ctx
     def generate_trajectories(self, n, from_test=False):
         """n trajectories of 15 (state, action) pairs under the current policy (ac_irl.py:735-767)."""
         mat_dev = self._mat_pi0_dev
@@ -471,6 +475,7 @@ class AC_IRL(actor_critic):
         return off
 
     # ------------------------------------------------------------------ checkpoint / resume
+    @_with_ctx
     def state_dict(self):
         """actor_critic.state_dict() plus the reward network, its optimiser, the policy FIFO and the counters of the
         outer loop (the reference only saves the TF reward net, ac_irl.py:948)."""
@@ -500,6 +505,7 @@ class AC_IRL(actor_critic):
                    'torch_cuda_rng_state': torch.cuda.get_rng_state(self.device)})
         return st
 
+    @_with_ctx
     def load_state_dict(self, state, restore_np_random=True):
         super().load_state_dict(state, restore_np_random)
         self.reward_net.load_state_dict(state['reward_net'])
@@ -525,6 +531,7 @@ class AC_IRL(actor_critic):
             torch.cuda.set_rng_state(state['torch_cuda_rng_state'].cpu(), self.device)
 
     # ------------------------------------------------------------------ importance weights (ac_irl.py:270-379)
+    @_with_ctx
     def calc_pdf_action(self, theta, action, state, log=False):
         """q(a_t; s_t, theta) of the product-Dirichlet policy (ac_irl.py:270-289); `log=True` returns ln q (the
         density itself under/overflows fp64 long before d=15 rows are multiplied)."""
@@ -533,6 +540,7 @@ class AC_IRL(actor_critic):
         lq = float(ops.policy_logpdf(s, a, th, self.shift)[0, 0].cpu())
         return lq if log else float(np.exp(lq))
 
+    @_with_ctx
     def calc_z(self, list_trajectories, log=False):
         """z(traj_j) = [1/k sum_k q_k(traj_j)]^-1 over the policies in `list_policies` (ac_irl.py:292-321, :324-379;
         alpha lower-bounded by 1+1e-6 like :359).  One HIP launch for all (transition, policy) pairs; the products
@@ -549,6 +557,7 @@ class AC_IRL(actor_critic):
         return out.cpu().numpy()
 
     # ------------------------------------------------------------------ reward learning (ac_irl.py:804-897)
+    @_with_ctx
     def update_reward(self, summary=False, iteration=0):
         """One gradient step on the reward network (ac_irl.py:804-846).  The batch is drawn with the reference's
         `random.sample` calls -- on INDEX ranges: random.sample(population, k) picks positions from len(population) alone, so
@@ -636,6 +645,7 @@ class AC_IRL(actor_critic):
         nd, ng = ds.shape[0], gs.shape[0]
         return (float(sums[0]) / nd if nd else float('nan')), (float(sums[1]) / ng if ng else float('nan'))
 
+    @_with_ctx
     def reward_iteration(self, max_iterations=500, stop_criteria=0.01, iter_check=10):
         prev_reward_demo_avg = -100
         self._sync_host_sampler()
@@ -664,6 +674,7 @@ class AC_IRL(actor_critic):
         if self.verbose:
             print('----- Exiting reward_iteration at iter %d -----' % it)
 
+    @_with_ctx
     def outerloop(self, num_iterations=20, num_gen_from_policy=5, max_reward_iterations=100,
                   max_forward_episodes=200, gamma=1, constant=False, lr_critic=0.1, lr_actor=0.001, *, first_iteration=0,
                   final_training=True):

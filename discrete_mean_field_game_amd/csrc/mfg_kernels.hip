@@ -2382,24 +2382,37 @@ struct StatusWord {
   unsigned* host = nullptr;
   unsigned* dev = nullptr;
 };
+// ---- contexts (mfg_ctx_t, include/mfg_hip.h): the mutable state a launch touches -- the status word, an RCCL communicator --
+// owned by an opaque object instead of the process.  A thread binds a context (mfg_ctx_bind) and every entry point called
+// from that thread acts on it; with none bound the device's default context (the process-wide word of ABI 14) is used.
+struct mfg_ctx {
+  int device = -1;
+  StatusWord sw;
+  void* comm = nullptr;  // adopted RCCL communicator (mfg_ctx_adopt_comm), destroyed with the context
+};
+static thread_local mfg_ctx* g_ctx = nullptr;
+extern "C" int mfg_dist_destroy(void* comm);
+static bool alloc_status_word(StatusWord* out) {
+  void* h = nullptr;
+  void* d = nullptr;
+  if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return false;
+  memset(h, 0, 64);
+  if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+    (void)hipHostFree(h);
+    return false;
+  }
+  out->host = (unsigned*)h;
+  out->dev = (unsigned*)d;
+  return true;
+}
 static StatusWord status_word() {
   static std::mutex mu;
   static StatusWord sw[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return StatusWord{};
+  if (g_ctx) return g_ctx->device == dev ? g_ctx->sw : StatusWord{};  // (a context of another device: refused by the callers)
   std::lock_guard<std::mutex> lock(mu);
-  if (!sw[dev].host) {
-    void* h = nullptr;
-    void* d = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return StatusWord{};
-    memset(h, 0, 64);
-    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
-      (void)hipHostFree(h);
-      return StatusWord{};
-    }
-    sw[dev].host = (unsigned*)h;
-    sw[dev].dev = (unsigned*)d;
-  }
+  if (!sw[dev].host && !alloc_status_word(&sw[dev])) return StatusWord{};
   return sw[dev];
 }
 static int status_error(unsigned bits) {
@@ -2487,7 +2500,7 @@ static int reduce_core_sums(int d, int64_t B, double* G, int accumulate, void* w
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 14; }
+int mfg_abi_version(void) { return 15; }
 
 int mfg_init(void) {
   if (!htab_ptr()) return fail(MFG_ELAUNCH, "%s", "mfg_init: no HIP device / table initialisation failed");
@@ -2509,6 +2522,65 @@ int mfg_clear_status(void) {
   *(volatile unsigned*)sw.host = 0u;
   return MFG_OK;
 }
+
+int mfg_ctx_create(mfg_ctx_t** ctx_out) {
+  REQUIRE(ctx_out, "null pointer");
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(MFG_ELAUNCH, "%s", "mfg_ctx_create: no HIP device");
+  if (!htab_ptr()) return fail(MFG_ELAUNCH, "%s", "mfg_ctx_create: table initialisation failed");  // (shared, immutable, per device)
+  mfg_ctx* c = new (std::nothrow) mfg_ctx();
+  if (!c) return fail(MFG_ELAUNCH, "%s", "mfg_ctx_create: out of memory");
+  c->device = dev;
+  if (!alloc_status_word(&c->sw)) {
+    delete c;
+    return fail(MFG_ELAUNCH, "%s", "mfg_ctx_create: status word allocation failed");
+  }
+  *ctx_out = c;
+  return MFG_OK;
+}
+
+int mfg_ctx_destroy(mfg_ctx_t* ctx) {
+  if (!ctx) return MFG_OK;
+  if (g_ctx == ctx) g_ctx = nullptr;
+  int rc = MFG_OK;
+  if (ctx->comm) rc = mfg_dist_destroy(ctx->comm);
+  if (ctx->sw.host) (void)hipHostFree(ctx->sw.host);
+  delete ctx;
+  return rc;
+}
+
+int mfg_ctx_bind(mfg_ctx_t* ctx) {
+  if (ctx) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev != ctx->device)
+      return fail(MFG_EINVAL, "mfg_ctx_bind: the context belongs to device %d, the current device is %d", ctx->device, dev);
+  }
+  g_ctx = ctx;
+  return MFG_OK;
+}
+
+mfg_ctx_t* mfg_ctx_current(void) { return g_ctx; }
+
+int mfg_ctx_status(mfg_ctx_t* ctx, unsigned* bits_host) {
+  REQUIRE(ctx && ctx->sw.host, "null context");
+  const unsigned bits = *(volatile unsigned*)ctx->sw.host;
+  if (bits_host) *bits_host = bits;
+  return bits ? status_error(bits) : MFG_OK;
+}
+
+int mfg_ctx_clear_status(mfg_ctx_t* ctx) {
+  REQUIRE(ctx && ctx->sw.host, "null context");
+  *(volatile unsigned*)ctx->sw.host = 0u;
+  return MFG_OK;
+}
+
+int mfg_ctx_adopt_comm(mfg_ctx_t* ctx, void* comm) {
+  REQUIRE(ctx, "null context");
+  ctx->comm = comm;
+  return MFG_OK;
+}
+
+void* mfg_ctx_comm(mfg_ctx_t* ctx) { return ctx ? ctx->comm : nullptr; }
 
 int mfg_device_info(int* cu_count_host, char* arch_host, int arch_len) {
   int dev = 0;

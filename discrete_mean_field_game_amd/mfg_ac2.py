@@ -43,6 +43,18 @@ def _as_np(x):
     return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
 
 
+def _with_ctx(method):
+    """Public methods that reach the HIP library run with the instance's own context bound (ops.Context: its status word),
+    so that two instances on one device cannot stop each other (include/mfg_hip.h, mfg_ctx_bind)."""
+    import functools
+
+    @functools.wraps(method)
+    def bound(self, *args, **kwargs):
+        self._ctx.bind()
+        return method(self, *args, **kwargs)
+    return bound
+
+
 class actor_critic:
 
     def __init__(self, theta=8.86349, shift=0.16, alpha_scale=12000, d=21, *, pi0=None, path_to_dir=None,
@@ -57,6 +69,7 @@ class actor_critic:
         L.lib()
         ops.init()
         self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        self._ctx = ops.Context(self.device).bind()      # this instance's library state (status word), bound by its methods
         self.shift = shift
         self.alpha_scale = alpha_scale
         self.d = d
@@ -233,6 +246,7 @@ class actor_critic:
                                      % (episode, float(self._theta.cpu()[0])))
 
     # ------------------------------------------------------------------ checkpoint / resume
+    @_with_ctx
     def state_dict(self):
         """Everything a run needs to resume bit for bit: theta, w (fp64, device values copied to the host), the Philox
         step counter and seed, the policy hyper-parameters and the global np.random state (start-state draws).
@@ -247,6 +261,7 @@ class actor_critic:
                 'np_random_key': torch.as_tensor(key.astype(np.int64)), 'np_random_pos': int(pos),
                 'np_random_has_gauss': int(has_gauss), 'np_random_cached_gaussian': float(cached)}
 
+    @_with_ctx
     def load_state_dict(self, state, restore_np_random=True):
         if int(state['d']) != int(self.d):
             raise ValueError('checkpoint is for d=%d, object has d=%d' % (state['d'], self.d))
@@ -292,6 +307,7 @@ class actor_critic:
         self._rng_step += 1
         return P
 
+    @_with_ctx
     def sample_action(self, pi):
         """P ~ prod_i Dirichlet(alpha_i. * alpha_scale); (d,) -> (d,d), (B,d) -> (B,d,d)  (mfg_ac2.py:211-254)."""
         pi_dev, single = self._pi_dev(pi)
@@ -299,6 +315,7 @@ class actor_critic:
         return self._out(self._sample(pi_dev), pi, single)
 
     # ------------------------------------------------------------------ a3 - a5, a7
+    @_with_ctx
     def calc_reward(self, P, pi, d=None):
         """R = sum_i pi_i sum_j P_ij^2 (pi_j - pi_i); shape (1,) for one trajectory (mfg_ac2.py:257-287)."""
         pi_dev, single = self._pi_dev(pi)
@@ -307,16 +324,19 @@ class actor_critic:
             return r
         return r.cpu().numpy().astype(np.float64)          # (1,) when single, like the reference
 
+    @_with_ctx
     def transition(self, P, pi):
         """pi' = P^T pi (mfg_ac2.py:497)."""
         pi_dev, single = self._pi_dev(pi)
         pn, _ = ops.step_given_P(pi_dev, self._P_dev(P), want_reward=False)
         return self._out(pn, pi, single)
 
+    @_with_ctx
     def calc_features(self, pi):
         pi_dev, single = self._pi_dev(pi)
         return self._out(ops.features(pi_dev), pi, single)
 
+    @_with_ctx
     def calc_value(self, pi):
         pi_dev, single = self._pi_dev(pi)
         v = ops.value(pi_dev, self._w)
@@ -324,6 +344,7 @@ class actor_critic:
             return v
         return v.cpu().numpy()                               # (1,) when single (mfg_ac2.py:311)
 
+    @_with_ctx
     def calc_gradient_vectorized(self, P, pi):
         """Score of the product-Dirichlet policy w.r.t. theta (mfg_ac2.py:347-381).  Like the reference it
         uses the concentrations of the LAST sample_action call when there is one (hidden state), and
@@ -368,6 +389,7 @@ class actor_critic:
             idx = idx[shard.traj_offset:shard.traj_offset + shard.local_batch]
         return torch.as_tensor(idx.astype(np.int32), device=self.device)
 
+    @_with_ctx
     def train(self, num_episodes=4000, gamma=1, constant=0, lr_critic=0.1, lr_actor=0.001, consecutive=100,
               file_theta='results/theta.csv', file_pi='results/pi.csv', file_reward='results/reward.csv',
               write_file=0, write_all=0, *, first_episode=0):
@@ -623,13 +645,21 @@ class actor_critic:
                 self.trace.append(float(self._theta.cpu()[0]))
         return pi
 
+    def status(self, synchronize=True) -> int:
+        """Bits of THIS instance's status word (0 = healthy; include/mfg_hip.h mfg_ctx_status)."""
+        return self._ctx.status(synchronize)
+
+    def clear_status(self):
+        """Reset this instance's sticky status word after a reported numeric-range condition (mfg_ctx_clear_status)."""
+        self._ctx.clear_status()
+
     def _check_status(self):
         """Raise MfgError if a launch of this run reported a numeric-range condition (mixed-precision sampling with
         theta outside its range, include/mfg_hip.h mfg_status) -- the end-of-train check; during a run the next sampling
-        launch after the condition is refused by the library itself.  The word is one per device: an instance the condition
-        cannot concern (strict precision, host-injected variates) does not raise for another instance's bit."""
-        if self.precision == 'mixed' and self.rng == 'philox' and ops.status(synchronize=True):
-            L.check(L.lib().mfg_status(None), 'train')
+        launch after the condition is refused by the library itself.  The word belongs to this instance's context: another
+        instance's diverged run neither raises here nor stops this one's launches."""
+        if self.precision == 'mixed' and self.rng == 'philox' and self._ctx.status(synchronize=True):
+            L.check(L.lib().mfg_ctx_status(self._ctx._ptr, None), 'train')
 
     def _train_log_extra(self):
         """Hook for the variants' additional per-report log lines (mfg_synthetic.py:522 logs w)."""
@@ -657,6 +687,7 @@ class actor_critic:
         out = out.cpu().numpy()
         return float(out[0]) if single else out
 
+    @_with_ctx
     def generate_trajectory(self, pi0, total_hours):
         """Rows pi^0 .. pi^{total_hours-1} under the current policy (mfg_ac2.py:566-592);
         (d,) -> (total_hours, d), (B,d) -> (B, total_hours, d)."""
@@ -707,6 +738,7 @@ class actor_critic:
         return torch.stack([diff[:, -1].mean(), std(diff[:, -1]), diff.mean(1).mean(), std(diff.mean(1)),
                             jsd[:, -1].mean(), std(jsd[:, -1]), jsd.mean(1).mean(), std(jsd.mean(1))])
 
+    @_with_ctx
     def evaluate(self, theta=8.86349, shift=0.5, alpha_scale=1e4, d=21, episode_length=16,
                  indir='test_normalized_round2', outfile='eval_mfg_round2/test_eval_fixed_reward.csv',
                  write_header=0):
@@ -724,6 +756,7 @@ class actor_critic:
             f.write('%f,%f,%f,%.3e,%.3e,%.3e,%.3e,%.3e,%.3e,%.3e,%.3e\n' % ((theta, shift, alpha_scale) + tuple(res)))
         return res[0], res[2], res[4], res[6]
 
+    @_with_ctx
     def gridsearch(self, theta_range, shift_range, alpha_range, indir, outfile):
         """Sweep (theta, shift, alpha_scale) and keep the best of each metric (mfg_ac2.py:673-689).  The test files
         are read once, every grid point is evaluated on the device back to back (one rollout + one JSD launch per

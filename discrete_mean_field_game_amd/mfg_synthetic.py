@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .mfg_ac2 import actor_critic as _base
+from .mfg_ac2 import _with_ctx, actor_critic as _base
 
 
 class actor_critic(_base):
@@ -35,6 +35,7 @@ class actor_critic(_base):
                 rows.append(list(map(float, f.readline().strip().split(' ')))[0:self.d])
         self.mat_pi0 = np.array(rows, dtype=np.float64)
 
+    @_with_ctx
     def train(self, num_episodes=4000, gamma=1, constant=0, lr_critic=0.1, lr_actor=0.001, consecutive=100,
               file_theta='results_syn/theta.csv', file_pi='results_syn/pi.csv', file_reward='results_syn/reward.csv',
               file_w='results_syn/w.csv', write_file=0, write_all=0, **kw):
@@ -55,6 +56,7 @@ class actor_critic(_base):
         if getattr(self, '_file_w', None):
             self.train_log(np.ravel(self.w), self._file_w, '%.5e')
 
+    @_with_ctx
     def calc_reward_vector(self, P):
         """v_i = -1/2 ||P_i||^2 (mfg_synthetic.py:726-738) via the backward kernel on a 1-step sequence."""
         Pd = self._P_dev(P)                               # [B,d,d]
@@ -62,12 +64,14 @@ class actor_critic(_base):
         v = V[:, 0].cpu().numpy()
         return v[0] if np.asarray(P).ndim == 2 else v
 
+    @_with_ctx
     def JSD(self, P, Q):
         """Entries <= 0 count as 1e-100 (mfg_synthetic.py:540-541; the base class only replaces exact zeros)."""
         P = np.array(P, dtype=np.float64); Q = np.array(Q, dtype=np.float64)
         P[P <= 0] = 0.0; Q[Q <= 0] = 0.0
         return super().JSD(P, Q)
 
+    @_with_ctx
     def generate_trajectory(self, pi0, total_hours):
         """(mat_trajectory [total_hours,d], array_actions [total_hours-1,d,d]) (mfg_synthetic.py:549-578);
         batched for (B,d) input."""
@@ -96,6 +100,7 @@ class actor_critic(_base):
         vals = (js if jsd else l1).cpu().numpy().reshape(-1)
         return float(np.mean(vals)), float(np.std(vals))
 
+    @_with_ctx
     def evaluate_synthetic(self, day_first=1, day_last=26, verbose=0):
         """Mean / std over (day, hour) of sum_ij |P_ij - value_ij| (mfg_synthetic.py:741-812)."""
         m, s = self._evaluate_synthetic(day_first, day_last, False)
@@ -104,6 +109,7 @@ class actor_critic(_base):
             print('Standard deviation', s)
         return m, s
 
+    @_with_ctx
     def evaluate_synthetic_JSD(self, day_first=1, day_last=26, write_file=0, filename='synthetic_log.csv', verbose=0):
         """Mean / std over (day, hour) of sum_i JSD(P_i, value-implied row i) (mfg_synthetic.py:815-899)."""
         m, s = self._evaluate_synthetic(day_first, day_last, True)

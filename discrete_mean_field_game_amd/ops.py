@@ -55,6 +55,57 @@ def clear_status():
     L.check(L.lib().mfg_clear_status(), 'mfg_clear_status')
 
 
+class Context:
+    """An mfg_ctx_t (include/mfg_hip.h): the mutable library state of ONE model instance -- its status word.  `bind()` makes it
+    the calling thread's current context: every ops.* call from this thread then reports into / is refused on this context's
+    word, not another instance's.  The drop-in classes create one each and bind it at the start of every public method."""
+
+    def __init__(self, device=None):
+        import ctypes as C
+        self._ptr = None
+        dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+        out = C.c_void_p()
+        with torch.cuda.device(dev):
+            L.check(L.lib().mfg_ctx_create(C.byref(out)), 'mfg_ctx_create')
+        self._ptr = out.value
+        self.device = dev
+
+    def bind(self):
+        lib = L.lib()
+        if lib.mfg_ctx_current() != self._ptr:
+            with torch.cuda.device(self.device):
+                L.check(lib.mfg_ctx_bind(self._ptr), 'mfg_ctx_bind')
+        return self
+
+    @staticmethod
+    def unbind():
+        L.check(L.lib().mfg_ctx_bind(None), 'mfg_ctx_bind')
+
+    def status(self, synchronize=True) -> int:
+        import ctypes as C
+        if synchronize:
+            torch.cuda.current_stream(self.device).synchronize()
+        bits = C.c_uint(0)
+        L.lib().mfg_ctx_status(self._ptr, C.byref(bits))
+        return int(bits.value)
+
+    def clear_status(self):
+        L.check(L.lib().mfg_ctx_clear_status(self._ptr), 'mfg_ctx_clear_status')
+
+    def close(self):
+        if self._ptr is not None:
+            try:
+                L.lib().mfg_ctx_destroy(self._ptr)           # (also unbinds it from THIS thread)
+            finally:
+                self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def num_features(d: int) -> int:
     return int(L.lib().mfg_num_features(d))
 

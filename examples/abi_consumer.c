@@ -40,6 +40,10 @@ int main(int argc, char** argv) {
   char arch[64];
   MFG_OK_(mfg_device_info(&cus, arch, (int)sizeof arch));
   MFG_OK_(mfg_init());
+  /* this program's library state (the status word of its launches) lives in a context of its own, bound to this thread */
+  mfg_ctx_t* ctx = NULL;
+  MFG_OK_(mfg_ctx_create(&ctx));
+  MFG_OK_(mfg_ctx_bind(ctx));
 
   /* deterministic inputs that the Python side can rebuild: start states, start indices, critic weights */
   float* mat_h = (float*)malloc(sizeof(float) * num_start * d);
@@ -91,8 +95,8 @@ int main(int argc, char** argv) {
   HIP_OK(hipStreamSynchronize(st));
   { /* numeric sanitiser of the boundary: a launch that met theta outside the mixed-precision range would have reported it */
     unsigned status_bits = 1u;
-    MFG_OK_(mfg_status(&status_bits));
-    if (status_bits != 0u) return 3;
+    MFG_OK_(mfg_ctx_status(ctx, &status_bits));
+    if (status_bits != 0u || mfg_ctx_current() != ctx) return 3;
   }
 
   double racc_h = 0.0, count = 0.0;
@@ -121,5 +125,7 @@ int main(int argc, char** argv) {
          "\"mean_reward_acc\": %.17g, \"count\": %.0f, \"theta_after_native_loop\": %.17g, "
          "\"native_loop_rewards\": [%.17g, %.17g, %.17g]}\n",
          mfg_abi_version(), arch, cus, (long long)B, theta_h, wsum, racc_h, count, theta2, racc3_h[0], racc3_h[1], racc3_h[2]);
+  MFG_OK_(mfg_ctx_destroy(ctx)); /* (also unbinds it from this thread) */
+  if (mfg_ctx_current() != NULL) return 3;
   return 0;
 }

@@ -80,13 +80,38 @@ int mfg_init(void);
  * not finite) sets MFG_STATUS_MIXED_RANGE in a host-visible status word and its outputs are NaN.  Every later call that
  * launches a mixed-precision SAMPLING kernel (sample / rollout / train entry points with MFG_PRECISION_MIXED) then fails
  * with MFG_ERANGE until mfg_clear_status() -- a diverged run stops with an error code instead of carrying NaNs.  The word is
- * one per device and process: launches the condition does not concern (MFG_PRECISION_F64, kernels on given actions) are
+ * one per CONTEXT (below; one per device and process for callers that never bind one): launches the condition does not concern (MFG_PRECISION_F64, kernels on given actions) are
  * not refused, so another model instance or thread on the device keeps working.  mfg_status() reads the word without
  * synchronising (synchronise the stream first to be sure a given launch has reported); it returns MFG_OK or MFG_ERANGE and
  * stores the bits in *bits_host (may be NULL). */
 enum { MFG_STATUS_MIXED_RANGE = 1 };
 int mfg_status(unsigned* bits_host);
 int mfg_clear_status(void);
+
+/* Contexts ("no global mutable state except an opaque mfg_ctx*").  The mutable state a launch touches -- the
+ * status word above, optionally an RCCL communicator -- belongs to a context; everything else the library keeps is immutable
+ * (the h(z) table, per device) or passed in by the caller (workspaces).  Model: the CURRENT context of the calling thread,
+ * like the current device of the HIP runtime -- mfg_ctx_bind(ctx) makes `ctx` the context of every entry point this thread
+ * calls from then on (sampling launches report into ITS status word and are refused on ITS sticky bits; mfg_status /
+ * mfg_clear_status act on it); mfg_ctx_bind(NULL) returns to the device's default context, which is what a thread that never
+ * binds uses (the process-wide word of ABI <= 14: existing callers keep their behaviour).  Two model instances with a context
+ * each cannot stop each other: a diverged run poisons only its own word.
+ *   mfg_ctx_create      on the current device (initialises the device's table like mfg_init); one context per model instance
+ *   mfg_ctx_destroy     also unbinds it from the calling thread and destroys an adopted communicator
+ *   mfg_ctx_bind        thread-local, no device work; fails with MFG_EINVAL if ctx belongs to another device than the current
+ *   mfg_ctx_status / mfg_ctx_clear_status   explicit-context forms of mfg_status / mfg_clear_status
+ *   mfg_ctx_adopt_comm  hand a communicator from mfg_dist_init to the context (lifetime); mfg_ctx_comm returns it
+ * Captured hipGraphs: the status-word address is baked into the captured kernel arguments (the capturing thread's context);
+ * a replay reports into that word but is not refused on it -- check mfg_ctx_status after synchronising a replay. */
+typedef struct mfg_ctx mfg_ctx_t;
+int mfg_ctx_create(mfg_ctx_t** ctx_out);
+int mfg_ctx_destroy(mfg_ctx_t* ctx);
+int mfg_ctx_bind(mfg_ctx_t* ctx);
+mfg_ctx_t* mfg_ctx_current(void);
+int mfg_ctx_status(mfg_ctx_t* ctx, unsigned* bits_host);
+int mfg_ctx_clear_status(mfg_ctx_t* ctx);
+int mfg_ctx_adopt_comm(mfg_ctx_t* ctx, void* comm);
+void* mfg_ctx_comm(mfg_ctx_t* ctx);
 
 /* Host-side query: multiprocessor count and gcnArchName of the current device. */
 int mfg_device_info(int* cu_count_host, char* arch_host, int arch_len);

@@ -1177,3 +1177,44 @@ def test_given_P_wave_kernel_ragged_tiles(dev, d, B):
     assert np.max(np.abs(r.cpu().numpy() - ref) / np.maximum(np.abs(ref), 1e-6)) < 1e-6
     pn2, none = ops.step_given_P(torch.as_tensor(pi, device=dev), torch.as_tensor(P, device=dev), want_reward=False)
     assert none is None and torch.equal(pn2, pn)
+
+
+def test_contexts_isolate_the_status_word_between_instances(dev):
+    """SURVEY.md 8b / VERDICT r4 item 4: the sticky status word belongs to a context (mfg_ctx_t); every model instance owns one
+    and binds it in its public methods.  A diverged mixed-precision run poisons ITS word: it is refused from then on
+    (MFG_ERANGE), while a second instance on the same device -- and a caller that never binds a context (the default one) --
+    keep sampling.  Clearing is per context too."""
+    import ctypes as C
+    from discrete_mean_field_game_amd import ops, _lib as L
+    d = 21
+    rs = np.random.RandomState(0)
+    mat = rs.dirichlet(np.ones(d), size=4)
+    a = AC(d=d, pi0=mat, batch=32, seed=1, update_every='rollout', verbose=0)
+    b = AC(d=d, pi0=mat, batch=32, seed=2, update_every='rollout', verbose=0)
+    assert a._ctx._ptr != b._ctx._ptr
+    with pytest.raises(L.MfgError, match='mfg_clear_status'):
+        a.train(num_episodes=3, lr_actor=1e300, lr_critic=1e300)          # diverges: theta leaves the mixed-precision range
+    assert a.status() == L.STATUS_MIXED_RANGE and b.status() == 0
+    b.train(num_episodes=2)                                               # the other instance is not stopped ...
+    assert np.isfinite(np.ravel(b.theta)[0]) and b.status() == 0
+    P = b.sample_action(mat[0])
+    assert np.all(np.isfinite(P))
+    a.theta = 8.86349                                                     # ... while the poisoned one stays refused until cleared
+    with pytest.raises(L.MfgError):
+        a.sample_action(mat[0])
+    # a caller without a context: the device's default word, untouched by either instance
+    ops.Context.unbind()
+    assert L.lib().mfg_ctx_current() is None and ops.status() == 0
+    th = torch.tensor([8.86349], dtype=torch.float64, device=dev)
+    pi = torch.as_tensor(mat.astype(np.float32), device=dev)
+    assert torch.isfinite(ops.sample_dirichlet(pi, th, 0.16, 12000.0, seed=3)).all()
+    a.clear_status()
+    a.w = a.init_w(d)                                                     # (the diverged critic weights too)
+    assert a.status() == 0 and np.all(np.isfinite(a.sample_action(mat[0])))
+    assert L.lib().mfg_ctx_current() == a._ctx._ptr                       # the method bound its instance's context
+    # a context of its own for plain ops.* callers; destroying the bound context unbinds it
+    c = ops.Context(dev).bind()
+    assert L.lib().mfg_ctx_current() == c._ptr and c.status() == 0
+    c.close()
+    assert L.lib().mfg_ctx_current() is None
+    assert L.lib().mfg_abi_version() >= 15
