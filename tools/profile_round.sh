@@ -3,7 +3,7 @@
 # kernels at d = 21 / 128 / 256, SQ issue counters of the fused rollout kernels at the bench shape, C3 and the C5 share).
 # Counters are collected in their own runs (never combined with the trace domains gpurun refuses).
 # usage: bash tools/profile_round.sh <tag>     (outputs under gpurun_out/<tag>/; copy the summaries into profiles/)
-R=$GRAFT_REPO_ROOT; TAG=${1:-r04}; O=$R/gpurun_out/$TAG; mkdir -p $O
+R=$GRAFT_REPO_ROOT; TAG=${1:-r05}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 # (the CPU-baseline leg forks one process per host core; it is left out of the traced run -- the kernels are the same)
@@ -33,7 +33,9 @@ python3 $R/tools/shard_table.py > $O/shards.txt 2>&1
 [ -x $R/tools/micro/valu_rates ] && $R/tools/micro/valu_rates > $O/valu_rates.txt 2>&1
 [ -x $R/tools/micro/mfma_f64_rate ] && $R/tools/micro/mfma_f64_rate > $O/mfma_f64_rate.txt 2>&1
 [ -x $R/tools/micro/mfma_valu_overlap ] && $R/tools/micro/mfma_valu_overlap > $O/mfma_valu_overlap.txt 2>&1
-for SH in 21,15,65536 128,40,16384 256,40,16384; do bash $R/tools/cycle_table.sh $SH > $O/cycle_table_d${SH%%,*}.txt 2>&1; done
+# (cycle tables need the ablation variant libraries of tools/ablate.sh under csrc/variants, which no longer travel to the GPU box:
+#  built into MFG_VARIANT_DIR=csrc/ab when a round changes the fused kernels; round 5 did not)
+[ -d $R/discrete_mean_field_game_amd/csrc/variants/abl ] && for SH in 21,15,65536 128,40,16384 256,40,16384; do bash $R/tools/cycle_table.sh $SH > $O/cycle_table_d${SH%%,*}.txt 2>&1; done
 bash $R/tools/trace_gaps.sh $R/tools/irl_mode_probe.py 4096 > $O/irl_step_mode_trace.txt 2>&1
 python3 $R/tools/perf_train.py 4096 > $O/perf_train_4096.txt 2>&1
 python3 $R/tools/perf_train.py 65536 > $O/perf_train_65536.txt 2>&1
@@ -44,6 +46,11 @@ python3 $R/tools/rn_probe.py 4096 65536 > $O/rn_probe.txt 2>&1
 V=$R/discrete_mean_field_game_amd/csrc/variants/librn_stamps.so
 [ -f $V ] && MFG_HIP_LIB=$V python3 $R/tools/rn_stamps.py 4096 > $O/rn_stamps_4096.txt 2>&1
 bash $R/tools/pmc_sq.sh k_reward_net_mfma $R/tools/rn_probe.py 65536 > $O/pmc_sq_reward_net_65536.txt 2>&1
+# round 5: the IRL experiment: reward-learning kernels (event timed + rocprofv3 per-kernel table), outer-loop split, rollout-mode trace
+python3 $R/tools/rn_train_probe.py > $O/rn_train_probe.txt 2>&1
+bash $R/tools/prof_any.sh $R/tools/rn_train_probe.py > $O/rn_train_kernel_stats.txt 2>&1
+python3 $R/tools/irl_outer_probe.py 4096 3 100 200 > $O/irl_outer_probe_4096.txt 2>&1
+TG_ROWS=30 bash $R/tools/trace_gaps.sh $R/tools/irl_rollout_probe.py 4096 > $O/irl_rollout_mode_trace.txt 2>&1
 cd /tmp
 # round 4: the multi-rank update cycle on a 1-rank RCCL communicator (bench.py --force-dist: per-episode loop, deferred update,
 # ONE all-reduce per update) at the 8-GPU shard and the full batch, with the measured latency of the exchange step
