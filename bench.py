@@ -407,6 +407,12 @@ def main():
                                             'region, not a share of ms_per_step: run-to-run scatter of ~2 % can put it above the headline',
                          'env_steps_per_s': B * T / t_f, 'hbm_algorithmic_GBs': B * T * bytes_per_step / t_f / 1e9}
                 fused.update(pmc_sq('k_core_', d, T, B))
+                # the kernel the HEADLINE times, on both lines: its share of the HBM roofline (it never sends P through HBM, so this
+                # is small by construction) and of the VALU issue bound that actually limits it (committed SQ counters)
+                fused['headline_frac_of_hbm_line'] = value * bytes_per_step / 1e9 / HBM_PEAK_GBS
+                fused['headline_bound'] = ('VALU issue: valu_busy %.2f of the kernel time, priced issue work ~0.76-0.9 of the SIMD cycles '
+                                           '(profiles/r04_cycle_table_d21.txt); the roofline object above is the given-P kernel'
+                                           % fused.get('valu_busy', float('nan')))
                 # host-boundness of the class API: the same updates issued by one native call, GPU time from events
                 t_native = native_leg(d, T, B, args.steps, args.warmup)
                 fused['native_loop_ms_per_step'] = t_native / args.steps * 1e3
@@ -430,6 +436,9 @@ def main():
                        'theta0': theta0, 'shift': shift, 'alpha_scale': alpha_scale, 'rng': 'philox4x32-10',
                        'parallelism': 'trajectory-sharded x%d, 1 all-reduce/update' % world},
             'theta_end': theta_end,
+            'modes': {'headline': "update_every='rollout' (one update per 15-step episode)",
+                      'class_default': "update_every='step' (the reference's update after every env step, mfg_ac2.py:505-522): see the "
+                                       "'update per env step' entries of `configs`"},
             'roofline': roofline, 'fused_kernel': fused, 'cpu_baseline': cpu,
         }
         if collective is not None:

@@ -275,7 +275,6 @@ class AC_IRL(actor_critic):
         native_rollout = (fused_episode and shard.world == 1 and reward_fn is None and self.trace is None
                           and self.reward_net is not None and ops.reward_net_supported(self.reward_net)
                           and self._device_draw())
-        ep_acc = torch.zeros(max_episodes + 1, dtype=torch.float64, device=self.device) if native_rollout else None
         # per-step updates on one GPU with the reward network's HIP kernel: the whole episode (15 x [sample + transition +
         # score | reward net | batch sums + update]) is issued by native code (mfg_train_episode_irl)
         native_episode = (self.update_every == 'step' and self.rng == 'philox' and shard.world == 1 and reward_fn is None
@@ -283,6 +282,8 @@ class AC_IRL(actor_critic):
                           and ops.reward_net_supported(self.reward_net))
         if native_episode:
             nbufs = dict(ops.episode_buffers(Bl, d, self.device), P=rbufs['P'])
+        # per-episode return accumulators of the native paths: ONE zeroed buffer per train() call instead of a fill kernel per episode
+        ep_acc = torch.zeros(max_episodes + 1, dtype=torch.float64, device=self.device) if (native_rollout or native_episode) else None
         prev_theta = float(self._theta.cpu()[0])
         list_reward = []
         episode = 0
@@ -319,7 +320,8 @@ class AC_IRL(actor_critic):
             else:
                 pi = ops.gather_start(self._mat_pi0_dev, self._draw_start(shard))       # ac_irl.py:655
             discount = 1.0
-            total_reward = torch.zeros(1, dtype=torch.float64, device=self.device)
+            total_reward = (ep_acc[episode - first_episode:episode - first_episode + 1] if native_episode
+                            else torch.zeros(1, dtype=torch.float64, device=self.device))
             if fused_episode:
                 # one update per episode: theta and w are fixed over the 15 steps, so the whole episode is THREE launches:
                 # the fused rollout (running discount gamma^t, P of every step materialised for the network), one

@@ -111,18 +111,31 @@ def forward_cache(params, state, action, masks=None):
     """forward() that also returns what backward() needs.  masks = (m3 [N,n3], m4 [N,n4]) of 0 / (1/keep) or None."""
     N, d = state.shape
     x0 = action.reshape(N, d, d, 1).astype(np.float64)
-    a1 = np.maximum(conv2d_same(x0, params['conv1_w'], params['conv1_b']), 0)
-    a2 = np.maximum(conv2d_same(a1, params['conv2_w'], params['conv2_b']), 0)
+    z1 = conv2d_same(x0, params['conv1_w'], params['conv1_b'])
+    a1 = np.maximum(z1, 0)
+    z2 = conv2d_same(a1, params['conv2_w'], params['conv2_b'])
+    a2 = np.maximum(z2, 0)
     flat = a2.reshape(N, -1)
-    h3 = np.maximum(flat.dot(params['fc3_w']) + params['fc3_b'], 0)
+    z3 = flat.dot(params['fc3_w']) + params['fc3_b']
+    h3 = np.maximum(z3, 0)
     if masks is not None:
         h3 = h3 * masks[0]
     in4 = np.concatenate([h3, state.astype(np.float64)], axis=1)
-    h4 = np.maximum(in4.dot(params['fc4_w']) + params['fc4_b'], 0)
+    z4 = in4.dot(params['fc4_w']) + params['fc4_b']
+    h4 = np.maximum(z4, 0)
     if masks is not None:
         h4 = h4 * masks[1]
     r = np.tanh(h4.dot(params['out_w']) + params['out_b'])
-    return r, dict(x0=x0, a1=a1, a2=a2, flat=flat, h3=h3, in4=in4, h4=h4, r=r, masks=masks)
+    # smallest |pre-activation| of a ReLU, relative to the magnitude of the terms it sums: an fp32 evaluation may land on the
+    # other side of a kink this close to zero, and the gradient then differs by that unit's whole contribution -- a dense
+    # unit carries a sample's whole share of the fc gradients, a conv pixel ~1e-4 of a conv-weight gradient (one of ~8 000
+    # pixel terms).  The randomised soak (tools/rn_train_soak.py) skips such draws.
+    m3 = np.abs(flat).dot(np.abs(params['fc3_w'])) + np.abs(params['fc3_b'])
+    m4 = np.abs(in4).dot(np.abs(params['fc4_w'])) + np.abs(params['fc4_b'])
+    m1 = conv2d_same(np.abs(x0), np.abs(params['conv1_w']), np.abs(params['conv1_b']))
+    m2 = conv2d_same(np.abs(a1), np.abs(params['conv2_w']), np.abs(params['conv2_b']))
+    kink = min(float((np.abs(z) / np.maximum(m, 1e-300)).min()) for z, m in ((z1, m1), (z2, m2), (z3, m3), (z4, m4)))
+    return r, dict(x0=x0, a1=a1, a2=a2, flat=flat, h3=h3, in4=in4, h4=h4, r=r, masks=masks, kink=kink)
 
 
 def _conv_backward(x, w, dz):
