@@ -631,8 +631,7 @@ class AC_IRL(actor_critic):
         its own list of pairs (e.g. get_eval_transitions)."""
         if override is not None:
             return self._pairs_to_tensors(override)
-        st, ac = store.gather()
-        return st.reshape(-1, self.d), ac.reshape(-1, self.d, self.d)
+        return store.gather_flat()
 
     def _eval_reward_averages(self):
         """Mean reward over the demonstration / generated evaluation transitions (ac_irl.py:868-883): two forward launches

@@ -30,6 +30,7 @@
 
 #include "../../include/mfg_hip.h"
 #include "mfg_core.h"
+#include "mfg_rn_common.h"
 
 namespace mfg {
 
@@ -84,7 +85,8 @@ __device__ void rn_train_reg_block(const struct RtArgs& a, const RtLayout& L);
 
 // K1 / K2 / F2 > 0: compile-time conv geometry (the reference's 5 / 3 / 2: taps unroll, weights come as scalar loads,
 // the weight-gradient accumulators stay in registers); 0 = run-time geometry, tap by tap (any odd k <= 7, f2 <= 2).
-template <int K1, int K2, int F2>
+// QA: fc3 inputs per thread (4 covers f2 d^2 <= 1024, i.e. d <= 22 with two filters; 8 everything up to d = 32)
+template <int K1, int K2, int F2, int QA>
 __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float red[RT_WAVES][64];
@@ -120,11 +122,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
   //     when n3 <= RT_KC; their latency hides behind the convolutions);
   //   * all other weights (~180 floats) go to LDS.
   const float* W3 = P + L.o_w3;
-  float w3r[RT_KC][RT_QA];
+  float w3r[RT_KC][QA];
 #pragma unroll
   for (int kk = 0; kk < RT_KC; ++kk)
 #pragma unroll
-    for (int q = 0; q < RT_QA; ++q) {
+    for (int q = 0; q < QA; ++q) {
       const int i = tid + q * RT_BLOCK;
       w3r[kk][q] = (kk < n3 && i < L.a2) ? W3[(int64_t)kk * L.a2 + i] : 0.0f;
     }
@@ -146,9 +148,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
   for (int q = 0; q < RT_PP; ++q)
     if (tid + q * RT_BLOCK < dd) tin[(py[q] + h1) * W1 + px[q] + h1] = actv[q];
   __syncthreads();
-  // weights of the convolutions from LDS (uniform addresses: broadcast reads)
-  const float* c1w = sw + L.o_c1w;
-  const float* c2w = sw + L.o_c2w;
+  // weights of the convolutions: compile-time geometry -> scalar loads from read-only memory (uniform addresses, no vector or
+  // LDS instruction per tap); run-time geometry -> broadcast reads of the LDS copy
+  RnConstF c1w_g = (RnConstF)(P + L.o_c1w), c2w_g = (RnConstF)(P + L.o_c2w);
+  const float* c1w_l = sw + L.o_c1w;
+  const float* c2w_l = sw + L.o_c2w;
+  auto c1w = [&](int k) __attribute__((always_inline)) { return K1 ? c1w_g[k] : c1w_l[k]; };
+  auto c2w = [&](int k) __attribute__((always_inline)) { return K1 ? c2w_g[k] : c2w_l[k]; };
   // ---- forward: conv1 + ReLU
   float a1v[RT_PP];
 #pragma unroll
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
 #pragma unroll
       for (int dy = 0; dy < (K1 ? K1 : k1); ++dy)
 #pragma unroll
-        for (int dx = 0; dx < (K1 ? K1 : k1); ++dx) s = fmaf(tp[dy * W1 + dx], c1w[dy * k1 + dx], s);
+        for (int dx = 0; dx < (K1 ? K1 : k1); ++dx) s = fmaf(tp[dy * W1 + dx], c1w(dy * k1 + dx), s);
       a1v[q] = fmaxf(s, 0.0f);
       a1p[(py[q] + h2) * W2 + px[q] + h2] = a1v[q];
     }
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
           for (int dy = 0; dy < (K2 ? K2 : k2); ++dy)
 #pragma unroll
             for (int dx = 0; dx < (K2 ? K2 : k2); ++dx)
-              s = fmaf(tp[dy * W2 + dx], c2w[c * k2 * k2 + dy * k2 + dx], s);
+              s = fmaf(tp[dy * W2 + dx], c2w(c * k2 * k2 + dy * k2 + dx), s);
           a2s[p * f2 + c] = fmaxf(s, 0.0f);
         }
       }
@@ -188,9 +194,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
   }
   __syncthreads();
   // ---- fc3: thread owns inputs i = tid + 256 q
-  float a2v[RT_QA];
+  float a2v[QA];
 #pragma unroll
-  for (int q = 0; q < RT_QA; ++q) {
+  for (int q = 0; q < QA; ++q) {
     const int i = tid + q * RT_BLOCK;
     a2v[q] = i < L.a2 ? a2s[i] : 0.0f;
   }
@@ -202,27 +208,30 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
       float sacc = 0.0f;
       if (k0 == 0) {
 #pragma unroll
-        for (int q = 0; q < RT_QA; ++q) sacc = fmaf(a2v[q], w3r[kk][q], sacc);
+        for (int q = 0; q < QA; ++q) sacc = fmaf(a2v[q], w3r[kk][q], sacc);
       } else if (k0 + kk < n3) {
-        float wv[RT_QA];
+        float wv[QA];
 #pragma unroll
-        for (int q = 0; q < RT_QA; ++q) {
+        for (int q = 0; q < QA; ++q) {
           const int i = tid + q * RT_BLOCK;
           wv[q] = i < L.a2 ? W3[(int64_t)(k0 + kk) * L.a2 + i] : 0.0f;
         }
 #pragma unroll
-        for (int q = 0; q < RT_QA; ++q) sacc = fmaf(a2v[q], wv[q], sacc);
+        for (int q = 0; q < QA; ++q) sacc = fmaf(a2v[q], wv[q], sacc);
       }
       part[kk] = sacc;
     }
+    // wave sums on the DPP path, four at a time (24 adds per group; a shuffle tree is six LDS-pipe permutes per sum)
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
+    for (int g4 = 0; g4 < RT_KC; g4 += 4) {
+      float p4[4] = {part[g4], part[g4 + 1], part[g4 + 2], part[g4 + 3]};
+      wave_sum4_to_lane63(p4);
+      if (lane == 63) {
 #pragma unroll
-      for (int kk = 0; kk < RT_KC; ++kk) part[kk] += __shfl_xor(part[kk], off, WAVE);
-    if (lane == 0)
-#pragma unroll
-      for (int kk = 0; kk < RT_KC; ++kk)
-        if (k0 + kk < n3) red[wv][k0 + kk] = part[kk];
+        for (int u = 0; u < 4; ++u)
+          if (k0 + g4 + u < n3) red[wv][k0 + g4 + u] = p4[u];
+      }
+    }
   }
   __syncthreads();
   const bool drop = a.keep_prob < 1.0f;
@@ -290,7 +299,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
   // ---- fc3 backward: d a2, stored factored (a2, dz3) for the combine kernel; dz2 into the padded maps
   float gb2[2] = {0.0f, 0.0f};
 #pragma unroll
-  for (int q = 0; q < RT_QA; ++q) {
+  for (int q = 0; q < QA; ++q) {
     const int i = tid + q * RT_BLOCK;
     if (i < L.a2) {
       float da = 0.0f;
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
             for (int dx = 0; dx < K2; ++dx) {
               acc[c * K2 * K2 + dy * K2 + dx] = fmaf(dzc, ap[dy * W2 + dx], acc[c * K2 * K2 + dy * K2 + dx]);
               // a1[y,x] feeds a2[c, y - dy + h2, x - dx + h2] through tap (dy, dx)
-              da1 = fmaf(c2w[c * K2 * K2 + dy * K2 + dx], zc[(y - dy + 2 * h2) * W2 + (x - dx + 2 * h2)], da1);
+              da1 = fmaf(c2w(c * K2 * K2 + dy * K2 + dx), zc[(y - dy + 2 * h2) * W2 + (x - dx + 2 * h2)], da1);
             }
         }
         const float dz1 = a1v[q] > 0.0f ? da1 : 0.0f;
@@ -350,9 +359,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
       }
     }
 #pragma unroll
-    for (int k = 0; k < NACC; ++k) {
-      const float s = wave_sum(acc[k]);
-      if (lane == 0) red[wv][k] = s;
+    for (int k = 0; k < NACC; k += 4) {
+      float p4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p4[u] = k + u < NACC ? acc[k + u] : 0.0f;
+      wave_sum4_to_lane63(p4);
+      if (lane == 63) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (k + u < NACC) red[wv][k + u] = p4[u];
+      }
     }
     __syncthreads();
     if (tid < NACC) {
@@ -375,7 +391,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_sample(RtArgs a) {
         for (int c = 0; c < f2; ++c)
           for (int dy = 0; dy < k2; ++dy)
             for (int dx = 0; dx < k2; ++dx)
-              da1 = fmaf(c2w[c * k2 * k2 + dy * k2 + dx],
+              da1 = fmaf(c2w(c * k2 * k2 + dy * k2 + dx),
                          dz2p[c * W2 * W2 + (y - dy + 2 * h2) * W2 + (x - dx + 2 * h2)], da1);
         dz1v[q] = a1v[q] > 0.0f ? da1 : 0.0f;
       }
@@ -458,10 +474,10 @@ __device__ __forceinline__ float adam_param(float p, float g, float& m, float& v
 }
 
 // block = RT_CP consecutive parameters x RT_WAVES sample slices: wave s sums the samples n = s, s + 4, ... of the block's 64
-// parameters (coalesced: lane = parameter), RT_CU loads in flight per lane; the four slice sums meet in LDS and are added in
+// parameters (coalesced: lane = parameter), RT_CU loads in flight per lane (the first round issued before anything else); the four slice sums meet in LDS and are added in
 // slice order (fixed association: bit-reproducible).  The first version ran one thread per parameter over all 150 samples
 // with a load and an integer division per iteration: 30 us, all of it L2 latency.
-constexpr int RT_CP = WAVE, RT_CU = 10;
+constexpr int RT_CP = WAVE, RT_CU = 38, RT_DZ = 8;  // RT_CU: one round covers 4 x 38 = 152 samples (the reference batch is 150; a second round of reads cost 4 us)
 __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_combine(RtCombineArgs a) {
   __shared__ float s_c[2 * RT_MAX_TRAJ];  // dL/dr per trajectory: demonstrations, then generated
   __shared__ float s_S[RT_MAX_TRAJ];
@@ -473,20 +489,40 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_combine(RtCombineArgs a) 
   const int nd = a.n_demo, ng = a.n_gen, T = a.steps, n3 = a.n3;
   const int N = (nd + ng) * T;
   float* s_cdz = s_cn + N;
-  // issue the block's first loads before the coefficient phase needs anything
+  const int p0 = blockIdx.x * RT_CP;
+  const bool any_w3 = p0 + RT_CP > L.o_w3 && p0 < L.o_b3;
+  const int p = p0 + lane;
+  const bool live = p < L.np, w3 = live && p >= L.o_w3 && p < L.o_b3;
+  const int k3 = w3 ? (p - L.o_w3) / L.a2 : 0;
+  const float* src = w3 ? a.a2 + ((p - L.o_w3) - k3 * L.a2) : a.js + (live ? rt_small(L, p) : 0);
+  const int64_t stride = w3 ? L.a2 : L.ns;
+  // Every read that does not depend on the coefficients is issued HERE, before the coefficient phase waits for the rewards:
+  // the rewards, the block's share of dz3, and the FIRST round of this lane's Jacobian column (the kernel is a latency chain:
+  // rewards -> soft-max -> weighted sums -> Adam; 18 us in the version that started the column reads after the soft-max).
+  // (UNCONDITIONAL loads from clamped addresses, masked where they are used: a load under a lane predicate compiles to a
+  //  branch with a full wait behind it -- the first version of this block issued its 38 column reads one after the other)
   float r_mine[8];
 #pragma unroll
   for (int u = 0; u < 8; ++u) {
     const int n = tid + u * RT_BLOCK;
-    r_mine[u] = n < N ? a.r[n] : 0.0f;
+    r_mine[u] = a.r[n < N ? n : 0];
   }
-  if (tid < ng) s_S[tid] = 0.0f;
-  __syncthreads();
-  // S_j = sum_t r[j, t]: one thread per generated trajectory would read 15 values one after the other; N <= 1920 = 8 x 256
-  // values are already in registers, so trajectory sums go through LDS in step order (fixed association per trajectory)
+  float dz_mine[RT_DZ];
 #pragma unroll
-  for (int u = 0; u < 8; ++u) s_cn[(tid + u * RT_BLOCK) < N ? tid + u * RT_BLOCK : 0] = 0.0f;
-  __syncthreads();
+  for (int u = 0; u < RT_DZ; ++u) {
+    const int e = tid + u * RT_BLOCK;
+    dz_mine[u] = a.dz3[e < N * n3 ? e : 0];
+  }
+  float x0[RT_CU];
+#pragma unroll
+  for (int u = 0; u < RT_CU; ++u) {
+    const int n = wv + u * RT_WAVES;
+    x0[u] = src[(int64_t)(n < N ? n : 0) * stride];
+  }
+  const int pc = live ? p : 0;
+  const float w_old = a.params[pc];
+  const float m_old = a.m ? a.m[pc] : 0.0f, v_old = a.v ? a.v[pc] : 0.0f;   // (uniform pointers: scalar branches)
+  // S_j = sum_t r[j, t] in step order (fixed association per trajectory), the first term's sum on another wave
 #pragma unroll
   for (int u = 0; u < 8; ++u)
     if (tid + u * RT_BLOCK < N) s_cn[tid + u * RT_BLOCK] = r_mine[u];
@@ -497,64 +533,71 @@ __global__ __launch_bounds__(RT_BLOCK) void k_rn_train_combine(RtCombineArgs a) 
     s_S[tid] = sacc;
   }
   if (tid < nd) s_c[tid] = -a.demo_scale;
-  float sd = 0.0f;
-  if (tid == 64) {  // (another wave than the soft-max below) first term: sum of the demonstration rewards
-    for (int n = 0; n < nd * T; ++n) sd += s_cn[n];
-    s_stat[1] = sd;
+  if (wv == 1) {  // first term: sum of the demonstration rewards, one wave (lane-strided partial sums in index order + a DPP tree)
+    float sd = 0.0f;
+    for (int n = lane; n < nd * T; n += WAVE) sd += s_cn[n];
+    sd = wave_sum_f32_dpp(sd);
+    if (lane == 0) s_stat[1] = sd;
   }
   __syncthreads();
-  if (tid == 0) {
-    float mx = -INFINITY;
-    for (int jj = 0; jj < ng; ++jj) mx = fmaxf(mx, s_S[jj]);
-    float z = 0.0f;
-    for (int jj = 0; jj < ng; ++jj) z += expf(s_S[jj] - mx);
-    for (int jj = 0; jj < ng; ++jj) s_c[nd + jj] = ng ? expf(s_S[jj] - mx) / z : 0.0f;
-    s_stat[0] = ng ? mx + logf(z / (float)ng) : 0.0f;  // = log( 1/M sum exp S_j )
+  if (wv == 0) {  // soft-max over the generated trajectories (<= 64: one per lane) and log-mean-exp, wave-parallel
+    const float Sj = lane < ng ? s_S[lane] : -INFINITY;
+    float mx = Sj;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, WAVE));
+    const float ej = lane < ng ? expf(Sj - mx) : 0.0f;
+    const float z = wave_sum_f32_dpp(ej);
+    if (lane < ng) s_c[nd + lane] = ej / z;
+    if (lane == 0) s_stat[0] = ng ? mx + logf(z / (float)ng) : 0.0f;  // = log( 1/M sum exp S_j )
   }
   __syncthreads();
   // per-sample coefficient, and c_n dz3_n for the factored fc3_w gradient
   for (int n = tid; n < N; n += RT_BLOCK) s_cn[n] = s_c[n / T];
   __syncthreads();
-  const int p0 = blockIdx.x * RT_CP;
-  const bool any_w3 = p0 + RT_CP > L.o_w3 && p0 < L.o_b3;
   if (any_w3) {
-    for (int e = tid; e < N * n3; e += RT_BLOCK) s_cdz[e] = s_cn[e / n3] * a.dz3[e];
+#pragma unroll
+    for (int u = 0; u < RT_DZ; ++u) {
+      const int e = tid + u * RT_BLOCK;
+      if (e < N * n3) s_cdz[e] = s_cn[e / n3] * dz_mine[u];
+    }
+    for (int e = tid + RT_DZ * RT_BLOCK; e < N * n3; e += RT_BLOCK) s_cdz[e] = s_cn[e / n3] * a.dz3[e];  // (batches beyond 256 x RT_DZ entries)
     __syncthreads();
   }
-  const int p = p0 + lane;
   // the sum over the batch runs in fp64: its terms (demonstrations -, generated +) cancel to a small net value, and an
-  // fp32 running sum would leave ~1e-7 of the LARGEST partial sum in it
+  // fp32 running sum would leave ~1e-7 of the LARGEST partial sum in it.  Wave s owns the samples s, s + 4, ... of the
+  // block's 64 parameters; the four slice sums are added in slice order (fixed association: bit-reproducible).
   double gs = 0.0;
-  if (p < L.np) {
-    const bool w3 = p >= L.o_w3 && p < L.o_b3;
-    const int k = w3 ? (p - L.o_w3) / L.a2 : 0;
-    const float* src = w3 ? a.a2 + ((p - L.o_w3) - k * L.a2) : a.js + rt_small(L, p);
-    const int64_t stride = w3 ? L.a2 : L.ns;
-    for (int n0 = wv; n0 < N; n0 += RT_WAVES * RT_CU) {
+  if (live) {
+#pragma unroll
+    for (int u = 0; u < RT_CU; ++u) {
+      const int n = wv + u * RT_WAVES;
+      if (n < N) gs = fma((double)(w3 ? s_cdz[n * n3 + k3] : s_cn[n]), (double)x0[u], gs);
+    }
+    for (int n0 = wv + RT_CU * RT_WAVES; n0 < N; n0 += RT_WAVES * RT_CU) {
       float x[RT_CU];
 #pragma unroll
       for (int u = 0; u < RT_CU; ++u) {
         const int n = n0 + u * RT_WAVES;
-        x[u] = n < N ? src[(int64_t)n * stride] : 0.0f;
+        x[u] = src[(int64_t)(n < N ? n : 0) * stride];
       }
 #pragma unroll
       for (int u = 0; u < RT_CU; ++u) {
         const int n = n0 + u * RT_WAVES;
-        if (n < N) gs = fma((double)(w3 ? s_cdz[n * n3 + k] : s_cn[n]), (double)x[u], gs);
+        if (n < N) gs = fma((double)(w3 ? s_cdz[n * n3 + k3] : s_cn[n]), (double)x[u], gs);
       }
     }
   }
   s_part[wv][lane] = gs;
   __syncthreads();
-  if (wv == 0 && p < L.np) {
+  if (wv == 0 && live) {
     gs = ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane];
-    const float w = a.params[p];
+    const float w = w_old;
     if (a.l1l2 && ((p >= L.o_w3 && p < L.o_b3) || (p >= L.o_w4 && p < L.o_b4)))
       gs += (double)((w > 0.0f ? 1.0f : (w < 0.0f ? -1.0f : 0.0f)) + w);  // d/dw (|w| + w^2 / 2)
     const float g = (float)gs;
     if (a.grad) a.grad[p] = g;
     if (a.apply) {
-      float m = a.m[p], v = a.v[p];
+      float m = m_old, v = v_old;
       a.params[p] = adam_param(w, g, m, v, a.lr_t, a.beta1, a.beta2, a.eps);
       a.m[p] = m;
       a.v[p] = v;
@@ -662,9 +705,12 @@ int mfg_reward_net_train_step(float* params, float* adam_m, float* adam_v, int d
   const int h1 = k1 / 2, h2 = k2 / 2, W1 = d + 2 * h1, W2 = d + 2 * h2;
   const size_t lds = (size_t)(W1 * W1 + W2 * W2 + L.a2 + f2 * W2 * W2 + L.ns) * sizeof(float);
   if (k1 == 5 && k2 == 3 && f2 == 2)
-    hipLaunchKernelGGL((k_rn_train_sample<5, 3, 2>), dim3((unsigned)N + 1), dim3(RT_BLOCK), lds, st, a);
+    {
+    if (L.a2 <= 4 * RT_BLOCK) hipLaunchKernelGGL((k_rn_train_sample<5, 3, 2, 4>), dim3((unsigned)N + 1), dim3(RT_BLOCK), lds, st, a);
+    else hipLaunchKernelGGL((k_rn_train_sample<5, 3, 2, 8>), dim3((unsigned)N + 1), dim3(RT_BLOCK), lds, st, a);
+  }
   else
-    hipLaunchKernelGGL((k_rn_train_sample<0, 0, 0>), dim3((unsigned)N + 1), dim3(RT_BLOCK), lds, st, a);
+    hipLaunchKernelGGL((k_rn_train_sample<0, 0, 0, 8>), dim3((unsigned)N + 1), dim3(RT_BLOCK), lds, st, a);
   RtCombineArgs c{};
   c.params = params; c.m = adam_m; c.v = adam_v; c.grad = grad; c.stats = stats;
   c.r = a.r; c.a2 = a.a2; c.dz3 = a.dz3; c.js = a.js; c.reg = a.reg;

@@ -104,6 +104,16 @@ class TrajectoryStore:
         idx = torch.as_tensor(rows, dtype=torch.int64, device=self.device)
         return self.state.index_select(0, idx), self.action.index_select(0, idx)
 
+    def gather_flat(self):
+        """(states [n*steps, d], actions [n*steps, d, d]) of ALL trajectories in logical order, cached until the store changes
+        (reward_iteration evaluates the whole store every `iter_check` updates: D_samp changes once per outer iteration, the
+        demonstrations never)."""
+        if getattr(self, '_flat_version', None) != self.version:
+            st, ac = self.gather()
+            self._flat = (st.reshape(-1, self.d), ac.reshape(-1, self.d, self.d))
+            self._flat_version = self.version
+        return self._flat
+
     def to_list(self):
         if self._list is None:
             if not self.rows:
