@@ -147,6 +147,16 @@ class AC_IRL(actor_critic):
             self._gen_store._list = trajs if trajs else None       # keep the caller's objects as the list view
         self._eval_gen_override = None
 
+    def _resync_stores(self):
+        """In-place edits of a list view (`ac.list_generated += more`, `.append`) change its LENGTH without passing the setter:
+        re-upload a view whose length no longer matches its store (edits that keep the length are not seen -- assign a list)."""
+        if len(self._demo_list) != len(self._demo_store):
+            self._demo_store.assign_list(self._demo_list)
+        view = self._gen_store._list
+        if view is not None and len(view) != len(self._gen_store):
+            self._gen_store.assign_list(view)
+            self._gen_store._list = view
+
     def _is_all_pairs(self, pairs, store, trajs):
         """True if `pairs` is the flattened view [pair for traj in trajs for pair in traj] of the store's current list."""
         n = len(store) * store.steps
@@ -565,6 +575,7 @@ class AC_IRL(actor_critic):
         `random.sample` calls -- on INDEX ranges: random.sample(population, k) picks positions from len(population) alone, so
         the same trajectories are chosen and the host stream advances identically -- and the update itself is
         mfg_reward_net_train_step on the device stores: two launches, nothing copied, no synchronisation."""
+        self._resync_stores()
         nd_all, ng_all = len(self._demo_store), len(self._gen_store)
         if nd_all >= self.num_demo_samples:
             demo_idx = random.sample(range(nd_all), self.num_demo_samples)
@@ -636,6 +647,7 @@ class AC_IRL(actor_critic):
     def _eval_reward_averages(self):
         """Mean reward over the demonstration / generated evaluation transitions (ac_irl.py:868-883): two forward launches
         and ONE host read for both numbers."""
+        self._resync_stores()
         ds, da = self._eval_transitions(self._eval_demo_override, self._demo_store)
         gs, ga = self._eval_transitions(self._eval_gen_override, self._gen_store)
         self._reward_sample_offset = 0

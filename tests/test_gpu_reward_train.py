@@ -297,3 +297,20 @@ def test_eval_override_is_honoured(dev):
     assert abs(g_avg - ref) <= 1e-5
     ac.list_eval_gen_transitions = [p for t in ac.list_generated for p in t]
     assert ac._eval_gen_override is None
+
+
+def test_in_place_growth_of_a_list_view_reaches_the_store(dev):
+    """`ac.list_generated += more` / `.append(...)` bypass the property setter: the next update re-uploads a view whose length
+    no longer matches its store (same for the demonstrations)."""
+    ac, demos = _irl(dev, reg='none')
+    ac.list_generated = ac.generate_trajectories(5)
+    more = ac.generate_trajectories(2)
+    ac.list_generated += more                              # getter + in-place extend + setter with the SAME object
+    assert len(ac.list_generated) == 7
+    ac.update_reward()
+    assert len(ac._gen_store) == 7
+    s, a = ac._gen_store.gather([6])
+    assert np.array_equal(a[0, 3].cpu().numpy(), np.asarray(more[1][3][1], dtype=np.float32))
+    ac.list_demonstrations.append(demos[0])
+    ac.update_reward()
+    assert len(ac._demo_store) == len(demos) == 8
