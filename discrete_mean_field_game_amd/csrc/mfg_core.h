@@ -640,7 +640,10 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
               wp += 4;
               asm volatile("" : "+v"(rp), "+v"(wp));
             };
-#pragma unroll 1
+#ifndef MFG_QUAD_UNROLL
+#define MFG_QUAD_UNROLL 1  // quads of a row whose chains the scheduler may interleave (developer switch; 2 measured below)
+#endif
+#pragma unroll MFG_QUAD_UNROLL
             for (int j = 0; j < dq; j += 4) {
               float ys;
               TT as, ds, gs;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B timing of variant libraries (tools/variant.sh) against the shipped one: alternates them, two rounds.
 #   bash tools/ab_variants.sh "<variant names, '-' = shipped>" <probe.py> [probe args]
-R=$(cd "$(dirname "$0")/.." && pwd); V=$R/discrete_mean_field_game_amd/csrc/variants
+R=$(cd "$(dirname "$0")/.." && pwd); V=${MFG_VARIANT_DIR:-$R/discrete_mean_field_game_amd/csrc/variants}
 names=$1; shift
 for round in 1 2; do
   for n in $names; do
