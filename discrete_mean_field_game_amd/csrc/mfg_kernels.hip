@@ -2121,6 +2121,18 @@ __global__ __launch_bounds__(RP_SLICES* RP_OUT) void k_reduce_partials(const dou
   __shared__ double red[RP_SLICES][RP_OUT + 1];
   const int lo = threadIdx.x & (RP_OUT - 1), sl = threadIdx.x / RP_OUT;
   const int64_t k = (int64_t)blockIdx.x * RP_OUT + lo;
+  // the value this output updates (parameter / accumulator / running G): read FIRST, under the row reads -- read where it is
+  // used it was one more dependent L2 round trip at the end of a kernel that is nothing but such round trips
+  double old_val = 0.0, old_G = 0.0;
+  if (sl == 0 && k < FO) {
+    const int64_t F = FO - 3;
+    if (accumulate) old_G = G[k];
+    if (ap.on) {
+      if (k < F) old_val = ap.w[k];
+      else if (k == F) old_val = *ap.theta;
+      else if (k == F + 1 && ap.reward_acc) old_val = *ap.reward_acc;
+    }
+  }
   double s = 0.0;
   if (k < FO) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -2164,14 +2176,14 @@ __global__ __launch_bounds__(RP_SLICES* RP_OUT) void k_reduce_partials(const dou
       t3 += red[q + 3][lo];
     }
     const double tot = (t0 + t1) + (t2 + t3);
-    const double gk = accumulate ? G[k] + tot : tot;
+    const double gk = accumulate ? old_G + tot : tot;
     G[k] = gk;
     if (ap.on) {
       const int64_t F = FO - 3;
       const double inv = 1.0 / ap.count;
-      if (k < F) ap.w[k] = updated_param(ap.w[k], ap.lr_c, gk, inv);
-      else if (k == F) *ap.theta = updated_param(*ap.theta, ap.lr_a, gk, inv);
-      else if (k == F + 1 && ap.reward_acc) *ap.reward_acc += gk * inv;
+      if (k < F) ap.w[k] = updated_param(old_val, ap.lr_c, gk, inv);
+      else if (k == F) *ap.theta = updated_param(old_val, ap.lr_a, gk, inv);
+      else if (k == F + 1 && ap.reward_acc) *ap.reward_acc = old_val + gk * inv;
     }
   }
 }

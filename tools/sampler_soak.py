@@ -17,7 +17,7 @@ LOG2 = int(sys.argv[1]) if len(sys.argv) > 1 else 22
 REGIMES = {'policy': (8.86349, 0.16, 12000.0), 'mid': (5.0, 0.1, 40.0), 'small': (6.0, 0.3, 2.5)}
 
 
-def run(d, regime, precision, n_total):
+def run(d, regime, precision, n_total, seed_offset=0):
     theta, shift, scale = REGIMES[regime]
     rs = np.random.RandomState(100 + d)
     pi1 = rs.dirichlet(np.ones(d) * 0.8).astype(np.float32)
@@ -37,7 +37,7 @@ def run(d, regime, precision, n_total):
     pi = torch.as_tensor(np.repeat(pi1[None], chunk, 0), device=dev)
     done = 0
     while done < n_total:
-        P = ops.sample_dirichlet(pi, th, shift, scale, seed=12345 + d, step=7, traj_offset=done, precision=precision).double()
+        P = ops.sample_dirichlet(pi, th, shift, scale, seed=12345 + d + seed_offset, step=7, traj_offset=done, precision=precision).double()
         s1 += P.sum(0)
         s2 += (P * P).sum(0)
         if len(keep) < 8:
@@ -62,11 +62,19 @@ def run(d, regime, precision, n_total):
 
 
 if __name__ == '__main__':
-    worst_z, worst_p, nks = 0.0, 1.0, 0
+    worst_z, worst_p, nks, worst_case = 0.0, 1.0, 0, None
     for d in (2, 5, 21):
         for regime in ('policy', 'mid', 'small'):
             for precision in ('mixed', 'f64'):
                 zz, pp, k = run(d, regime, precision, 1 << (LOG2 if d < 21 else LOG2 - 2))
+                if pp < worst_p:
+                    worst_case = (d, regime, precision, 1 << (LOG2 if d < 21 else LOG2 - 2))
                 worst_z, worst_p, nks = max(worst_z, zz), min(worst_p, pp), nks + k
     print('worst |z| of a mean %.2f (%.0f entries in total: 5 sigma would be suspicious), smallest KS p-value %.4f (%d tests)'
           % (worst_z, 2 * 3 * (4 + 25 + 441), worst_p, nks))
+    if worst_case is not None and worst_p < 0.02:
+        # the smallest of 32 p-values is expected around 0.03; one well below that is re-drawn with three other Philox keys: a
+        # distortion of the marginal reproduces (p collapses in every re-draw), a fluctuation does not
+        print('re-draw of the case with the smallest p-value %s under three other seeds:' % (worst_case[:3],))
+        for off in (1000, 2000, 3000):
+            run(*worst_case, seed_offset=off)
