@@ -586,7 +586,9 @@ class AC_IRL(actor_critic):
         else:
             gen_idx = list(range(ng_all))
         self._reward_train_calls += 1
-        if self._trainer is not None and len(demo_idx) <= L.RN_TRAIN_MAX_TRAJ and len(gen_idx) <= L.RN_TRAIN_MAX_TRAJ:
+        n_tr = (len(demo_idx) + len(gen_idx)) * EPISODE_STEPS
+        fits = n_tr <= 2048 and n_tr * (1 + self.n_fc3) * 4 <= 60 * 1024            # limits of mfg_reward_net_train_step's combine kernel
+        if self._trainer is not None and fits and len(demo_idx) <= L.RN_TRAIN_MAX_TRAJ and len(gen_idx) <= L.RN_TRAIN_MAX_TRAJ:
             key = ((self.seed + 0x7EA1) ^ (self._reward_train_calls * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
             dist = torch.distributed
             multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1

@@ -676,6 +676,9 @@ int mfg_reward_net_train_step(float* params, float* adam_m, float* adam_v, int d
     return set_error(MFG_EUNSUPPORTED, "reward_net_train_step: at most MFG_RN_TRAIN_MAX_TRAJ trajectories per batch half");
   const int64_t N = (int64_t)(n_demo + n_gen) * steps;
   if (N == 0) return set_error(MFG_EINVAL, "reward_net_train_step: empty batch");
+  // the combine kernel keeps one coefficient per transition and c_n dz3_n [N][n3] in LDS and eight rewards per thread in registers
+  if (N > 8 * RT_BLOCK || (size_t)N * (size_t)(1 + n3) * sizeof(float) > 60 * 1024)
+    return set_error(MFG_EUNSUPPORTED, "reward_net_train_step: batch too large ((n_demo + n_gen) * steps <= 2048 and * (1 + n_fc3) * 4 B <= 60 KB)");
   if (workspace_bytes < mfg_reward_net_train_workspace_bytes(d, k1, f2, k2, n3, n4, N))
     return set_error(MFG_EWORKSPACE, "reward_net_train_step: workspace too small (mfg_reward_net_train_workspace_bytes)");
   const RtLayout L = rt_layout(d, k1, f2, k2, n3, n4);

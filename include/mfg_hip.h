@@ -321,7 +321,8 @@ int mfg_reward_net_forward(const float* state, const float* action, int64_t B, i
  *   stats (may be NULL) [4] <- loss, first term, second term, regulariser, evaluated at the weights BEFORE the update
  *   (what sess.run([r_train_op, loss, ...]) returns, ac_irl.py:846).
  *   workspace: mfg_reward_net_train_workspace_bytes(..., (n_demo + n_gen) * steps); contents are scratch.
- * Supported shapes as mfg_reward_net_forward. */
+ * Supported shapes as mfg_reward_net_forward; batch: (n_demo + n_gen) * steps <= 2048 transitions and
+ * (n_demo + n_gen) * steps * (1 + n3) * 4 B <= 60 KB (MFG_EUNSUPPORTED beyond; the reference's batch is 150 transitions). */
 #define MFG_RN_TRAIN_MAX_TRAJ 64
 enum { MFG_RN_TRAIN_GRAD_ONLY = 1 };
 int64_t mfg_reward_net_num_params(int d, int k1, int f2, int k2, int n3, int n4);

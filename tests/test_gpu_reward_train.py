@@ -205,6 +205,8 @@ def test_error_paths(dev):
         tr.step(demo, [0] * 65, gen, [0], 5, 1)
     with pytest.raises(L.MfgError):                       # empty batch
         tr.step(demo, [], gen, [], 5, 1)
+    with pytest.raises(L.MfgError, match='batch too large'):   # 64 + 64 trajectories x 15 with n_fc3 = 8: 69 KB of coefficients
+        tr.step(demo, [0] * 64, gen, [0] * 64, 5, 1)
     tr._ws = torch.empty(8, dtype=torch.float32, device=dev)
     tr._workspace = lambda n: tr._ws
     with pytest.raises(L.MfgError):                       # workspace too small
