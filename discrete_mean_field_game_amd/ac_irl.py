@@ -689,6 +689,77 @@ class AC_IRL(actor_critic):
         if self.verbose:
             print('----- Exiting reward_iteration at iter %d -----' % it)
 
+    # ------------------------------------------------------------------ experiment harnesses of the reference (ac_irl.py:961-1050)
+    @_with_ctx
+    def test_convergence(self, num_iterations=500, num_gen_from_policy=5, iter_check=10, filename='reward_convergence.csv'):
+        """Train the reward network on demonstrations and a FIXED generated set from the current (fixed) policy and log the average
+        rewards every `iter_check` updates (ac_irl.py:961-1005): D_samp is generated once on the device, the updates are
+        mfg_reward_net_train_step, the averages two forward launches.  Writes results/<filename> when `results/` exists;
+        returns the logged rows [(iteration, reward_demo_avg, reward_gen_avg), ...]."""
+        if self.rng == 'philox':
+            self._gen_store.clear()
+            self._gen_store.push(*self._generate_device(num_gen_from_policy * self.num_policies))
+        else:
+            self.list_generated = self.generate_trajectories(num_gen_from_policy * self.num_policies)
+        self._eval_gen_override = None
+        write = os.path.isdir('results')
+        if write:
+            with open('results/' + filename, 'w') as f:
+                f.write('iteration,reward_demo_avg,reward_gen_avg\n')
+        self._sync_host_sampler()
+        rows = []
+        for it in range(1, num_iterations + 1):
+            if it % iter_check != 0:
+                self.update_reward(summary=False)
+                continue
+            self.update_reward(summary=False, iteration=it)
+            reward_demo_avg, reward_gen_avg = self._eval_reward_averages()
+            if self.verbose:
+                print('Iteration %d' % it)
+                print('Reward demo avg %f | Reward gen avg %f' % (reward_demo_avg, reward_gen_avg))
+                print('First %f | Second %f | Loss %f' % (self.first_term_val, self.second_term_val, self.loss_val))
+            rows.append((it, reward_demo_avg, reward_gen_avg))
+            if write:
+                with open('results/' + filename, 'a') as f:
+                    f.write('%d,%f,%f\n' % (it, reward_demo_avg, reward_gen_avg))
+            if np.isnan(reward_demo_avg) or np.isnan(reward_gen_avg):
+                break
+        return rows
+
+    @_with_ctx
+    def test_reward_network(self):
+        """Average reward of the fixed network over the training demonstrations, the test demonstrations and as many freshly
+        generated trajectories as there are training demonstrations (ac_irl.py:1008-1046).  Returns the reference's tuple
+        (reward_demo_avg_train, reward_demo_avg_test, reward_gen_avg); a missing test set gives nan."""
+        num_demos = len(self._demo_store)
+        if self.rng == 'philox':
+            self._gen_store.clear()
+            if num_demos:
+                self._gen_store.push(*self._generate_device(num_demos))
+        else:
+            self.list_generated = self.generate_trajectories(num_demos)
+        self._eval_gen_override = None
+        self._eval_demo_override = None
+        train_avg, gen_avg = self._eval_reward_averages()
+        test = [pair for traj in self.list_demonstrations_test for pair in traj]
+        if test:
+            ts, ta = self._pairs_to_tensors(test)
+            self._reward_sample_offset = 0
+            with torch.no_grad():
+                test_avg = float(self.reward(ts, ta).double().sum().cpu()) / len(test)
+        else:
+            test_avg = float('nan')
+        if self.verbose:
+            print('Avg reward demo train %f | Avg reward demo test %f | Avg reward gen %f' % (train_avg, test_avg, gen_avg))
+        return train_avg, test_avg, gen_avg
+
+    @_with_ctx
+    def evaluate(self, theta=8.86349, shift=0.5, alpha_scale=1e4, d=15, episode_length=16, indir='test_normalized_round2',
+                 outfile='eval_mfg_round2/validation.csv', write_header=0):
+        """actor_critic.evaluate with the defaults of the reference's AC_IRL.evaluate (ac_irl.py:1495: d = 15, validation.csv)."""
+        return super().evaluate(theta=theta, shift=shift, alpha_scale=alpha_scale, d=d, episode_length=episode_length, indir=indir,
+                                outfile=outfile, write_header=write_header)
+
     @_with_ctx
     def outerloop(self, num_iterations=20, num_gen_from_policy=5, max_reward_iterations=100,
                   max_forward_episodes=200, gamma=1, constant=False, lr_critic=0.1, lr_actor=0.001, *, first_iteration=0,

@@ -2,6 +2,7 @@
 mfg_reward_net_train_step against the fp64 analytic gradient of oracle/reward_net_oracle.py (which tests/test_reward_learning.py
 checks against PyTorch autograd and central differences on the CPU) and against networks.RewardNet autograd.
 PARITY UNPINNED vs TensorFlow (TF 1.x cannot run here): what these tests pin is the restated graph."""
+import os
 import random
 
 import numpy as np
@@ -335,3 +336,29 @@ def test_outerloop_with_the_reference_rng_goes_through_the_list_setters(dev):
     s, a = ac._gen_store.gather()
     assert np.array_equal(a[3, 14].cpu().numpy(), np.asarray(lg[3][14][1], dtype=np.float32))
     assert np.isfinite(ac.loss_val) and np.isfinite(float(np.ravel(ac.theta)[0]))
+
+
+def test_reference_harnesses_test_convergence_and_test_reward_network(dev, tmp_path, monkeypatch):
+    """ac_irl.py:961-1046: `test_convergence` (reward training against a fixed generated set, averages logged every iter_check
+    updates, CSV in results/) and `test_reward_network` (average reward on train / test demonstrations and fresh trajectories)
+    run on the device path; the logged averages equal an fp64 evaluation of the network at that point (no dropout here)."""
+    monkeypatch.chdir(tmp_path)
+    os.makedirs('results')
+    ac, demos = _irl(dev, reg='l1l2')
+    rows = ac.test_convergence(num_iterations=6, num_gen_from_policy=3, iter_check=3, filename='conv.csv')
+    assert [r[0] for r in rows] == [3, 6] and ac._trainer.step_count == 6 and len(ac._gen_store) == 6
+    text = open('results/conv.csv').read().splitlines()
+    assert text[0] == 'iteration,reward_demo_avg,reward_gen_avg' and len(text) == 3 and text[2].startswith('6,')
+    prm = RO.params_from_torch(ac.reward_net)
+    f = lambda trajs, k: np.array([np.asarray(p[k], dtype=np.float32) for t in trajs for p in t], dtype=np.float64)
+    ref_demo = RO.forward(prm, f(demos, 0), f(demos, 1)).mean()
+    ref_gen = RO.forward(prm, f(ac.list_generated, 0), f(ac.list_generated, 1)).mean()
+    assert abs(rows[-1][1] - ref_demo) <= 1e-5 and abs(rows[-1][2] - ref_gen) <= 1e-5
+    ac.list_demonstrations_test = demos[:2]
+    tr_avg, te_avg, ge_avg = ac.test_reward_network()
+    assert abs(tr_avg - ref_demo) <= 1e-5 and len(ac._gen_store) == len(demos)
+    assert abs(te_avg - RO.forward(prm, f(demos[:2], 0), f(demos[:2], 1)).mean()) <= 1e-5
+    assert abs(ge_avg - RO.forward(prm, f(ac.list_generated, 0), f(ac.list_generated, 1)).mean()) <= 1e-5
+    import inspect
+    sig = inspect.signature(ac.evaluate)
+    assert sig.parameters['d'].default == 15 and sig.parameters['outfile'].default == 'eval_mfg_round2/validation.csv'
