@@ -119,6 +119,8 @@ SIGNATURES['mfg_train_episode_irl'] = (_i32, [_p, _p, _i64, _i32, _i32, _p, _f64
                                               _f64, C.POINTER(RewardNetStruct), _u64, _u64, _u64, _p, _p, _p, _p, _p, _p, _p,
                                               _sz, _p])
 
+SIGNATURES['mfg_train_episode_irl_draw'] = (_i32, [_p, _i64] + SIGNATURES['mfg_train_episode_irl'][1])
+
 SIGNATURES['mfg_train_rollout_irl'] = (_i32, [_p, _i64, _p, _i64, _i32, _i32, _p, _f64, _f64, _p, _f64, _u64, _u32, _u64, _i32, _f64,
                                               _f64, C.POINTER(RewardNetStruct), _u64, _u64, _p, _p, _p, _p, _p, _p, _p, _p, _p, _sz,
                                               _p])

@@ -291,7 +291,7 @@ class AC_IRL(actor_critic):
                           and self.trace is None and not write_all and self.reward_net is not None
                           and ops.reward_net_supported(self.reward_net))
         if native_episode:
-            nbufs = dict(ops.episode_buffers(Bl, d, self.device), P=rbufs['P'])
+            nbufs = dict(ops.episode_buffers(Bl, d, self.device), P=rbufs['P'], pi=torch.empty(Bl, d, dtype=torch.float32, device=self.device))
         # per-episode return accumulators of the native paths: ONE zeroed buffer per train() call instead of a fill kernel per episode
         ep_acc = torch.zeros(max_episodes + 1, dtype=torch.float64, device=self.device) if (native_rollout or native_episode) else None
         prev_theta = float(self._theta.cpu()[0])
@@ -325,7 +325,9 @@ class AC_IRL(actor_critic):
                         break
                     prev_theta = cur
                 continue
-            if device_draw:
+            if native_episode and device_draw:
+                pi = nbufs['pi']                           # (output only: the start states are drawn inside the native call)
+            elif device_draw:
                 _, pi = ops.draw_start(self._mat_pi0_dev, Bl, self.seed, self._rng_step, shard.traj_offset)
             else:
                 pi = ops.gather_start(self._mat_pi0_dev, self._draw_start(shard))       # ac_irl.py:655
@@ -358,7 +360,8 @@ class AC_IRL(actor_critic):
                 ops.train_episode_irl(pi, T, self._theta, self.shift, self.alpha_scale, self._w, gamma, lr_critic * sc,
                                       lr_actor * sa, self.reward_net, G, ws, nbufs, seed=self.seed, first_step=self._rng_step,
                                       traj_offset=shard.traj_offset, rn_seed=self.seed + 0x5EED, rn_call0=self._reward_calls,
-                                      rn_sample_offset=shard.traj_offset, reward_acc=total_reward, precision=self.precision)
+                                      rn_sample_offset=shard.traj_offset, reward_acc=total_reward, precision=self.precision,
+                                      mat_pi0=self._mat_pi0_dev if device_draw else None)
                 self._rng_step += T
                 self._reward_calls += T                    # the dropout-mask keys of T reward() calls were consumed
                 self._reward_sample_offset = shard.traj_offset

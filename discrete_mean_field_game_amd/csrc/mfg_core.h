@@ -22,7 +22,10 @@ struct CoreArgs {
   int start_draw;           // != 0: pi0 is the table and the row of trajectory b is DRAWN in the kernel (start_draw_row,
                             // mfg_device.h: Philox keyed by seed, first_step, global trajectory id); start_idx is ignored
   const float* pi_alpha;    // GIVEN: state the concentrations are computed from (NULL -> pi0)
-  const float* P_in;        // GIVEN: [B,d,d]
+  union {
+    const float* P_in;      // GIVEN: [B,d,d]
+    float* pi_start_out;    // STEP variant (sampling): [B,d] the start states are also written here (drawn in the kernel), or NULL
+  };
   const float* pi_next_in;  // GIVEN: [B,d] (may be NULL when no delta is wanted)
   const float* reward_in;   // external reward [B*T] or NULL
   const double* theta;
@@ -32,6 +35,7 @@ struct CoreArgs {
   int d, T, reward_kind, discount_pow;
   uint64_t seed;
   uint32_t first_step;
+  int step_nrows;      // != 0: STEP variant (see below); < 0: without rows to reduce (an episode's first env step)
   uint64_t traj_offset;
   float* pi_traj;      // [B,T+1,d] or NULL
   float* pi_next_out;  // [B,d] final state or NULL
@@ -41,16 +45,34 @@ struct CoreArgs {
   float* P_out;        // [B,T,d,d] or NULL
   const float4* htab;  // h(z) cubic table (mixed precision TD), see mfg_device.h
   unsigned* status;    // device address of the host-visible status word (mfg_status), or NULL
-  double* part_rows;   // SUMS variant (T == 1, one tile per block): partial rows [ntiles][F+3] of the batch sums, or NULL
+  union {
+    double* part_rows;   // SUMS variant (T == 1, one tile per block): partial rows [ntiles][F+3] of the batch sums, or NULL
+    double* step_G;      // STEP variant: [F+3] batch sums of the previous env step (output)
+  };
   // Deferred update (packed kernel, mfg_train_rollout_deferred): pend_G != NULL = the all-reduced batch sums [F+3] of the
   // PREVIOUS update, not applied yet.  Every block forms the updated parameters while it stages them (theta, w above are
   // the parameters BEFORE that update); block 0 also writes them to theta_out / w_out (other buffers than theta / w: blocks
   // that start later still read the old values) and adds the update's mean reward to *pend_reward_acc.
-  const double* pend_G;
+  union {
+    const double* pend_G;
+    const double* step_rows;  // STEP variant: [step_nrows][F+3] partial rows of the previous env step; column F once more,
+                              // contiguous, in the step_nrows doubles in FRONT of them (step_rows[-step_nrows .. -1])
+  };
   double pend_lr_c, pend_lr_a;
   double* w_out;
   double* theta_out;
   double* pend_reward_acc;
+  // IRL env step (STEP variant of the packed kernel, mfg_train_episode_irl): the batch sums of the PREVIOUS env step are still
+  // `step_nrows` partial rows [F+3] (left by the reward-network launch).  Every sampling wave adds up column F itself
+  // (rows_column_sum) and forms theta = updated_param(*theta, pend_lr_a, sum, 1 / step_count) -- the one parameter sampling
+  // needs; the last `red_blocks` blocks of the grid add up ALL columns (a wave per column) and publish the update:
+  // step_G[k], w_out[k] (in place: nobody reads the critic weights in this launch -- the TD error is formed in the
+  // reward-network launch that follows), *theta_out (another slot than *theta), *pend_reward_acc.  The row reduction is off
+  // the critical path: it runs under the sampling blocks instead of between two launches.
+  // These arguments SHARE storage with arguments the variant never reads (step_nrows sits in the padding behind first_step,
+  // step_rows = pend_G, step_G = part_rows, the sample count is B, red_blocks follows from d): a longer argument block moves the
+  // hidden launch arguments and, with them, the register allocation of every other instantiation of the kernel (measured on the
+  // headline kernel: two more spilled registers).
 #ifdef MFG_TIMING
   unsigned long long* dbg;  // timing variant only (tools/phase_timing.py): s_memtime stamps of block 0, wave 0
 #endif
@@ -66,6 +88,9 @@ struct CoreArgs {
 #define MFG_STAMPB(k)
 #endif
 
+// blocks behind the sampling blocks of a STEP launch: a wave per column of the FO-entry rows
+__host__ __device__ constexpr int core_step_red_blocks(int FO) { return (FO + WAVES - 1) / WAVES; }
+
 int set_error(int code, const char* msg);  // records mfg_last_error() (defined in mfg_kernels.hip)
 
 // IRL env step: reward network + the batch sums of the TD update over the same samples in one launch
@@ -76,7 +101,16 @@ struct RnSums {
   double* delta_out;     // [B] delta = delta0 + r (may alias delta0)
   double* part_rows;     // [max_rows][F+3]
   int64_t max_rows;
+  // td_w != NULL (after reward_net_sums_td_ready() said yes): delta0 is NOT read -- the matrix-core kernel forms
+  // td_gamma V(state_next) - V(state) itself from the critic weights td_w [F]
+  const double* td_w;
+  const float* state_next;  // [B,d]
+  double td_gamma;
+  double* col_f;            // [max_rows] column F of the rows, contiguous (see RewardNetArgs)
 };
+// true: a reward_net_forward_sums call of this shape runs the matrix-core SUMS kernel with the TD error formed in the kernel
+// (d = 21 / 15 at the reference's layer geometry, n_fc3 <= 16, aligned FC3 weights, one row per block fits max_rows)
+bool reward_net_sums_td_ready(int64_t B, int d, int k1, int f2, int k2, int n3, int n4, const float* fc3_w, int64_t max_rows);
 int reward_net_forward_sums(const float* state, const float* action, int64_t B, int d, int k1, int f2, int k2, int n3, int n4,
                             const float* conv1_w, const float* conv1_b, const float* conv2_w, const float* conv2_b,
                             const float* fc3_w, const float* fc3_b, const float* fc4_w, const float* fc4_b,
@@ -412,7 +446,9 @@ __device__ __forceinline__ double value_wave(const float* pis, const double* __r
 // partial row in a.part_rows: the separate gradient kernel (a launch, a re-read of pi / delta / g / reward, a
 // fence-and-last-block finish: 10.6 us per env step at B = 4 096) shrinks to the row reduction.  Register budget of two
 // waves per SIMD (the three-wave cap spills 31 registers here); used while all tiles are resident at that occupancy.
-template <bool SAMPLE, bool TD, bool FAST, int D, bool SUMS = false>
+// STEP: 0 plain; 1 IRL env step with the previous step's partial rows (CoreArgs::step_rows); 2 an IRL episode's FIRST env step
+// (nothing to reduce; the start states are also written to pi_start_out)
+template <bool SAMPLE, bool TD, bool FAST, int D, bool SUMS = false, int STEP = 0>
 #ifndef MFG_CORE_SMALL_WAVES_F64
 #define MFG_CORE_SMALL_WAVES_F64 3  // strict precision: 227 registers wanted; at 168 the third wave still pays (5.95 -> 5.80 ms at the bench shape)
 #endif
@@ -452,11 +488,47 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
                                                          // evaluated inside step 0, next to V of the next state
   const int tid = threadIdx.x, lane = tid & (WAVE - 1), wv = tid / WAVE;
   const int t = lane / d, i = lane - t * d;
+  // blocks that walk the tiles (STEP: the grid's last red_blocks blocks reduce the previous env step's partial rows instead)
+  auto nblk_f = [&]() -> unsigned { return STEP == 1 ? gridDim.x - (unsigned)core_step_red_blocks(F + 3) : gridDim.x; };  // (read where it is used)
+  if constexpr (STEP == 1) {
+    if (blockIdx.x >= nblk_f()) {
+      const int64_t k = (int64_t)(blockIdx.x - nblk_f()) * WAVES + wv;
+      const int64_t FO = F + 3;
+      if (k >= FO) return;
+      double old_val = 0.0;  // read first, under the row reads
+      if (lane == 0) {
+        if (k < F) old_val = a.w_out[k];
+        else if (k == F) old_val = *a.theta;
+        else if (k == F + 1 && a.pend_reward_acc) old_val = *a.pend_reward_acc;
+      }
+      const double gk = rows_column_sum(a.step_rows, a.step_nrows, FO, k, lane);
+      if (lane == 0) {
+        const double inv = 1.0 / (double)a.B;
+        a.step_G[k] = gk;
+        if (k < F) a.w_out[k] = updated_param(old_val, a.pend_lr_c, gk, inv);
+        else if (k == F) *a.theta_out = updated_param(old_val, a.pend_lr_a, gk, inv);
+        else if (k == F + 1 && a.pend_reward_acc) *a.pend_reward_acc = old_val + gk * inv;
+      }
+      return;
+    }
+  }
+  float pi_first = 0.0f;
+  if constexpr (STEP == 1) {  // (the first tile's start state, see below: here in flight under the row reads of theta's update)
+    const int64_t b0f = (int64_t)blockIdx.x * TB;
+    const int tlf = wv * G + t;
+    if (b0f < a.B) {
+      const int64_t bf = b0f + ((t < G && b0f + tlf < a.B) ? tlf : 0);
+      pi_first = a.pi0[core_src_row(a, bf) * d + i];
+    }
+  }
   // deferred update of the previous episode (CoreArgs::pend_G): applied here, on the fly, with the arithmetic of
   // k_apply_update (updated_param); a sum over no samples (count 0) leaves the parameters alone
-  const bool pend = a.pend_G != nullptr && a.pend_G[F + 2] > 0.0;
+  const bool pend = STEP != 1 && a.pend_G != nullptr && a.pend_G[F + 2] > 0.0;
   const double pinv = pend ? 1.0 / a.pend_G[F + 2] : 0.0;
-  const double theta = pend ? updated_param(*a.theta, a.pend_lr_a, a.pend_G[F], pinv) : *a.theta;
+  double theta = pend ? updated_param(*a.theta, a.pend_lr_a, a.pend_G[F], pinv) : *a.theta;
+  if constexpr (STEP == 1) {
+    theta = updated_param(theta, a.pend_lr_a, rows_column_sum(a.step_rows - a.step_nrows, a.step_nrows, 1, 0, lane), 1.0 / (double)a.B);
+  }
   const ThetaSplit ts = theta_split(theta, a.shift);
   const float inv_d = 1.0f / (float)d;
   // mixed sampling kernels: separable e^z = E_j F_i (mfg_device.h), in range while |theta| (1/2 + |shift|) <= 86; beyond
@@ -465,8 +537,7 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
   if (sep) report_sep_range(a.status, theta, a.shift);
   // first tile's start state: the load is issued BEFORE the weight staging so that its latency (L2 / HBM, ~1 us) overlaps
   // the staging instead of stalling the first use (a T = 1 launch spent 4 300 of its 20 900 cycles waiting for it)
-  float pi_first = 0.0f;
-  {
+  if constexpr (STEP != 1) {
     const int64_t b0f = (int64_t)blockIdx.x * TB;
     const int tlf = wv * G + t;
     if (b0f < a.B) {
@@ -488,7 +559,7 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
       for (int k = tid; k < F; k += BLOCK) wl[k] = w_now(k);
     }
   }
-  if (a.pend_G != nullptr && blockIdx.x == 0) {
+  if (STEP != 1 && a.pend_G != nullptr && blockIdx.x == 0) {
     // block 0 publishes the updated parameters (out of place) and books the update's mean reward
     if (a.w_out && a.w)
       for (int k = tid; k < F; k += BLOCK) a.w_out[k] = w_now(k);
@@ -535,7 +606,7 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
     return (double)pi_e * (col + wl[Q + i]);
   };
   const int64_t ntiles = (a.B + TB - 1) / TB;
-  for (int64_t tileid = blockIdx.x; tileid < ntiles; tileid += gridDim.x) {
+  for (int64_t tileid = blockIdx.x; tileid < ntiles; tileid += nblk_f()) {
     const int64_t b0 = tileid * TB;
     const int nb = (int)((a.B - b0) < TB ? (a.B - b0) : TB);
     const int tl = wv * G + t;
@@ -549,7 +620,7 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
     //  the L2 / HBM latency of this load once per tile)
     float pi_i = pi_first;
     {
-      const int64_t tn = tileid + gridDim.x;
+      const int64_t tn = tileid + nblk_f();
       if (tn < ntiles) {
         const int64_t b0n = tn * TB;
         const int64_t bn = b0n + ((t < G && b0n + tl < a.B) ? tl : 0);
@@ -557,6 +628,9 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
       }
     }
     if (valid && a.pi_traj) a.pi_traj[b * (int64_t)(T + 1) * d + i] = pi_i;
+    if constexpr (STEP == 2) {
+      if (valid && a.pi_start_out) a.pi_start_out[b * d + i] = pi_i;
+    }
     double v_cur = 0.0, discount = 1.0;  // meaningful on lane i == 0 only
     // (V of the start state: evaluated inside step 0 next to V of the next state -- as a prologue it cost three barriers,
     //  two LDS round trips and a serial sum BEFORE any sampling could start: 3 500 of the 20 000 cycles of a T = 1 launch.

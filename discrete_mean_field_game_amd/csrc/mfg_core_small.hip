@@ -11,7 +11,7 @@ namespace mfg {
 // resident blocks): exactly-resident persistent grid 2.30 ms, x1.5 2.21, x2 2.14, x4 2.07, one tile per block 2.07 --
 // tiles do not take equal time (rejection retries), so the hardware dispatcher back-filling finished blocks beats
 // a static tile split.
-template <bool SAMPLE, bool TD, bool FAST, int D, bool SUMS = false>
+template <bool SAMPLE, bool TD, bool FAST, int D, bool SUMS = false, int STEP = 0>
 static void go(const CoreArgs& a, int num_cus, size_t lds, hipStream_t st) {
   // occupancy of this instantiation at this LDS size, cached per device
   static std::atomic<size_t> cached_lds[64];
@@ -20,7 +20,7 @@ static void go(const CoreArgs& a, int num_cus, size_t lds, hipStream_t st) {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (cached_lds[dev].load() != lds + 1) {  // (+1: zero-initialised slots never match)
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_small<SAMPLE, TD, FAST, D, SUMS>, BLOCK, lds) != hipSuccess || n < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_small<SAMPLE, TD, FAST, D, SUMS, STEP>, BLOCK, lds) != hipSuccess || n < 1)
       n = 1;
     cached_bpc[dev].store(n);
     cached_lds[dev].store(lds + 1);
@@ -29,12 +29,24 @@ static void go(const CoreArgs& a, int num_cus, size_t lds, hipStream_t st) {
   // (single-step launches: x2 -- a block's weight staging and first state load are then shared by ~3-4 tiles; measured
   //  1.64 -> 1.61 ms per 15-step episode of per-step updates at B = 65 536, x1 1.70, x4 1.62)
   const int grid = core_grid(a.B, TB, cached_bpc[dev].load() * (a.T == 1 ? 2 : MFG_CORE_OVERSUBSCRIBE), num_cus);
-  hipLaunchKernelGGL((k_core_small<SAMPLE, TD, FAST, D, SUMS>), dim3(grid), dim3(BLOCK), lds, st, a);
+  // (STEP: the blocks that reduce the previous env step's partial rows ride behind the sampling blocks)
+  hipLaunchKernelGGL((k_core_small<SAMPLE, TD, FAST, D, SUMS, STEP>), dim3(grid + (STEP == 1 ? core_step_red_blocks(a.d * (a.d + 1) / 2 + a.d + 1 + 3) : 0)), dim3(BLOCK), lds, st, a);
 }
 
 template <int D>
 static void dispatch(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, size_t lds, hipStream_t st) {
   if constexpr (D > 0) {
+    // IRL env step (mfg_train_episode_irl): theta from the previous step's partial rows, their reduction in the same launch
+    if (sample && td && a.step_nrows > 0) {
+      if (fast) go<true, true, true, D, false, 1>(a, num_cus, lds, st);
+      else go<true, true, false, D, false, 1>(a, num_cus, lds, st);
+      return;
+    }
+    if (sample && td && a.step_nrows < 0) {
+      if (fast) go<true, true, true, D, false, 2>(a, num_cus, lds, st);
+      else go<true, true, false, D, false, 2>(a, num_cus, lds, st);
+      return;
+    }
     // per-step updates: the variant that also leaves the tile's batch sums (launch_core_sums in mfg_kernels.hip)
     if (sample && td && a.part_rows) {
       if (fast) go<true, true, true, D, true>(a, num_cus, lds, st);

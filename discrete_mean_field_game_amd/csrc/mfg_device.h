@@ -680,6 +680,25 @@ __host__ __device__ __forceinline__ int64_t start_draw_row(uint64_t seed, uint32
 // staging, so that every path produces the same bits.  `inv` = 1 / count.
 __host__ __device__ __forceinline__ double updated_param(double p, double lr, double gk, double inv) { return fma(lr, gk * inv, p); }
 
+// Column k of `nsb` partial rows [nsb][FO] of batch sums, added up by ONE wavefront in a fixed order: lane L adds rows L, L + 64,
+// ... in row order (four loads in flight, unconditional, from clamped addresses), the 64 lane sums go through wave_sum_dpp; every
+// lane returns the total.  ONE definition for the blocks that publish the update and for every sampling wave that forms the
+// updated theta on its own (IRL env step, mfg_train_episode_irl): the same bits everywhere.
+__device__ __forceinline__ double rows_column_sum(const double* __restrict__ rows, int nsb, int64_t FO, int64_t k, int lane) {
+  double s = 0.0;
+  for (int p0 = 0; p0 < nsb; p0 += 4 * WAVE) {
+    double v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * WAVE + lane;
+      v[u] = rows[(int64_t)(p < nsb ? p : 0) * FO + k];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += (p0 + u * WAVE + lane < nsb) ? v[u] : 0.0;
+  }
+  return wave_sum_dpp(s);
+}
+
 // k(i,j) for i <= j: row-major upper triangle (mfg_ac2.py:333).
 __host__ __device__ __forceinline__ int feat_idx(int i, int j, int d) { return i * d - (i * (i - 1)) / 2 + (j - i); }
 

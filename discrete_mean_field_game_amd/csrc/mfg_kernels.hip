@@ -2188,6 +2188,31 @@ __global__ __launch_bounds__(RP_SLICES* RP_OUT) void k_reduce_partials(const dou
   }
 }
 
+// The row reduction + update of the IRL env step as a launch of its own (after an episode's LAST step; the other steps' reductions
+// ride in the next step kernel, k_core_small<.., STEP>): a wave per column, rows_column_sum -- the same order, the same bits.
+__global__ __launch_bounds__(BLOCK) void k_reduce_rows_apply(const double* __restrict__ rows, int nrows, int64_t FO, double* __restrict__ G,
+                                                            double lr_c, double lr_a, double count, double* __restrict__ w,
+                                                            const double* theta_in, double* theta_out,
+                                                            double* __restrict__ reward_acc) {
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const int64_t k = (int64_t)blockIdx.x * WAVES + wv, F = FO - 3;
+  if (k >= FO) return;
+  double old_val = 0.0;
+  if (lane == 0) {
+    if (k < F) old_val = w[k];
+    else if (k == F) old_val = *theta_in;
+    else if (k == F + 1 && reward_acc) old_val = *reward_acc;
+  }
+  const double gk = rows_column_sum(rows, nrows, FO, k, lane);
+  if (lane == 0) {
+    const double inv = 1.0 / count;
+    G[k] = gk;
+    if (k < F) w[k] = updated_param(old_val, lr_c, gk, inv);
+    else if (k == F) *theta_out = updated_param(old_val, lr_a, gk, inv);
+    else if (k == F + 1 && reward_acc) *reward_acc = old_val + gk * inv;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side: launch helpers
 // ---------------------------------------------------------------------------------------------
@@ -2512,7 +2537,7 @@ static int reduce_core_sums(int d, int64_t B, double* G, int accumulate, void* w
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 15; }
+int mfg_abi_version(void) { return 16; }
 
 int mfg_init(void) {
   if (!htab_ptr()) return fail(MFG_ELAUNCH, "%s", "mfg_init: no HIP device / table initialisation failed");
@@ -3571,20 +3596,116 @@ int mfg_train_rollout_irl(const float* mat_pi0, int64_t num_start, const int32_t
   return check_launch("train_rollout_irl");
 }
 
-int mfg_train_episode_irl(float* pi_io, float* pi_scratch, int64_t B, int d, int T, double* theta, double shift,
-                          double alpha_scale, double* w, double gamma, uint64_t seed, uint32_t first_step,
-                          uint64_t traj_offset, int precision, double lr_critic, double lr_actor,
-                          const mfg_reward_net_t* net, uint64_t rn_seed, uint64_t rn_call0, uint64_t rn_sample_offset,
-                          float* P, float* reward, double* delta, double* g, double* G, double* reward_acc, void* workspace,
-                          size_t workspace_bytes, mfg_stream_t stream) {
+}  // extern "C"
+// mat_pi0 != NULL: the start states are DRAWN from the table [num_start,d] (the draw of mfg_draw_start at step = first_step) --
+// inside the first step kernel where the two-launch flow serves -- and pi_io is an output only
+static int train_episode_irl_impl(const float* mat_pi0, int64_t num_start, float* pi_io, float* pi_scratch, int64_t B, int d, int T,
+                                  double* theta, double shift, double alpha_scale, double* w, double gamma, uint64_t seed,
+                                  uint32_t first_step, uint64_t traj_offset, int precision, double lr_critic, double lr_actor,
+                                  const mfg_reward_net_t* net, uint64_t rn_seed, uint64_t rn_call0, uint64_t rn_sample_offset,
+                                  float* P, float* reward, double* delta, double* g, double* G, double* reward_acc, void* workspace,
+                                  size_t workspace_bytes, mfg_stream_t stream) {
   CHECK_BD();
   CHECK_PRECISION();
   REQUIRE(T >= 1, "T < 1");
   REQUIRE(pi_io && pi_scratch && theta && w && net && P && reward && delta && g && G && workspace, "null pointer");
+  REQUIRE(!mat_pi0 || (num_start > 0 && num_start <= 0x7FFFFFFF), "empty / oversized start-state table");
   hipStream_t st = S(stream);
   float* cur = pi_io;
   float* nxt = pi_scratch;
   double discount = 1.0;  // running gamma^t of ac_irl.py:691, :710
+  {
+    // Two launches per env step where the matrix-core reward-network kernel serves (d = 21 / 15, n_fc3 <= 16):
+    //   step kernel (STEP variant): sampling + transition + score with theta formed from the PREVIOUS step's partial rows by
+    //     every wave; the grid's last blocks reduce those rows and publish w, theta, G, the return;
+    //   reward network: r, the TD error delta = r + discount V(pi') - V(pi) from the updated w, this step's partial rows.
+    // The row reduction -- a launch of its own between two dependent launches before -- leaves the critical path.
+    const int64_t FO = mfg_num_features(d) + 3;
+    // workspace: control block | column F of the rows, contiguous [nrows] | the rows [nrows][FO]   (nrows <= 256: one per block)
+    const int64_t max_rows = (B + 15) / 16 < 256 ? (B + 15) / 16 : 256;
+    const int64_t room = workspace_bytes >= MFG_WS_CONTROL_BYTES + (size_t)max_rows * (FO + 1) * 8 ? max_rows : 0;
+    if (d <= WAVE && reward_net_sums_td_ready(B, d, net->k1, net->f2, net->k2, net->n3, net->n4, net->fc3_w, room)) {
+      double* rows_buf = reinterpret_cast<double*>((char*)workspace + MFG_WS_CONTROL_BYTES) + max_rows;
+      double* th_slot = reinterpret_cast<double*>((char*)workspace + 16);  // two slots: theta after odd / even steps
+      const double* th_in = theta;
+      int nrows = 0;
+      if (mat_pi0 && (T & 1)) {  // drawn start states: the buffers alternate so that the LAST step writes pi_io (no copy)
+        cur = pi_scratch;
+        nxt = pi_io;
+      }
+      for (int s = 0; s < T; ++s) {
+        CoreArgs a{};
+        a.pi0 = cur;
+        if (s == 0 && mat_pi0) {  // the first step kernel draws its start states itself and leaves them in `cur` for the network
+          a.pi0 = mat_pi0;
+          a.num_start = num_start;
+          a.start_draw = 1;
+          a.pi_start_out = cur;
+          a.step_nrows = -1;
+        }
+        a.theta = th_in;
+        a.w = nullptr;  // no value part here
+        a.shift = shift;
+        a.alpha_scale = alpha_scale;
+        a.gamma = discount;
+        a.B = B;
+        a.d = d;
+        a.T = 1;
+        a.reward_kind = MFG_REWARD_EXTERNAL;
+        a.seed = seed;
+        a.first_step = first_step + (uint32_t)s;
+        a.traj_offset = traj_offset;
+        a.pi_next_out = nxt;
+        a.g = g;
+        a.P_out = P;
+        if (s > 0) {  // (the first step has nothing to reduce: the plain kernel, without its value part)
+          a.step_G = G;
+          a.pend_lr_c = lr_critic;
+          a.pend_lr_a = lr_actor;
+          a.w_out = w;
+          a.pend_reward_acc = reward_acc;
+          a.step_rows = rows_buf;
+          a.step_nrows = nrows;
+          a.theta_out = th_slot + (s & 1);
+        }
+        int rc = launch_core(a, true, true, precision, st);
+        if (rc != MFG_OK) return rc;
+        if (s > 0) th_in = th_slot + (s & 1);
+        const uint64_t key = rn_seed ^ ((rn_call0 + (uint64_t)s + 1ull) * 0x9E3779B97F4A7C15ull);
+        RnSums sm{};
+        sm.g = g;
+        sm.delta_out = delta;
+        sm.part_rows = rows_buf;
+        sm.max_rows = room;
+        sm.td_w = w;
+        sm.state_next = nxt;
+        sm.td_gamma = discount;
+        sm.col_f = rows_buf - max_rows;
+        int rows = 0;
+        rc = reward_net_forward_sums(cur, P, B, d, net->k1, net->f2, net->k2, net->n3, net->n4, net->conv1_w, net->conv1_b,
+                                     net->conv2_w, net->conv2_b, net->fc3_w, net->fc3_b, net->fc4_w, net->fc4_b, net->out_w,
+                                     net->out_b, net->keep_prob, key, rn_sample_offset, reward, &sm, &rows, stream);
+        if (rc != MFG_OK) return rc;
+        if (rows != (int)max_rows) return fail(MFG_ELAUNCH, "%s", "train_episode_irl: the reward-network launch left no partial rows");
+        nrows = rows;
+        discount *= gamma;
+        float* t = cur;
+        cur = nxt;
+        nxt = t;
+      }
+      hipLaunchKernelGGL(k_reduce_rows_apply, dim3((unsigned)((FO + WAVES - 1) / WAVES)), dim3(BLOCK), 0, st, (const double*)rows_buf,
+                         nrows, FO, G, lr_critic, lr_actor, (double)B, w, th_in, theta, reward_acc);
+      if (cur != pi_io && hipMemcpyAsync(pi_io, cur, (size_t)B * d * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(MFG_ELAUNCH, "%s", "train_episode_irl: final state copy failed");
+      return check_launch("train_episode_irl");
+    }
+  }
+  if (mat_pi0) {
+    hipLaunchKernelGGL(k_draw_start, dim3(grid_for(B * d, 256, 8)), dim3(256), 0, st, mat_pi0, num_start, B, d, seed, first_step,
+                       traj_offset, (int32_t*)nullptr, pi_io);
+    const int rc = check_launch("draw_start");
+    if (rc != MFG_OK) return rc;
+  }
   for (int s = 0; s < T; ++s) {
     CoreArgs a{};
     a.pi0 = cur;
@@ -3649,6 +3770,30 @@ int mfg_train_episode_irl(float* pi_io, float* pi_scratch, int64_t B, int d, int
   if (cur != pi_io && hipMemcpyAsync(pi_io, cur, (size_t)B * d * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
     return fail(MFG_ELAUNCH, "%s", "train_episode_irl: final state copy failed");
   return check_launch("train_episode_irl");
+}
+
+extern "C" {
+int mfg_train_episode_irl(float* pi_io, float* pi_scratch, int64_t B, int d, int T, double* theta, double shift,
+                          double alpha_scale, double* w, double gamma, uint64_t seed, uint32_t first_step,
+                          uint64_t traj_offset, int precision, double lr_critic, double lr_actor,
+                          const mfg_reward_net_t* net, uint64_t rn_seed, uint64_t rn_call0, uint64_t rn_sample_offset,
+                          float* P, float* reward, double* delta, double* g, double* G, double* reward_acc, void* workspace,
+                          size_t workspace_bytes, mfg_stream_t stream) {
+  return train_episode_irl_impl(nullptr, 0, pi_io, pi_scratch, B, d, T, theta, shift, alpha_scale, w, gamma, seed, first_step,
+                                traj_offset, precision, lr_critic, lr_actor, net, rn_seed, rn_call0, rn_sample_offset, P, reward,
+                                delta, g, G, reward_acc, workspace, workspace_bytes, stream);
+}
+
+int mfg_train_episode_irl_draw(const float* mat_pi0, int64_t num_start, float* pi_out, float* pi_scratch, int64_t B, int d, int T,
+                               double* theta, double shift, double alpha_scale, double* w, double gamma, uint64_t seed,
+                               uint32_t first_step, uint64_t traj_offset, int precision, double lr_critic, double lr_actor,
+                               const mfg_reward_net_t* net, uint64_t rn_seed, uint64_t rn_call0, uint64_t rn_sample_offset,
+                               float* P, float* reward, double* delta, double* g, double* G, double* reward_acc, void* workspace,
+                               size_t workspace_bytes, mfg_stream_t stream) {
+  if (!mat_pi0) return fail(MFG_EINVAL, "%s", "train_episode_irl_draw: null start-state table");
+  return train_episode_irl_impl(mat_pi0, num_start, pi_out, pi_scratch, B, d, T, theta, shift, alpha_scale, w, gamma, seed,
+                                first_step, traj_offset, precision, lr_critic, lr_actor, net, rn_seed, rn_call0, rn_sample_offset,
+                                P, reward, delta, g, G, reward_acc, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

@@ -39,6 +39,14 @@ struct RewardNetArgs {
   const double* gsc;
   double* delta_out;
   double* part_rows;  // [gridDim.x][F+3]
+  // matrix-core SUMS kernel: the TD error's value part is formed HERE, delta0_b = sum_k w_k (gamma phi_k(next_b) - phi_k(state_b))
+  // (ac_irl.py:686-691 with the critic of mfg_ac2.py:333-347), from the features the batch sums need anyway -- the step kernel
+  // that precedes this launch then needs theta only, and the row reduction of the previous env step runs inside it
+  const double* td_w;       // [F] critic weights
+  const float* state_next;  // [B,d]
+  double td_gamma;          // discount^t of this env step
+  double* col_f;            // [gridDim.x] column F (the actor's sum) of the partial rows once more, contiguous: what every
+                            // sampling wave of the next step kernel reads
   // states inside a rollout's pi_traj [B', T+1, d]: sample n = (b', t) reads row b' (T+1) + t (state_T = T; 0: plain [B,d])
   int state_T;
 };
@@ -633,10 +641,12 @@ struct MfmaGeom {
   // weight transposition (16 rows of KW + 2)
   static_assert(P1 >= D + 2 * H1, "tile pitch");
   static constexpr int T1 = D * P1, WS = KW + 2, TS = ((T1 > 16 * WS ? T1 : 16 * WS) + 3) & ~3;
+  // SUMS: two lines [state | 1], [next state | 1] per wave and the critic weights as doubles, zero-padded to whole waves of entries
+  static constexpr int SUMS_WPAD = ((D * (D + 1) / 2 + D + 1 + 3 + WAVE - 1) / WAVE) * WAVE;
   static size_t lds_floats(int n3, int n4, bool sums) {
     size_t fl = (size_t)(n4 * (n3 + D) + 2 * n4 + 1 + n3);
     fl = (fl + 3) & ~(size_t)3;
-    return fl + (size_t)RM_WAVES * (PITCH + RM_RED + TS) + 2 * RM_WAVES * 16 + (sums ? RM_WAVES * 32 : 0);
+    return fl + (size_t)RM_WAVES * (PITCH + RM_RED + TS) + 2 * RM_WAVES * 16 + (sums ? RM_WAVES * 64 + 2 * SUMS_WPAD : 0);
   }
 };
 
@@ -680,8 +690,8 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
   const int64_t ngroups = (a.B + RM_WAVES - 1) / RM_WAVES;
   int64_t g = blockIdx.x;
   int64_t b = g * RM_WAVES + wv;
-  float av[PP], st_mine = 0.0f;
-  double d0_next = 0.0, g_next = 0.0;
+  float av[PP], st_mine = 0.0f, sn_mine = 0.0f;
+  double g_next = 0.0;
   // (every load of the prologue is UNCONDITIONAL, from a clamped address, and masked afterwards: loads under branches make
   //  the compiler wait for all outstanding loads at the first use of any of them -- including the weight slice below)
   {
@@ -696,7 +706,8 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
     const float sv = a.state[rn_state_row(a, bc) * D + (lane >= n3 && lane < nin ? lane - n3 : 0)];
     st_mine = st_ok ? sv : 0.0f;
     if constexpr (SUMS) {
-      d0_next = a.delta0[bc];
+      const float nv = a.state_next[bc * D + (lane >= n3 && lane < nin ? lane - n3 : 0)];
+      sn_mine = st_ok ? nv : 0.0f;
       g_next = a.gsc[bc];
     }
   }
@@ -742,6 +753,11 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
     for (int q = 0; q < NP4; ++q) pw4[q] = q * WAVE < nw4 ? a.w4[lane + q * WAVE < nw4 ? lane + q * WAVE : 0] : 0.0f;
     const float pb4 = a.b4[lane < n4 ? lane : 0], pwo = a.wo[lane < n4 ? lane : 0], pb3 = a.b3[lane < n3 ? lane : 0];
     const float pbo = a.bo[0];
+    double pwt[NPL];
+    if constexpr (SUMS) {
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) pwt[q] = a.td_w[lane + q * WAVE < Fs ? lane + q * WAVE : 0];
+    }
     if constexpr (SUMS) {
       static constexpr SumsTable<D> tab{};
 #pragma unroll
@@ -750,6 +766,11 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
 #pragma unroll
     for (int q = 0; q < NP4; ++q)
       if (lane + q * WAVE < nw4) s_w4[lane + q * WAVE] = pw4[q];
+    if constexpr (SUMS) {
+      double* s_wtd0 = reinterpret_cast<double*>(tiles + RM_WAVES * Gm::TS + 2 * RM_WAVES * 16 + RM_WAVES * 64);
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) s_wtd0[lane + q * WAVE] = lane + q * WAVE < Fs ? pwt[q] : 0.0;
+    }
     if (lane < n4) {
       s_b4[lane] = pb4;
       s_wo[lane] = pwo;
@@ -814,7 +835,8 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
     o1[q] = (pc / D) * P1 + pc % D + H1;
   }
   float* s_udrop = tiles + RM_WAVES * Gm::TS;  // [2][16 samples][16 slots]
-  float* xs = s_udrop + 2 * RM_WAVES * 16 + wv * 32;  // (only allocated for SUMS launches)
+  float* xs = s_udrop + 2 * RM_WAVES * 16 + wv * 64;  // (only allocated for SUMS launches): [state | 1], at + 32 [next state | 1]
+  const double* s_wtd = reinterpret_cast<const double*>(s_udrop + 2 * RM_WAVES * 16 + RM_WAVES * 64);  // critic weights
   double e_acc[NPL];
   if constexpr (SUMS) {
     // (the run-mapped kernel derives the entries with a search per lane: ~800 instructions per wave, as much as a sample's
@@ -822,6 +844,7 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
 #pragma unroll
     for (int q = 0; q < NPL; ++q) e_acc[q] = 0.0;
     if (lane == 0) xs[D] = 1.0f;
+    if (lane == 1) xs[32 + D] = 1.0f;
   }
   const bool shared_u = n3 + n4 <= 16;
   int u_par = 0;
@@ -840,8 +863,11 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
     for (int q = 0; q < PP; ++q)
       if (ln + q * WAVE < DD) tin[o1[q]] = av[q];
     const float st_cur = st_mine;
-    const double d0_cur = d0_next, g_cur = g_next;
-    if (SUMS && ln >= n3 && ln < nin) xs[lane - n3] = st_cur;
+    const double g_cur = g_next;
+    if (SUMS && ln >= n3 && ln < nin) {
+      xs[lane - n3] = st_cur;
+      xs[32 + lane - n3] = sn_mine;
+    }
     {
       // (one uniform branch, unconditional loads from clamped addresses: pixels beyond DD are never written to the tile, the
       //  state entry is masked where it is used)
@@ -852,13 +878,28 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
         for (int q = 0; q < PP; ++q) av[q] = src[(q + 1) * WAVE <= DD ? lane + q * WAVE : (ln + q * WAVE < DD ? lane + q * WAVE : 0)];
         st_mine = a.state[rn_state_row(a, bn) * D + (ln >= n3 && ln < nin ? lane - n3 : 0)];
         if constexpr (SUMS) {
-          d0_next = a.delta0[bn];
+          sn_mine = a.state_next[bn * D + (ln >= n3 && ln < nin ? lane - n3 : 0)];
           g_next = a.gsc[bn];
         }
       }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
+    // value part of the TD error from the lane's feature entries: delta0 = sum_k w_k (gamma phi_k(next) - phi_k(state)); the wave
+    // sum is not needed before the fold at the end of the pass
+    double d0_cur = 0.0;
+    if constexpr (SUMS) {
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) {
+        if (q * WAVE < Fs) {
+          const int ia = tabv[q] & 0xFFu, ib = (tabv[q] >> 8) & 0xFFu;
+          const double x = (double)xs[ia] * (double)xs[ib], xn = (double)xs[32 + ia] * (double)xs[32 + ib];
+          acc = fma(s_wtd[lane + q * WAVE], fma(a.td_gamma, xn, -x), acc);   // (weights beyond F are staged as zeros)
+        }
+      }
+      d0_cur = wave_sum_dpp(acc);
+    }
     // 2. conv1 5x5 + ReLU over the run: the run's own row from LDS, rows y -+ 1, y -+ 2 from the lanes below / above.
     // The weights of a convolution come in through the scalar cache right before it (read-only memory, uniform addresses:
     // scalar loads, no vector instruction) -- all 46 of them held for the whole loop do not fit next to the kernel's
@@ -1085,12 +1126,33 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
 #pragma unroll
       for (int w_ = 1; w_ < RM_WAVES; ++w_) t += rows[w_ * FO + k];
       a.part_rows[(int64_t)blockIdx.x * FO + k] = t;
+      if (k == Fs) a.col_f[blockIdx.x] = t;
     }
   }
 #ifdef MFG_RN_STAMPS
   first_pass = true;
 #endif
   RN_STAMP(11)
+}
+
+// dynamic LDS above 64 KB needs the attribute, which applies to the CURRENT device: once per device, result kept -- a device
+// where it failed takes the run-mapped kernels
+template <int D, int RUN, int RPR, int P1>
+static bool mfma_lds_attribute() {
+  static std::mutex attr_mu;
+  static signed char attr_state[64] = {0};   // 0 = not tried, 1 = ok, -1 = failed
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lock(attr_mu);
+  if (attr_state[dev] == 0) {
+    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+    attr_state[dev] = (e1 == hipSuccess && e2 == hipSuccess) ? 1 : -1;
+    (void)hipGetLastError();
+  }
+  return attr_state[dev] > 0;
 }
 
 template <int D, int RUN, int RPR, int P1>
@@ -1100,24 +1162,8 @@ static int launch_reward_net_mfma(const RewardNetArgs& a, bool want_sums, int64_
   if (grid > 256) grid = 256;  // one 16-wave block per CU (LDS: 137 KB at d = 21)
   const bool sums = want_sums && grid <= max_rows;
   const size_t lds = Gm::lds_floats(a.n3, a.n4, sums) * 4;
-  // dynamic LDS above 64 KB needs the attribute, which applies to the CURRENT device: once per device, result kept --
-  // a device where it failed takes the run-mapped kernels (return 1: the caller falls through)
-  static std::mutex attr_mu;
-  static signed char attr_state[64] = {0};   // 0 = not tried, 1 = ok, -1 = failed
-  {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
-    std::lock_guard<std::mutex> lock(attr_mu);
-    if (attr_state[dev] == 0) {
-      const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);  // (the SUMS variant also holds a few static bytes)
-      const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_mfma<D, RUN, RPR, P1, false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);  // (the SUMS variant also holds a few static bytes)
-      attr_state[dev] = (e1 == hipSuccess && e2 == hipSuccess) ? 1 : -1;
-      (void)hipGetLastError();
-    }
-    if (attr_state[dev] < 0) return 1;
-  }
+  // (return 1: the caller falls through to the run-mapped kernels)
+  if (!mfma_lds_attribute<D, RUN, RPR, P1>()) return 1;
   if (sums) {
     hipLaunchKernelGGL((k_reward_net_mfma<D, RUN, RPR, P1, true>), dim3((unsigned)grid), dim3(RM_BLOCK), lds, st, a);
     *rows_out = (int)grid;
@@ -1132,6 +1178,17 @@ static int launch_reward_net_mfma(const RewardNetArgs& a, bool want_sums, int64_
 using namespace mfg;
 
 namespace mfg {
+static bool mfma_shape_ok(int d, int k1, int f2, int k2, int n3, const float* fc3_w) {
+  return MFG_RN_MFMA && k1 == 5 && k2 == 3 && f2 == 2 && n3 <= 16 && (d == 21 || d == 15) && (((uintptr_t)fc3_w & 7) == 0);
+}
+bool reward_net_sums_td_ready(int64_t B, int d, int k1, int f2, int k2, int n3, int n4, const float* fc3_w, int64_t max_rows) {
+  if (B < 1 || n3 < 1 || n4 < 1 || n4 > RN_MAXN || !mfma_shape_ok(d, k1, f2, k2, n3, fc3_w)) return false;
+  int64_t grid = (B + RM_WAVES - 1) / RM_WAVES;
+  if (grid > 256) grid = 256;
+  if (grid > max_rows) return false;
+  return d == 21 ? mfma_lds_attribute<21, 7, 3, MFG_RM_P21>() : mfma_lds_attribute<15, 5, 3, MFG_RM_P15>();
+}
+
 // sums != NULL: ask for the SUMS variant; *rows_out = partial rows written (0: this shape has no SUMS kernel -- the plain
 // forward ran and the caller takes the separate gradient kernel)
 int reward_net_forward_sums(const float* state, const float* action, int64_t B, int d, int k1, int f2, int k2, int n3, int n4,
@@ -1156,6 +1213,10 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
     a.gsc = sums->g;
     a.delta_out = sums->delta_out;
     a.part_rows = sums->part_rows;
+    a.td_w = sums->td_w;
+    a.state_next = sums->state_next;
+    a.td_gamma = sums->td_gamma;
+    a.col_f = sums->col_f;
   }
   const int dd = d * d;
   const int W1 = d + 2 * (k1 / 2), W2 = d + 2 * (k2 / 2);
@@ -1185,8 +1246,9 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
   // w3 rows are read as float2 at even offsets: needs an 8-byte aligned fc3_w when it is not staged in LDS
   const bool runs_ok = ref_geom && (a.w3_in_lds || (((uintptr_t)fc3_w & 7) == 0));
   const bool want_sums = sums && sums->delta0 && sums->g && sums->delta_out && sums->part_rows && grid <= sums->max_rows;
-  const bool sums_ptrs = sums && sums->delta0 && sums->g && sums->delta_out && sums->part_rows;
-  const bool mfma_ok = MFG_RN_MFMA && ref_geom && n3 <= 16 && (d == 21 || d == 15) && (((uintptr_t)fc3_w & 7) == 0);
+  // (the matrix-core SUMS kernel forms the TD error itself: it wants the critic weights and the next states, not delta0)
+  const bool sums_ptrs = sums && sums->td_w && sums->state_next && sums->col_f && sums->g && sums->delta_out && sums->part_rows;
+  const bool mfma_ok = mfma_shape_ok(d, k1, f2, k2, n3, fc3_w);
   bool mfma_done = false;
   if (mfma_ok) {
     int rows = 0;

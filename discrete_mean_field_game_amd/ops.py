@@ -458,21 +458,28 @@ def reward_net_struct(net, dropout=None):
 
 
 def train_episode_irl(pi, T, theta, shift, alpha_scale, w, gamma, lr_critic, lr_actor, net, G, ws, bufs, seed=0, first_step=0,
-                      traj_offset=0, rn_seed=0, rn_call0=0, rn_sample_offset=0, reward_acc=None, precision='mixed'):
+                      traj_offset=0, rn_seed=0, rn_call0=0, rn_sample_offset=0, reward_acc=None, precision='mixed', mat_pi0=None):
     """T env steps of AC_IRL.train with per-step updates, issued natively (single GPU): sample + transition + score,
     reward network, batch sums + update per step.  `pi` [B,d] is updated in place to the final states; `bufs` =
-    dict(scratch [B,d] f32, P [B,d,d] f32, reward [B] f32, delta [B] f64, g [B] f64); `net` = networks.RewardNet."""
+    dict(scratch [B,d] f32, P [B,d,d] f32, reward [B] f32, delta [B] f64, g [B] f64); `net` = networks.RewardNet.
+    mat_pi0 [num_start,d]: the start states are drawn from this table inside the call (the draw of draw_start at step =
+    first_step; `pi` is then an output only)."""
     import ctypes as C
     _chk_f32(pi, 'pi'); _chk_f64(theta, 'theta'); _chk_f64(w, 'w')
     B, d = pi.shape
     st = reward_net_struct(net)
-    L.check(L.lib().mfg_train_episode_irl(pi.data_ptr(), bufs['scratch'].data_ptr(), B, d, int(T), theta.data_ptr(),
-                                          float(shift), float(alpha_scale), w.data_ptr(), float(gamma), int(seed),
-                                          int(first_step), int(traj_offset), L.PRECISIONS[precision], float(lr_critic),
-                                          float(lr_actor), C.byref(st), int(rn_seed) & 0xFFFFFFFFFFFFFFFF, int(rn_call0),
-                                          int(rn_sample_offset), bufs['P'].data_ptr(), bufs['reward'].data_ptr(),
-                                          bufs['delta'].data_ptr(), bufs['g'].data_ptr(), G.data_ptr(), _ptr(reward_acc),
-                                          ws.data_ptr(), ws.numel() * 8, _stream()), 'mfg_train_episode_irl')
+    rest = (pi.data_ptr(), bufs['scratch'].data_ptr(), B, d, int(T), theta.data_ptr(), float(shift), float(alpha_scale),
+            w.data_ptr(), float(gamma), int(seed), int(first_step), int(traj_offset), L.PRECISIONS[precision], float(lr_critic),
+            float(lr_actor), C.byref(st), int(rn_seed) & 0xFFFFFFFFFFFFFFFF, int(rn_call0), int(rn_sample_offset),
+            bufs['P'].data_ptr(), bufs['reward'].data_ptr(), bufs['delta'].data_ptr(), bufs['g'].data_ptr(), G.data_ptr(),
+            _ptr(reward_acc), ws.data_ptr(), ws.numel() * 8, _stream())
+    if mat_pi0 is None:
+        L.check(L.lib().mfg_train_episode_irl(*rest), 'mfg_train_episode_irl')
+    else:
+        _chk_f32(mat_pi0, 'mat_pi0')
+        if mat_pi0.dim() != 2 or mat_pi0.shape[1] != d:
+            raise ValueError('train_episode_irl: mat_pi0 must be [num_start, %d]' % d)
+        L.check(L.lib().mfg_train_episode_irl_draw(mat_pi0.data_ptr(), int(mat_pi0.shape[0]), *rest), 'mfg_train_episode_irl_draw')
     return pi
 
 

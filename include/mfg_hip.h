@@ -396,6 +396,10 @@ typedef struct mfg_reward_net {
  *   r = r_net(pi, P)                                                              (mfg_reward_net_forward, :683)
  *   delta = r + delta0; batch sums; w += lr_critic G_w/B, theta += lr_actor G_theta/B; *reward_acc += mean r   (:691-708)
  *   discount *= gamma; pi <- pi'                                                   (:710-711)
+ * Where the matrix-core reward-network kernel serves (d = 21 / 15, the reference's layer geometry, n_fc3 <= 16) an env step is
+ * TWO launches: [sampling + transition + score, theta formed by every wavefront from the previous step's partial sums; the
+ * grid's last blocks reduce those sums and publish w, theta, G, the return] | [reward network + TD error from the updated w
+ * + this step's partial sums]; one row reduction closes the episode.  Otherwise three (step | network | row reduction).
  * The dropout masks of step s use the Philox key  rn_seed ^ ((rn_call0 + s + 1) * 0x9E3779B97F4A7C15)  (mod 2^64) and the
  * sample counter rn_sample_offset + b -- the keys the host class would have passed to T separate
  * mfg_reward_net_forward calls numbered rn_call0 + 1 ... .  pi_io [B,d]: start states in, final states out; pi_scratch
@@ -407,6 +411,16 @@ int mfg_train_episode_irl(float* pi_io, float* pi_scratch, int64_t B, int d, int
                           const mfg_reward_net_t* net_host, uint64_t rn_seed, uint64_t rn_call0, uint64_t rn_sample_offset,
                           float* P, float* reward, double* delta, double* g, double* G, double* reward_acc, void* workspace,
                           size_t workspace_bytes, mfg_stream_t stream);
+
+/* The same episode with the start states DRAWN from the table mat_pi0 [num_start,d] (the draw of mfg_draw_start at
+ * step = first_step, trajectory ids traj_offset + b; ac_irl.py:655) -- inside the first step kernel where the two-launch flow
+ * serves, by a launch of its own otherwise.  pi_out [B,d]: final states (output only); the rest as above. */
+int mfg_train_episode_irl_draw(const float* mat_pi0, int64_t num_start, float* pi_out, float* pi_scratch, int64_t B, int d, int T,
+                               double* theta, double shift, double alpha_scale, double* w, double gamma, uint64_t seed,
+                               uint32_t first_step, uint64_t traj_offset, int precision, double lr_critic, double lr_actor,
+                               const mfg_reward_net_t* net_host, uint64_t rn_seed, uint64_t rn_call0, uint64_t rn_sample_offset,
+                               float* P, float* reward, double* delta, double* g, double* G, double* reward_acc, void* workspace,
+                               size_t workspace_bytes, mfg_stream_t stream);
 
 /* a9 (IRL flavour), one update per episode (the batched form of ac_irl.py:664-712 with theta, w fixed over the episode) on
  * ONE GPU, issued natively: [fused T-step rollout: start states drawn in the kernel (idx == NULL) or gathered, actions
