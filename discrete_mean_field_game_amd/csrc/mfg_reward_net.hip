@@ -1135,402 +1135,6 @@ __global__ __launch_bounds__(RM_BLOCK) void k_reward_net_mfma(RewardNetArgs a) {
   RN_STAMP(11)
 }
 
-// =============================================================================================
-// Row-mapped matrix-core kernel (round 5, second half): lane = (sample j of the wave, image row y).
-//
-// The strip-mapped kernel above gives a wavefront ONE sample: its ~300 multiply-adds per lane come with as many instructions
-// of per-sample overhead again (tile write, strip-edge predicates and permutes, the loop's scalar bookkeeping, a tail that uses
-// 16 of 64 lanes) -- ~840 instructions per sample.  Here a wavefront carries SPW = 64 / d samples (3 at d = 21, 4 at d = 15):
-//   * a lane owns image row y of sample j: the d inputs of its row in registers (read once from the wave's staging buffer), the
-//     rows above / below from the neighbouring lanes (one DPP move per value; lanes at the top / bottom of an image skip those
-//     taps under the exec mask -- the lane beyond belongs to another sample); no strips, no side columns, no halo;
-//   * the actions of a wave's samples are contiguous in memory: 16-byte lane-contiguous loads a pass ahead, committed to the
-//     wave's staging buffer at the top of their pass, from where every lane picks up its row;
-//   * FC3 on the matrix cores, split along K over the block's 4 waves; the k's of a wave are visited in an order that makes
-//     BOTH operands 16-byte pieces (the weights straight from global memory, once per kernel; the activations with one
-//     ds_read_b128 per four matrix instructions);
-//   * the tail (FC3 bias / ReLU / dropout, FC4, output) runs 16 lanes per sample for all samples of the wave at once.
-// A block is 4 waves = 12 (16) samples per pass, ~77 KB of LDS: two blocks per CU.
-// =============================================================================================
-constexpr int RR_WAVES = 4, RR_BLOCK = RR_WAVES * WAVE;
-#ifdef MFG_RN_STAMPS
-// (developer build: shader-clock stamps of the phases of blocks 0 and 100, second pass, tools/rr_stamps.py)
-#define RR_STAMP(i)                                                                                 \
-  if ((blockIdx.x == 0 || blockIdx.x == 100) && lane == 0 && g == (int64_t)blockIdx.x + gridDim.x)  \
-    rn_stamps[((blockIdx.x ? 1 : 0) * RM_WAVES + wv) * 16 + (i)] = __builtin_readcyclecounter();
-#else
-#define RR_STAMP(i)
-#endif
-typedef __attribute__((address_space(3))) void* rn_lds_ptr_t;
-typedef __attribute__((address_space(1))) const void* rn_glb_ptr_t;
-
-template <int D>
-struct RowsGeom {
-  static_assert(D <= 32 && (D & 1), "odd d <= 32: rows of D floats are bank-conflict free at lane stride D");
-  static constexpr int K1 = 5, K2 = 3, F2 = 2, H1 = 2, H2 = 1, DD = D * D;
-  static constexpr int SPW = WAVE / D, SPB = RR_WAVES * SPW;  // samples per wave / per block and pass
-  static_assert(SPB <= 16, "one 16-row tile of the matrix instruction per pass");
-  static constexpr int K = F2 * DD;                                                      // FC3 inputs
-  static constexpr int KW = ((K + RR_WAVES * 16 - 1) / (RR_WAVES * 16)) * 16, NP = KW / 16, KP = RR_WAVES * KW;
-  static constexpr int PITCH = ((KP + 31) / 32) * 32 + 4;  // activation rows: = 4 mod 32 (16-byte operand reads of 16 rows)
-  static constexpr int NF = SPW * DD;                      // floats of a wave's samples (contiguous in memory)
-  static constexpr int NX4 = NF / 256, NX1 = (NF - NX4 * 256 + 63) / 64, STG = NX4 * 256 + NX1 * 64;
-  static constexpr int LINE = 64;                          // per sample: FC4's input [h3 | state], zero padded (48) | uniforms (16)
-  static size_t lds_floats(int n3, int n4) {
-    size_t fl = (size_t)(n4 * (n3 + D) + 2 * n4 + 1 + n3);
-    fl = (fl + 3) & ~(size_t)3;
-    return fl + (size_t)SPB * PITCH + RR_WAVES * 256 + RR_WAVES * STG + (size_t)SPB * LINE;
-  }
-};
-
-template <int D, bool SUMS, bool DROP>
-__global__ __launch_bounds__(RR_BLOCK, 2) void k_reward_net_rows(RewardNetArgs a) {
-  using Gm = RowsGeom<D>;
-  constexpr int K1 = Gm::K1, K2 = Gm::K2, H1 = Gm::H1, DD = Gm::DD, SPW = Gm::SPW, SPB = Gm::SPB;
-  constexpr int KK = Gm::K, KW = Gm::KW, NP = Gm::NP, PITCH = Gm::PITCH, LINE = Gm::LINE;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n3 = a.n3, n4 = a.n4, nin = n3 + D;
-  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-  const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE);
-  float* s_w4 = smem;
-  float* s_b4 = s_w4 + n4 * nin;
-  float* s_wo = s_b4 + n4;
-  float* s_bo = s_wo + n4;
-  float* s_b3 = s_bo + 1;
-  int off = n4 * nin + 2 * n4 + 1 + n3;
-  off = (off + 3) & ~3;
-  float* acts = smem + off;                                   // [SPB][PITCH]
-  float* red = acts + SPB * PITCH;                            // [RR_WAVES k-slices][16 samples][16 units]
-  float* stage = red + RR_WAVES * 256 + wv * Gm::STG;         // this wave's staging buffer
-  float* lines = red + RR_WAVES * 256 + RR_WAVES * Gm::STG + wv * SPW * LINE;
-  // lane coordinates: convolutions (sample j, row y) / tail (sample tj, slot sub)
-  const bool active = lane < SPW * D;
-  const int la = active ? lane : SPW * D - 1;
-  const int j = la / D, y = la - j * D;
-  const int tj = lane >> 4, sub = lane & 15;
-  const int tjc = tj < SPW ? tj : SPW - 1;
-  const int64_t ngroups = (a.B + SPB - 1) / SPB;
-  int64_t g = blockIdx.x;
-  // A group's actions: NX4 pieces of 16 bytes per lane + NX1 of 4, lane-contiguous (the samples of a wave are contiguous in
-  // memory), fetched into registers a pass ahead and committed to the wave's staging buffer at the top of their pass.
-  // (Tried first: LDS-DMA, global_load_lds -- no registers, but every piece cost ~330 cycles of issue wherever it was placed,
-  //  2 000 of a pass's 14 800.)  A lane whose 16 bytes would pass the end of the array (the launch's last wave) reads its
-  // floats one by one from clamped addresses.
-  rn_v4f_u av4[Gm::NX4 > 0 ? Gm::NX4 : 1];
-  float av1[Gm::NX1 > 0 ? Gm::NX1 : 1];
-  auto fetch_group = [&](int64_t gg) {
-    const int64_t bw = gg * SPB + (int64_t)wv * SPW;
-    if (bw >= a.B) return;
-    const int64_t left = (a.B - bw) * DD;  // floats up to the end of the array (>= DD)
-    const float* src = a.action + bw * DD;  // (wave-uniform base + 32-bit lane offsets: no 64-bit lane addresses kept across the loop)
-    if (left >= Gm::STG) {
-#pragma unroll
-      for (int p = 0; p < Gm::NX4; ++p) av4[p] = *reinterpret_cast<const rn_v4f_u*>(src + (unsigned)(p * 256 + 4 * lane));
-#pragma unroll
-      for (int p = 0; p < Gm::NX1; ++p) av1[p] = src[(unsigned)(Gm::NX4 * 256 + p * 64 + lane)];
-    } else {  // the launch's last wave(s): float by float, clamped to the array
-      const unsigned last = (unsigned)(left - 1);
-#pragma unroll
-      for (int p = 0; p < Gm::NX4; ++p)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const unsigned i = (unsigned)(p * 256 + 4 * lane + c);
-          av4[p][c] = src[i < last ? i : last];
-        }
-#pragma unroll
-      for (int p = 0; p < Gm::NX1; ++p) {
-        const unsigned i = (unsigned)(Gm::NX4 * 256 + p * 64 + lane);
-        av1[p] = src[i < last ? i : last];
-      }
-    }
-  };
-  auto commit_group = [&]() {
-#pragma unroll
-    for (int p = 0; p < Gm::NX4; ++p) *reinterpret_cast<rn_v4f_t*>(stage + p * 256 + 4 * lane) = rn_v4f_t{av4[p][0], av4[p][1], av4[p][2], av4[p][3]};
-#pragma unroll
-    for (int p = 0; p < Gm::NX1; ++p) stage[Gm::NX4 * 256 + p * 64 + lane] = av1[p];
-  };
-  fetch_group(g);
-  // state of (sample j, entry y): FC4's second input block; fetched a pass ahead
-  float st_next = 0.0f;
-  {
-    const int64_t bj = g * SPB + (int64_t)wv * SPW + j;
-    const float v = a.state[rn_state_row(a, bj < a.B ? bj : 0) * D + y];
-    st_next = (active && bj < a.B) ? v : 0.0f;
-  }
-  // This wave's slice of the FC3 weights as B operands: lane (unit n = lane % 16, kq = lane / 16) holds, for piece p and
-  // c < 4, W3[n][wv KW + 16 p + 4 kq + c] -- 16-byte pieces of the rows, straight from global memory.  The matching A operand
-  // is the 16-byte piece of activation row (sample lane % 16) at the same k's: the sum over k does not care about the order.
-  float wreg[4 * NP];
-  {
-    const int n = lane & 15, kq = lane >> 4;
-    const float* row = a.w3 + (n < n3 ? n : n3 - 1) * KK;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      const int k0 = wv * KW + 16 * p + 4 * kq;
-      const int k0c = k0 <= KK - 4 ? k0 : KK - 4;
-      const rn_v4f_u v = *reinterpret_cast<const rn_v4f_u*>(row + k0c);
-      if ((RR_WAVES - 1) * KW + 16 * p + 15 < KK) {  // (compile time: no wave's piece p reaches the end of a row)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) wreg[4 * p + c] = n < n3 ? v[c] : 0.0f;
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int sh = k0 + c - k0c;  // 0 .. 3 while k0 + c < KK
-          const float e = sh == 0 ? v[0] : (sh == 1 ? v[1] : (sh == 2 ? v[2] : v[3]));
-          wreg[4 * p + c] = (n < n3 && k0 + c < KK) ? e : 0.0f;
-        }
-      }
-    }
-  }
-  for (int k = tid; k < n4 * nin; k += RR_BLOCK) s_w4[k] = a.w4[k];
-  if (tid < n4) {
-    s_b4[tid] = a.b4[tid];
-    s_wo[tid] = a.wo[tid];
-  }
-  if (tid == 0) s_bo[0] = a.bo[0];
-  if (tid < n3) s_b3[tid] = a.b3[tid];
-  // zero padding: the k's beyond K of every activation row; the FC4 input lines (their tail beyond n3 + d stays zero)
-  for (int k = tid; k < SPB * (PITCH - KK); k += RR_BLOCK) acts[(k / (PITCH - KK)) * PITCH + KK + k % (PITCH - KK)] = 0.0f;
-  for (int k = lane; k < SPW * LINE; k += WAVE) lines[k] = 0.0f;
-  __syncthreads();
-  const float inv_keep = 1.0f / a.keep_prob;
-  constexpr bool drop = DROP;
-  const bool shared_u = n3 + n4 <= 16;
-  const float* srow = stage + j * DD + y * D;
-  float2* arow = reinterpret_cast<float2*>(acts + (wv * SPW + j) * PITCH + y * 2 * D);
-  const float* abase = acts + ((lane & 15) < SPB ? (lane & 15) : SPB - 1) * PITCH + wv * KW + 4 * (lane >> 4);
-  float* red_out = red + (wv * 16 + 4 * (lane >> 4)) * 16 + (lane & 15);
-  const float* red_in = red + (wv * SPW + tjc) * 16 + sub;
-  float* xl = lines + tjc * LINE;
-  for (; g < ngroups; g += gridDim.x) {  // (block-uniform trip count: the barriers below are taken by all waves)
-    const int64_t bw = g * SPB + (int64_t)wv * SPW;
-    int yv = y;
-    asm volatile("" : "+v"(yv));  // (the row predicates are formed where they are used)
-    // 1. this wave's rows out of the staging buffer (landed: vmcnt), the buffer is then refilled for the next pass
-    RR_STAMP(0)
-    commit_group();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    RR_STAMP(1)
-    float in[D];
-#pragma unroll
-    for (int x = 0; x < D; ++x) in[x] = srow[x];
-    const float st_cur = st_next;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the rows are in registers)
-    {
-      const int64_t bn = bw + (int64_t)gridDim.x * SPB + j;
-      if (g + gridDim.x < ngroups) {
-        const float v = a.state[rn_state_row(a, bn < a.B ? bn : 0) * D + y];
-        st_next = (active && bn < a.B) ? v : 0.0f;
-      }
-    }
-    if (active) lines[j * LINE + n3 + y] = st_cur;
-    RR_STAMP(2)
-    RnConstF c1w_s = (RnConstF)a.c1w, c1b_s = (RnConstF)a.c1b, c2w_s = (RnConstF)a.c2w, c2b_s = (RnConstF)a.c2b;
-    asm volatile("" : "+s"(c1w_s), "+s"(c1b_s), "+s"(c2w_s), "+s"(c2b_s));  // (the weight loads stay in the loop)
-    // 2. conv1 5x5 + ReLU: row y of the map from rows y - 2 .. y + 2 of the input
-    float c1[D];
-    {
-      float w1[K1 * K1];
-#pragma unroll
-      for (int k = 0; k < K1 * K1; ++k) w1[k] = c1w_s[k];
-      const float b1 = c1b_s[0];
-#pragma unroll
-      for (int x = 0; x < D; ++x) c1[x] = b1;
-#define RR_ROW1(R, DY)                                                                       \
-  _Pragma("unroll") for (int x = 0; x < D; ++x) {                                            \
-    _Pragma("unroll") for (int dx = 0; dx < K1; ++dx) {                                      \
-      const int xx = x + dx - H1;                                                            \
-      if (xx >= 0 && xx < D) c1[x] = fmaf(R[xx], w1[(DY)*K1 + dx], c1[x]);                   \
-    }                                                                                        \
-  }
-      RR_ROW1(in, H1)
-      float t[D];
-#pragma unroll
-      for (int x = 0; x < D; ++x) t[x] = lane_below(in[x]);
-      if (yv >= 1) { RR_ROW1(t, H1 - 1) }
-#pragma unroll
-      for (int x = 0; x < D; ++x) t[x] = lane_below(t[x]);
-      if (yv >= 2) { RR_ROW1(t, H1 - 2) }
-#pragma unroll
-      for (int x = 0; x < D; ++x) t[x] = lane_above(in[x]);
-      if (yv + 1 < D) { RR_ROW1(t, H1 + 1) }
-#pragma unroll
-      for (int x = 0; x < D; ++x) t[x] = lane_above(t[x]);
-      if (yv + 2 < D) { RR_ROW1(t, H1 + 2) }
-#undef RR_ROW1
-#pragma unroll
-      for (int x = 0; x < D; ++x) c1[x] = relu_f32(c1[x]);
-    }
-    RR_STAMP(3)
-    // 3. conv2 3x3, two filters (one packed FMA per tap) + ReLU -> the sample's activation row, NHWC order
-    {
-      rn_v2f_t w2[K2 * K2];
-#pragma unroll
-      for (int k = 0; k < K2 * K2; ++k) w2[k] = rn_v2f_t{c2w_s[k], c2w_s[K2 * K2 + k]};
-      const rn_v2f_t b2 = {c2b_s[0], c2b_s[1]};
-      rn_v2f_t a2[D];
-#pragma unroll
-      for (int x = 0; x < D; ++x) a2[x] = b2;
-#define RR_ROW2(R, DY)                                                                                         \
-  _Pragma("unroll") for (int x = 0; x < D; ++x) {                                                              \
-    _Pragma("unroll") for (int dx = 0; dx < K2; ++dx) {                                                        \
-      const int xx = x + dx - 1;                                                                               \
-      if (xx >= 0 && xx < D) a2[x] = __builtin_elementwise_fma(rn_v2f_t{R[xx], R[xx]}, w2[(DY)*K2 + dx], a2[x]); \
-    }                                                                                                          \
-  }
-      RR_ROW2(c1, 1)
-      float t[D];
-#pragma unroll
-      for (int x = 0; x < D; ++x) t[x] = lane_below(c1[x]);
-      if (yv >= 1) { RR_ROW2(t, 0) }
-#pragma unroll
-      for (int x = 0; x < D; ++x) t[x] = lane_above(c1[x]);
-      if (yv + 1 < D) { RR_ROW2(t, 2) }
-#undef RR_ROW2
-      if (active) {
-#pragma unroll
-        for (int x = 0; x < D; ++x) arow[x] = make_float2(relu_f32(a2[x][0]), relu_f32(a2[x][1]));
-      }
-    }
-    // the next pass's actions: issued HERE, where the convolutions' registers are free again (a whole pass ahead the 21 registers
-    // pushed the kernel over its 256 and into scratch -- and every scratch reload waits for all loads in flight); the matrix phase
-    // and the tail (~2 us) cover their latency
-    fetch_group(g + gridDim.x);
-    // (raw barriers: a __syncthreads would also wait for the global loads of the next pass)
-    RR_STAMP(4)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the activation rows are complete
-    RR_STAMP(5)
-    // 4. FC3: this wave's k-slice of all samples of the block, C[sample 4 (lane / 16) + r][unit lane % 16]
-    const int64_t bt = bw + tjc;
-    const bool tvalid = tj < SPW && bt < a.B;
-    float u3 = 0.0f, u4a = 0.0f, u4b = 0.0f;
-    const int o0 = sub < n4 ? sub : n4 - 1, o1 = sub + 16 < n4 ? sub + 16 : n4 - 1;
-    float z0 = s_b4[o0], z1 = s_b4[o1];
-    {
-      rn_v4f_t acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const rn_v4f_t av = *reinterpret_cast<const rn_v4f_t*>(abase + 16 * p);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], wreg[4 * p], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], wreg[4 * p + 1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], wreg[4 * p + 2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], wreg[4 * p + 3], acc1, 0, 0, 0);
-      }
-      // In the shadow of the matrix pipe (its 4 NP instructions keep it busy for ~32 cycles each; the vector unit is free):
-      // the dropout uniforms of this wave's samples and the state part of FC4, neither of which needs FC3's output.
-      // (ONE basic block with the matrix instructions, no branches: slot < n3 draws FC3 unit `slot`, the others the FC4 units --
-      //  all of them when n3 + n4 <= 16; the scheduler is told to put vector instructions behind every matrix instruction)
-      const uint64_t traj = a.sample_offset + (uint64_t)bt;
-      uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
-      asm volatile("" : "+s"(k0), "+s"(k1));
-      const uint64_t key = ((uint64_t)k1 << 32) | k0;
-      if constexpr (DROP) {
-        const bool fc3 = sub < n3;
-        u3 = u01(philox_elem(key, (uint32_t)(fc3 ? sub : sub - n3), fc3 ? 3u : 4u, traj, 0).x);
-        xl[48 + sub] = u3;
-      }
-      {
-        const float* w40 = s_w4 + o0 * nin + n3;
-        const float* xs_ = xl + n3;
-#pragma unroll
-        for (int i = 0; i < D; ++i) z0 = fmaf(xs_[i], w40[i], z0);
-      }
-#pragma unroll
-      for (int i = 0; i < 4 * NP; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one matrix instruction
-        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);  // five vector instructions
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red_out[r * 16] = acc0[r] + acc1[r];
-      if (n4 > 16) {
-        const float* w41 = s_w4 + o1 * nin + n3;
-        const float* xs_ = xl + n3;
-#pragma unroll
-        for (int i = 0; i < D; ++i) z1 = fmaf(xs_[i], w41[i], z1);
-      }
-      if (DROP && !shared_u) {  // (more than 16 units: a draw per layer, FC4 units beyond 16 a third)
-        u3 = u01(philox_elem(key, (uint32_t)sub, 3u, traj, 0).x);
-        u4a = u01(philox_elem(key, (uint32_t)sub, 4u, traj, 0).x);
-        if (n4 > 16) u4b = u01(philox_elem(key, (uint32_t)(sub + 16), 4u, traj, 0).x);
-      }
-    }
-    RR_STAMP(6)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the partial products are complete; the activations are free
-    RR_STAMP(7)
-    // 5. tail, 16 lanes per sample: FC3 bias + ReLU (+ dropout) -> FC4 over [h3 | state] + ReLU (+ dropout) -> output unit
-    if (DROP && shared_u) u4a = xl[48 + ((n3 + sub) & 15)];  // (written before the barrier above)
-    {
-      float h = (red_in[0] + red_in[256]) + (red_in[512] + red_in[768]);
-      h = fmaxf(h + s_b3[sub < n3 ? sub : 0], 0.0f);
-      if (drop) h = (u3 <= a.keep_prob) ? h * inv_keep : 0.0f;
-      if (tj < SPW && sub < n3) xl[sub] = h;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the sample's input line [h3 | state] is complete (wave-local)
-    {  // the FC3 part of FC4's input (the state part was added in the shadow of the matrix instructions)
-      const float* w40 = s_w4 + o0 * nin;
-      const float* w41 = s_w4 + o1 * nin;
-      if (n4 <= 16) {
-        for (int i = 0; i < n3; ++i) z0 = fmaf(xl[i], w40[i], z0);
-      } else {
-        for (int i = 0; i < n3; ++i) {
-          z0 = fmaf(xl[i], w40[i], z0);
-          z1 = fmaf(xl[i], w41[i], z1);
-        }
-      }
-    }
-    float h40 = fmaxf(z0, 0.0f), h41 = fmaxf(z1, 0.0f);
-    if (drop) {
-      h40 = (u4a <= a.keep_prob) ? h40 * inv_keep : 0.0f;
-      h41 = (u4b <= a.keep_prob) ? h41 * inv_keep : 0.0f;
-    }
-    float z = (sub < n4 ? h40 * s_wo[o0] : 0.0f) + (sub + 16 < n4 ? h41 * s_wo[o1] : 0.0f);
-    z += dpp_mov_f32<0xB1, 0xF>(z);   // quad_perm [1,0,3,2]
-    z += dpp_mov_f32<0x4E, 0xF>(z);   // quad_perm [2,3,0,1]
-    z += dpp_mov_f32<0x141, 0xF>(z);  // row_half_mirror
-    z += dpp_mov_f32<0x140, 0xF>(z);  // row_mirror: every lane of the sample's 16 holds the sum
-    const float rwd = tanhf(z + s_bo[0]);
-    if (tvalid && sub == 0) a.reward[bt] = rwd;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    RR_STAMP(8)
-  }
-}
-
-template <int D>
-static bool rows_lds_attribute() {
-  static std::mutex attr_mu;
-  static signed char attr_state[64] = {0};   // 0 = not tried, 1 = ok, -1 = failed
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-  std::lock_guard<std::mutex> lock(attr_mu);
-  if (attr_state[dev] == 0) {
-    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_rows<D, false, false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reward_net_rows<D, false, true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-    attr_state[dev] = (e1 == hipSuccess && e2 == hipSuccess) ? 1 : -1;
-    (void)hipGetLastError();
-  }
-  return attr_state[dev] > 0;
-}
-
-#ifndef MFG_RN_ROWS
-#define MFG_RN_ROWS 1
-#endif
-// 0: launched; 1: not available here (the caller falls through to the strip-mapped kernels)
-template <int D>
-static int launch_reward_net_rows(const RewardNetArgs& a, hipStream_t st) {
-  using Gm = RowsGeom<D>;
-  if (!MFG_RN_ROWS || !rows_lds_attribute<D>()) return 1;
-  const size_t lds = Gm::lds_floats(a.n3, a.n4) * 4;
-  if (lds > 80 * 1024) return 1;
-  int64_t grid = (a.B + Gm::SPB - 1) / Gm::SPB;
-  if (grid > 512) grid = 512;  // two blocks per CU
-  if (a.keep_prob < 1.0f) hipLaunchKernelGGL((k_reward_net_rows<D, false, true>), dim3((unsigned)grid), dim3(RR_BLOCK), lds, st, a);
-  else hipLaunchKernelGGL((k_reward_net_rows<D, false, false>), dim3((unsigned)grid), dim3(RR_BLOCK), lds, st, a);
-  return 0;
-}
-
 // dynamic LDS above 64 KB needs the attribute, which applies to the CURRENT device: once per device, result kept -- a device
 // where it failed takes the run-mapped kernels
 template <int D, int RUN, int RPR, int P1>
@@ -1646,11 +1250,7 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
   const bool sums_ptrs = sums && sums->td_w && sums->state_next && sums->col_f && sums->g && sums->delta_out && sums->part_rows;
   const bool mfma_ok = mfma_shape_ok(d, k1, f2, k2, n3, fc3_w);
   bool mfma_done = false;
-  if (mfma_ok && !sums_ptrs) {
-    const int rc = d == 21 ? launch_reward_net_rows<21>(a, st) : launch_reward_net_rows<15>(a, st);
-    if (rc == 0) mfma_done = true;
-  }
-  if (mfma_ok && !mfma_done) {
+  if (mfma_ok) {
     int rows = 0;
     const int rc = d == 21 ? launch_reward_net_mfma<21, 7, 3, MFG_RM_P21>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st)
                            : launch_reward_net_mfma<15, 5, 3, MFG_RM_P15>(a, sums_ptrs, sums_ptrs ? sums->max_rows : 0, &rows, st);
