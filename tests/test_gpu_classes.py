@@ -504,6 +504,46 @@ def test_native_irl_episode_equals_python_step_loop(dev, d, B, precision, reg):
     assert runs[0][0][0] != 8.64
 
 
+@pytest.mark.parametrize('d,B,T,n3,precision', [(21, 300, 15, 8, 'mixed'), (21, 4096, 2, 8, 'mixed'), (21, 50, 1, 8, 'f64'),
+                                                (15, 130, 4, 16, 'mixed'), (21, 90, 3, 24, 'mixed'), (12, 40, 3, 8, 'mixed')])
+def test_irl_episode_with_drawn_start_states_equals_draw_then_episode(dev, d, B, T, n3, precision):
+    """mfg_train_episode_irl_draw (start states drawn inside the first step kernel of the two-launch flow; by a draw launch in the
+    three-launch flow: n_fc3 = 24 takes the run-mapped network kernel, d = 12 the generic one) == mfg_draw_start followed by
+    mfg_train_episode_irl, bit for bit: parameters, batch sums, return, final states, the last step's P / reward / delta / g.
+    Odd and even T (the ping-pong buffers end in pi_out without a copy), T = 1 (no step kernel with rows at all)."""
+    from discrete_mean_field_game_amd import ops
+    from discrete_mean_field_game_amd.networks import RewardNet
+    ops.init()
+    rs = np.random.RandomState(d * 1000 + B + T)
+    torch.manual_seed(d + B)
+    mat = torch.as_tensor(rs.dirichlet(np.ones(d), size=11).astype(np.float32), device=dev)
+    net = RewardNet(d=d, reg='dropout_l1l2', n_fc3=n3, n_fc4=8).to(dev)
+    F = ops.num_features(d)
+    w0 = rs.rand(F) * 0.1
+    outs = []
+    for draw_inside in (False, True):
+        th = torch.tensor([8.64], dtype=torch.float64, device=dev)
+        w = torch.as_tensor(w0.copy(), device=dev)
+        G = torch.zeros(F + 3, dtype=torch.float64, device=dev)
+        racc = torch.zeros(1, dtype=torch.float64, device=dev)
+        ws = ops.workspace(B, d, dev)
+        bufs = dict(ops.episode_buffers(B, d, dev), P=torch.empty(B, d, d, dtype=torch.float32, device=dev))
+        if draw_inside:
+            pi = torch.full((B, d), float('nan'), dtype=torch.float32, device=dev)
+            kw = dict(mat_pi0=mat)
+        else:
+            _, pi = ops.draw_start(mat, B, 7, 40, 5)
+            kw = {}
+        ops.train_episode_irl(pi, T, th, 0.1, 1e4, w, 0.95, 0.1, 0.001, net, G, ws, bufs, seed=7, first_step=40, traj_offset=5,
+                              rn_seed=99, rn_call0=3, rn_sample_offset=5, reward_acc=racc, precision=precision, **kw)
+        torch.cuda.synchronize()
+        outs.append([t.cpu().numpy().copy() for t in (th, w, G, racc, pi, bufs['P'], bufs['reward'], bufs['delta'], bufs['g'])])
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+    assert np.isfinite(outs[1][4]).all() and abs(outs[1][4].sum(axis=1) - 1).max() < 1e-5
+    assert outs[1][0][0] != 8.64 and outs[1][2][F + 2] == B
+
+
 def test_training_step_is_hip_graph_capturable(dev):
     """The C ABI launches on the caller's stream and never allocates or synchronises (after mfg_init), so a whole
     update (fused TD rollout + gradient kernels + parameter update) can be captured into a HIP graph and replayed;
