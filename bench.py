@@ -532,7 +532,10 @@ def other_configs(training_leg, native_leg, given_p_leg, d0, T0, B0, args):
             dt = _t.perf_counter() - t0
             out.append({'config': 'C4 AC_IRL.train (reward net in the loop), update per %s' % mode, 'd': 21, 'T': 15,
                         'batch': 4096, 'episodes': episodes, 'env_steps_per_s': 4096 * 15 * episodes / dt,
-                        'ms_per_episode': dt / episodes * 1e3})
+                        'ms_per_episode': dt / episodes * 1e3,
+                        'launches': ('2 per env step (step kernel carrying the previous step\'s row reduction | reward network + TD '
+                                     'error + batch sums) + 1 row reduction per episode: 31 per episode' if mode == 'step' else
+                                     '4 per episode (rollout | reward network | batch sums | row reduction + update)')})
     except Exception as exc:
         out.append({'config': 'C4', 'error': repr(exc)})
     # C4, the IRL experiment itself: AC_IRL.outerloop (ac_irl.py:900-954, what gridsearch.py:21-23 runs) = per iteration
