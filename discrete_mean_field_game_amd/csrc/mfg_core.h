@@ -64,13 +64,15 @@ struct CoreArgs {
   double* pend_reward_acc;
   // IRL env step (STEP variant of the packed kernel, mfg_train_episode_irl): the batch sums of the PREVIOUS env step are still
   // `step_nrows` partial rows [F+3] (left by the reward-network launch).  Every sampling wave adds up column F itself
-  // (rows_column_sum) and forms theta = updated_param(*theta, pend_lr_a, sum, 1 / step_count) -- the one parameter sampling
-  // needs; the last `red_blocks` blocks of the grid add up ALL columns (a wave per column) and publish the update:
+  // (rows_column_sum over the contiguous copy in front of the rows) and forms theta = updated_param(*theta, pend_lr_a, sum, 1 / B)
+  // -- the one parameter sampling needs; the grid's last core_step_red_blocks(F + 3) blocks add up ALL columns (a wave per
+  // column) and publish the update:
   // step_G[k], w_out[k] (in place: nobody reads the critic weights in this launch -- the TD error is formed in the
   // reward-network launch that follows), *theta_out (another slot than *theta), *pend_reward_acc.  The row reduction is off
   // the critical path: it runs under the sampling blocks instead of between two launches.
   // These arguments SHARE storage with arguments the variant never reads (step_nrows sits in the padding behind first_step,
-  // step_rows = pend_G, step_G = part_rows, the sample count is B, red_blocks follows from d): a longer argument block moves the
+  // step_rows = pend_G, step_G = part_rows, pi_start_out = P_in, the sample count is B, the number of reducing blocks follows from d):
+  // a longer argument block moves the
   // hidden launch arguments and, with them, the register allocation of every other instantiation of the kernel (measured on the
   // headline kernel: two more spilled registers).
 #ifdef MFG_TIMING
