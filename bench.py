@@ -212,11 +212,13 @@ def main():
         ac._force_collective = bool(args.force_dist)
         return ac
 
-    def training_leg(d, T, B, steps, warmup, precision='mixed', mode='rollout'):
+    def training_leg(d, T, B, steps, warmup, precision='mixed', mode='rollout', native_rccl=True):
         """`steps` timed episodes of actor_critic.train() (one update per episode in mode 'rollout', the reference's
-        per-step updates in mode 'step') with B trajectories PER RANK.  Returns (max-over-ranks seconds, theta at the end,
-        the class instance)."""
+        per-step updates in mode 'step') with B trajectories PER RANK.  native_rccl=False (several ranks): keep the exchange in
+        torch.distributed (one all-reduce per update issued from the class's Python loop) even where the library's own RCCL
+        loop passed its canary.  Returns (max-over-ranks seconds, theta at the end, the class instance)."""
         ac = make_class(d, T, B * world, mode, precision)
+        ac._use_native_rccl = bool(native_rccl)
         ac.train(num_episodes=warmup, gamma=gamma, constant=0, lr_critic=lr_c, lr_actor=lr_a, consecutive=10 ** 9)
         sync()
         t0 = time.perf_counter()
@@ -288,16 +290,20 @@ def main():
                 'achieved_GBs': N * bps / t_step / 1e9, 'frac': N * bps / t_step / 1e9 / HBM_PEAK_GBS,
                 'env_steps_per_s': N / t_step}
 
-    # clock ramp: ~30 ms of untimed streaming work on every CU before anything is measured (a cold device takes the first
-    # few launches to leave its idle power state; with a small --warmup the timed steps would otherwise pay for it).
-    # Not a step of the workload: the W warm-up steps below still run as asked.
-    _heat = torch.empty(64 * 1024 * 1024, device=dev).uniform_()
-    for _ in range(int(os.environ.get('MFG_BENCH_HEAT', '300'))):
-        _heat.mul_(1.0000001)
-    torch.cuda.synchronize()
-    del _heat
-
     d, T = args.d, args.T
+    # clock ramp: untimed launches of the WORKLOAD'S OWN kernels on every CU before anything is measured -- a separate instance of
+    # the drop-in class runs MFG_BENCH_HEAT (default 40) episodes of the headline shape (~40 ms at the default size; a cold
+    # device takes the first launches to leave its idle power state, and a streaming multiply in front of a VALU-bound kernel
+    # settles at another clock than the kernel itself).  Not a step of the workload: the W warm-up steps below still run as asked.
+    heat_eps = int(os.environ.get('MFG_BENCH_HEAT', '40'))
+    if heat_eps > 0:
+        Bh = args.batch // world if args.scaling == 'strong' else args.batch
+        _h = make_class(d, T, Bh * world)
+        _h._use_native_rccl = False          # (the heat-up must not depend on the native loop's canary having run)
+        _h.train(num_episodes=heat_eps, gamma=gamma, constant=0, lr_critic=lr_c, lr_actor=lr_a, consecutive=10 ** 9)
+        torch.cuda.synchronize()
+        del _h
+
     # ---- headline leg.  strong scaling (default): the GLOBAL batch --batch is split over the ranks; weak: --batch per GPU
     B = args.batch // world if args.scaling == 'strong' else args.batch
     elapsed, theta_end, ac = training_leg(d, T, B, args.steps, args.warmup)
@@ -305,6 +311,20 @@ def main():
     del ac
     other = None
     c5 = None
+    loops = None
+    if multi:
+        # both episode loops of the multi-GPU path in the same run: the headline above took the library's own RCCL loop
+        # (mfg_train_rollouts_dist: all episodes of the call issued natively, ncclAllReduce on the launch stream) if its canary
+        # passed on every rank, else the class's per-episode loop over torch.distributed; the other one is timed here
+        from discrete_mean_field_game_amd import parallel
+        native_on = bool(parallel.native_comm(None, dev, allow_single=True)) if args.backend == 'nccl' else False
+        et, _, ac = training_leg(d, T, B, args.steps, args.warmup, native_rccl=False)
+        del ac
+        loops = {'headline_loop': 'native_rccl' if native_on else 'torch_dist',
+                 'native_rccl_ms_per_update': (elapsed / args.steps * 1e3) if native_on else None,
+                 'torch_dist_ms_per_update': et / args.steps * 1e3,
+                 'torch_dist_value': world * B * T * args.steps / et,
+                 'canary': (dict(parallel.CANARY_LOG[-1]) if parallel.CANARY_LOG else None)}
     if world > 1:
         # the other scaling mode, same run (not the headline value)
         Bo = args.batch if args.scaling == 'strong' else args.batch // world
@@ -357,10 +377,10 @@ def main():
                       'world': world, 'payload_bytes': (Fc + 3) * 8, 'all_reduce_us': t_ar * 1e6,
                       'all_reduce_plus_apply_update_us': t_upd * 1e6,
                       'native_all_reduce_us': (t_nat * 1e6 if t_nat is not None else None),
-                      'note': 'the timed training legs exchange G through torch.distributed (one all-reduce per update, the update '
-                              'applied inside the next rollout kernel); MFG_NATIVE_RCCL=1 moves the exchange into the HIP library\'s '
-                              'own RCCL communicator (mfg_train_rollouts_dist, native episode loop) -- opt-in until a run with more '
-                              'than one rank has validated it; native_all_reduce_us is measured only then'}
+                      'note': 'the headline leg exchanges G through the HIP library\'s own RCCL communicator (mfg_train_rollouts_dist, '
+                              'native episode loop) when its canary passed on every rank (parallel.native_comm; `loops.canary`), '
+                              'else through torch.distributed (one all-reduce per update, the update applied inside the next rollout '
+                              'kernel); `loops` times both; native_all_reduce_us = ncclAllReduce of G issued by the library itself'}
 
     out = None
     if rank == 0:
@@ -443,6 +463,8 @@ def main():
         }
         if collective is not None:
             out['collective'] = collective
+        if loops is not None:
+            out['loops'] = loops
         if other is not None:
             out['other_scaling'] = other
         if c5 is not None:

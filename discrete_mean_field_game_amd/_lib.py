@@ -18,12 +18,13 @@ REWARD_MFG_AC2, REWARD_SYNTHETIC, REWARD_EXTERNAL = 0, 1, 2
 ROLLOUT_WRITE_P, ROLLOUT_TD, ROLLOUT_DISCOUNT_POW, ROLLOUT_F64, TRAIN_APPLY = 1, 2, 4, 8, 16
 PRECISION_F64, PRECISION_MIXED = 0, 1
 STATUS_MIXED_RANGE = 1
+ECOMM = -6                      # MFG_ECOMM: the call aborted its RCCL communicator, the handle is dead
 RN_TRAIN_MAX_TRAJ = 64          # MFG_RN_TRAIN_MAX_TRAJ
 PRECISIONS = {'f64': PRECISION_F64, 'mixed': PRECISION_MIXED, 0: 0, 1: 1}
 
 
 class MfgError(RuntimeError):
-    pass
+    code = 0                    # the negative MFG_E* code of the failed call (0 for errors raised on the Python side)
 
 
 def build(force: bool = False) -> str:
@@ -89,6 +90,7 @@ SIGNATURES = {
     'mfg_dist_unique_id': (_i32, [_p]),
     'mfg_dist_init': (_i32, [_p, _i32, _i32, C.POINTER(C.c_void_p)]),
     'mfg_dist_destroy': (_i32, [_p]),
+    'mfg_dist_abort': (_i32, [_p]),
     'mfg_dist_all_reduce': (_i32, [_p, _p, _i64, _p]),
     'mfg_train_rollouts_dist': (_i32, [_p, _p, _i64, _i64, _i32, _i32, _i64, _i64, _i32, _p, _p, _p, _p, _f64, _f64, _f64, _i32, _u64,
                                        _u32, _u64, _i32, _f64, _f64, _p, _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
@@ -150,4 +152,6 @@ def lib():
 
 def check(rc: int, what: str):
     if rc != 0:
-        raise MfgError('%s failed (%d): %s' % (what, rc, lib().mfg_last_error().decode()))
+        err = MfgError('%s failed (%d): %s' % (what, rc, lib().mfg_last_error().decode()))
+        err.code = int(rc)
+        raise err

@@ -130,7 +130,14 @@ class AC_IRL(actor_critic):
     @list_demonstrations.setter
     def list_demonstrations(self, trajs):
         self._demo_list = trajs
-        self._demo_store.assign_list(trajs)
+        # the reference flattens demonstrations of ANY length (ac_irl.py:816-821; only generated trajectories are reshaped to
+        # [M, 15]): a list with other lengths stays on the host and update_reward takes the autograd path for it
+        self._demo_ragged = any(len(tr) != EPISODE_STEPS for tr in trajs)
+        if self._demo_ragged:
+            self._demo_store.clear()
+        else:
+            self._demo_store.assign_list(trajs)
+        self._demo_ids = tuple(id(tr) for tr in trajs)
         self._eval_demo_override = None
 
     @property
@@ -145,17 +152,25 @@ class AC_IRL(actor_critic):
         if trajs is not self._gen_store._list or trajs is None:
             self._gen_store.assign_list(trajs if trajs is not None else [])
             self._gen_store._list = trajs if trajs else None       # keep the caller's objects as the list view
+        self._gen_ids = tuple(id(tr) for tr in trajs) if trajs else None
         self._eval_gen_override = None
 
     def _resync_stores(self):
-        """In-place edits of a list view (`ac.list_generated += more`, `.append`) change its LENGTH without passing the setter:
-        re-upload a view whose length no longer matches its store (edits that keep the length are not seen -- assign a list)."""
-        if len(self._demo_list) != len(self._demo_store):
-            self._demo_store.assign_list(self._demo_list)
+        """In-place edits of a list view do not pass the setter: `ac.list_generated += more`, `.append`, `list[i] = traj`.  A view
+        whose LENGTH or whose trajectory OBJECTS (ids: a cheap fingerprint, taken when the list was uploaded) no longer match
+        is uploaded again.  (Edits inside a trajectory -- replacing one (pi, P) pair, writing into an array -- are not seen:
+        assign the list.)"""
+        ids = tuple(id(tr) for tr in self._demo_list)
+        if ids != getattr(self, '_demo_ids', ids) or (not getattr(self, '_demo_ragged', False)
+                                                      and len(self._demo_list) != len(self._demo_store)):
+            self.list_demonstrations = self._demo_list
         view = self._gen_store._list
-        if view is not None and len(view) != len(self._gen_store):
-            self._gen_store.assign_list(view)
-            self._gen_store._list = view
+        if view is not None:
+            ids = tuple(id(tr) for tr in view)
+            if len(view) != len(self._gen_store) or (getattr(self, '_gen_ids', None) is not None and ids != self._gen_ids):
+                self._gen_store.assign_list(view)
+                self._gen_store._list = view
+                self._gen_ids = ids
 
     def _is_all_pairs(self, pairs, store, trajs):
         """True if `pairs` is the flattened view [pair for traj in trajs for pair in traj] of the store's current list."""
@@ -530,8 +545,13 @@ class AC_IRL(actor_critic):
         self._gen_traj_counter = int(state['gen_traj_counter'])
         self.theta_initial = state.get('theta_initial', self.theta_initial)
         self._reward_calls = int(state.get('reward_calls', 0))
-        if self._trainer is not None and state.get('reward_trainer'):
-            self._trainer.load_state_dict(state['reward_trainer'])
+        if self._trainer is not None:
+            if state.get('reward_trainer'):
+                self._trainer.load_state_dict(state['reward_trainer'])
+            else:
+                # a checkpoint from before the HIP training step (round <= 4): its Adam state lives in the torch optimiser
+                # only -- take the moments and the step count from there (same parameter order as the flat buffer)
+                self._trainer.seed_from_torch_adam(self.optimizer, list(self.reward_net.parameters()))
         self._reward_train_calls = int(state.get('reward_train_calls', 0))
         self._stats_host = None
         if 'list_generated_pi' in state:
@@ -579,7 +599,8 @@ class AC_IRL(actor_critic):
         the same trajectories are chosen and the host stream advances identically -- and the update itself is
         mfg_reward_net_train_step on the device stores: two launches, nothing copied, no synchronisation."""
         self._resync_stores()
-        nd_all, ng_all = len(self._demo_store), len(self._gen_store)
+        ragged = getattr(self, '_demo_ragged', False)
+        nd_all, ng_all = (len(self._demo_list) if ragged else len(self._demo_store)), len(self._gen_store)
         if nd_all >= self.num_demo_samples:
             demo_idx = random.sample(range(nd_all), self.num_demo_samples)
         else:
@@ -591,7 +612,8 @@ class AC_IRL(actor_critic):
         self._reward_train_calls += 1
         n_tr = (len(demo_idx) + len(gen_idx)) * EPISODE_STEPS
         fits = n_tr <= 2048 and n_tr * (1 + self.n_fc3) * 4 <= 60 * 1024            # limits of mfg_reward_net_train_step's combine kernel
-        if self._trainer is not None and fits and len(demo_idx) <= L.RN_TRAIN_MAX_TRAJ and len(gen_idx) <= L.RN_TRAIN_MAX_TRAJ:
+        if (self._trainer is not None and fits and not ragged and len(demo_idx) <= L.RN_TRAIN_MAX_TRAJ
+                and len(gen_idx) <= L.RN_TRAIN_MAX_TRAJ):
             key = ((self.seed + 0x7EA1) ^ (self._reward_train_calls * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
             dist = torch.distributed
             multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
@@ -619,7 +641,22 @@ class AC_IRL(actor_critic):
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self._all_reduce_reward_grads()
-        self.optimizer.step()
+        if self._trainer is not None:
+            # ONE optimiser state: a batch outside the HIP training step's range (more than 2 048 transitions, ragged
+            # demonstrations) still steps the trainer's Adam moments and step count (mfg_reward_net_adam, tf.train.AdamOptimizer's
+            # formula) -- the torch optimiser would keep moments and a bias-correction step of its own
+            tr = self._trainer
+            off = 0
+            for prm in self.reward_net.parameters():
+                n = prm.numel()
+                if prm.grad is None:
+                    tr.grad[off:off + n].zero_()
+                else:
+                    tr.grad[off:off + n].copy_(prm.grad.reshape(-1))
+                off += n
+            tr.apply_grad()
+        else:
+            self.optimizer.step()
         self.loss_val = float(loss.detach().cpu())
         self.first_term_val = float(first.detach().cpu())
         self.second_term_val = float(second.detach().cpu())
@@ -647,6 +684,10 @@ class AC_IRL(actor_critic):
         its own list of pairs (e.g. get_eval_transitions)."""
         if override is not None:
             return self._pairs_to_tensors(override)
+        if store is self._demo_store and getattr(self, '_demo_ragged', False):       # host-resident demonstrations
+            pairs = [pair for traj in self._demo_list for pair in traj]
+            if pairs:
+                return self._pairs_to_tensors(pairs)
         return store.gather_flat()
 
     def _eval_reward_averages(self):

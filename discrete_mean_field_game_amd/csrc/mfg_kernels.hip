@@ -19,6 +19,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <unordered_map>
 
 #include "../../include/mfg_hip.h"
 #include "mfg_core.h"
@@ -2427,7 +2428,33 @@ struct mfg_ctx {
   StatusWord sw;
   void* comm = nullptr;  // adopted RCCL communicator (mfg_ctx_adopt_comm), destroyed with the context
 };
+// The binding is per THREAD, the object's lifetime is not: a context may be destroyed by another thread than the one(s) it is
+// bound on (a garbage collector drops the last reference wherever it runs).  Every live context is therefore registered with
+// a generation id, a thread's binding remembers (pointer, generation), and a destroy bumps a global epoch: the next entry
+// point of a thread that finds the epoch moved re-validates its binding under the registry lock and, if its context is gone
+// (or the address now belongs to a younger one), falls back to the device's default word instead of touching freed memory.
+// The hot path (no destroy since the last look) is one relaxed-cost atomic load.
 static thread_local mfg_ctx* g_ctx = nullptr;
+static thread_local uint64_t g_ctx_gen = 0, g_ctx_seen_epoch = 0;
+static std::mutex g_ctx_mu;
+static std::unordered_map<mfg_ctx*, uint64_t> g_ctx_live;  // live contexts -> generation id (under g_ctx_mu)
+static uint64_t g_ctx_next_gen = 1;                          // (under g_ctx_mu)
+static std::atomic<uint64_t> g_ctx_epoch{1};                 // bumped by every mfg_ctx_destroy
+static bool ctx_is_live(mfg_ctx* c) {
+  std::lock_guard<std::mutex> lock(g_ctx_mu);
+  return g_ctx_live.find(c) != g_ctx_live.end();
+}
+// the calling thread's bound context; NULL if none, or if it has been destroyed (by any thread) since it was bound
+static mfg_ctx* bound_ctx() {
+  if (!g_ctx) return nullptr;
+  if (g_ctx_epoch.load(std::memory_order_acquire) != g_ctx_seen_epoch) {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    const auto it = g_ctx_live.find(g_ctx);
+    if (it == g_ctx_live.end() || it->second != g_ctx_gen) g_ctx = nullptr;
+    g_ctx_seen_epoch = g_ctx_epoch.load(std::memory_order_acquire);
+  }
+  return g_ctx;
+}
 extern "C" int mfg_dist_destroy(void* comm);
 static bool alloc_status_word(StatusWord* out) {
   void* h = nullptr;
@@ -2447,7 +2474,7 @@ static StatusWord status_word() {
   static StatusWord sw[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return StatusWord{};
-  if (g_ctx) return g_ctx->device == dev ? g_ctx->sw : StatusWord{};  // (a context of another device: refused by the callers)
+  if (mfg_ctx* c = bound_ctx()) return c->device == dev ? c->sw : StatusWord{};  // (a context of another device: refused by the callers)
   std::lock_guard<std::mutex> lock(mu);
   if (!sw[dev].host && !alloc_status_word(&sw[dev])) return StatusWord{};
   return sw[dev];
@@ -2537,7 +2564,7 @@ static int reduce_core_sums(int d, int64_t B, double* G, int accumulate, void* w
 extern "C" {
 
 const char* mfg_last_error(void) { return g_err; }
-int mfg_abi_version(void) { return 16; }
+int mfg_abi_version(void) { return 17; }
 
 int mfg_init(void) {
   if (!htab_ptr()) return fail(MFG_ELAUNCH, "%s", "mfg_init: no HIP device / table initialisation failed");
@@ -2572,12 +2599,23 @@ int mfg_ctx_create(mfg_ctx_t** ctx_out) {
     delete c;
     return fail(MFG_ELAUNCH, "%s", "mfg_ctx_create: status word allocation failed");
   }
+  {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    g_ctx_live[c] = g_ctx_next_gen++;
+  }
   *ctx_out = c;
   return MFG_OK;
 }
 
 int mfg_ctx_destroy(mfg_ctx_t* ctx) {
   if (!ctx) return MFG_OK;
+  {
+    // out of the registry first, then the epoch: a thread that still has it bound (this one or any other) drops the binding
+    // at its next entry point (bound_ctx) instead of dereferencing the freed object
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    if (g_ctx_live.erase(ctx) == 0) return fail(MFG_EINVAL, "%s", "mfg_ctx_destroy: not a live context (destroyed twice?)");
+    g_ctx_epoch.fetch_add(1, std::memory_order_release);
+  }
   if (g_ctx == ctx) g_ctx = nullptr;
   int rc = MFG_OK;
   if (ctx->comm) rc = mfg_dist_destroy(ctx->comm);
@@ -2587,37 +2625,47 @@ int mfg_ctx_destroy(mfg_ctx_t* ctx) {
 }
 
 int mfg_ctx_bind(mfg_ctx_t* ctx) {
+  uint64_t gen = 0, epoch = 0;
   if (ctx) {
+    {
+      std::lock_guard<std::mutex> lock(g_ctx_mu);
+      const auto it = g_ctx_live.find(ctx);
+      if (it == g_ctx_live.end()) return fail(MFG_EINVAL, "%s", "mfg_ctx_bind: not a live context (already destroyed?)");
+      gen = it->second;
+      epoch = g_ctx_epoch.load(std::memory_order_acquire);
+    }
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev != ctx->device)
       return fail(MFG_EINVAL, "mfg_ctx_bind: the context belongs to device %d, the current device is %d", ctx->device, dev);
   }
   g_ctx = ctx;
+  g_ctx_gen = gen;
+  g_ctx_seen_epoch = epoch;
   return MFG_OK;
 }
 
-mfg_ctx_t* mfg_ctx_current(void) { return g_ctx; }
+mfg_ctx_t* mfg_ctx_current(void) { return bound_ctx(); }
 
 int mfg_ctx_status(mfg_ctx_t* ctx, unsigned* bits_host) {
-  REQUIRE(ctx && ctx->sw.host, "null context");
+  REQUIRE(ctx && ctx_is_live(ctx) && ctx->sw.host, "null or destroyed context");
   const unsigned bits = *(volatile unsigned*)ctx->sw.host;
   if (bits_host) *bits_host = bits;
   return bits ? status_error(bits) : MFG_OK;
 }
 
 int mfg_ctx_clear_status(mfg_ctx_t* ctx) {
-  REQUIRE(ctx && ctx->sw.host, "null context");
+  REQUIRE(ctx && ctx_is_live(ctx) && ctx->sw.host, "null or destroyed context");
   *(volatile unsigned*)ctx->sw.host = 0u;
   return MFG_OK;
 }
 
 int mfg_ctx_adopt_comm(mfg_ctx_t* ctx, void* comm) {
-  REQUIRE(ctx, "null context");
+  REQUIRE(ctx && ctx_is_live(ctx), "null or destroyed context");
   ctx->comm = comm;
   return MFG_OK;
 }
 
-void* mfg_ctx_comm(mfg_ctx_t* ctx) { return ctx ? ctx->comm : nullptr; }
+void* mfg_ctx_comm(mfg_ctx_t* ctx) { return (ctx && ctx_is_live(ctx)) ? ctx->comm : nullptr; }
 
 int mfg_device_info(int* cu_count_host, char* arch_host, int arch_len) {
   int dev = 0;
@@ -3330,6 +3378,14 @@ int mfg_dist_destroy(void* comm) {
   return rc == 0 ? MFG_OK : rccl_fail("ncclCommDestroy", rc);
 }
 
+int mfg_dist_abort(void* comm) {
+  if (!comm) return MFG_OK;
+  const RcclApi& r = rccl();
+  if (!r.ok || !r.CommAbort) return fail(MFG_EUNSUPPORTED, "%s", "ncclCommAbort is not available in this process");
+  const int rc = r.CommAbort(comm);
+  return rc == 0 ? MFG_OK : rccl_fail("ncclCommAbort", rc);
+}
+
 int mfg_dist_all_reduce(void* comm, double* G, int64_t n, mfg_stream_t stream) {
   REQUIRE(comm && G && n >= 1, "bad arguments");
   const RcclApi& r = rccl();
@@ -3378,7 +3434,11 @@ int mfg_train_rollouts_dist(void* comm, const float* mat_pi0, int64_t num_start,
                                 first_step + (uint32_t)(k * T), traj_offset, flags, 0.0, 0.0, pi_traj, pi_last, reward, delta, g, G,
                                 nullptr, workspace, workspace_bytes, st, pending ? &du : nullptr);
     if (rc != MFG_OK) {
-      if (r.CommAbort) (void)r.CommAbort(comm);   // (the communicator is unusable afterwards: the caller drops it)
+      // (the communicator is dead afterwards: MFG_ECOMM tells the caller to forget the handle; mfg_last_error keeps the cause)
+      if (r.CommAbort) {
+        (void)r.CommAbort(comm);
+        return MFG_ECOMM;
+      }
       return rc;
     }
     if (pending) {  // the rollout left the updated parameters in the other set
@@ -3387,8 +3447,12 @@ int mfg_train_rollouts_dist(void* comm, const float* mat_pi0, int64_t num_start,
     }
     rc = r.AllReduce(G, G, (size_t)(F + 3), RCCL_FLOAT64, RCCL_SUM, comm, st);   // the ONE exchange of the update
     if (rc != 0) {
-      if (r.CommAbort) (void)r.CommAbort(comm);
-      return rccl_fail("ncclAllReduce", rc);
+      (void)rccl_fail("ncclAllReduce", rc);
+      if (r.CommAbort) {
+        (void)r.CommAbort(comm);
+        return MFG_ECOMM;
+      }
+      return MFG_ELAUNCH;
     }
     double sc, sa;
     lr_schedule(first_episode + k, constant, &sc, &sa);

@@ -38,7 +38,6 @@ constexpr int RT_BLOCK = 256, RT_WAVES = RT_BLOCK / WAVE;
 constexpr int RT_MAX_TRAJ = MFG_RN_TRAIN_MAX_TRAJ;  // per batch half (demonstrations / generated)
 constexpr int RT_MAXN = 32;                          // n3, n4
 constexpr int RT_PP = 4;                             // pixels per thread, d <= 32
-constexpr int RT_QA = 8;                             // fc3 inputs per thread, f2 d^2 <= 2048
 constexpr int RT_KC = 8;                             // fc3 units whose weight columns a thread holds in registers
 
 struct RtLayout {

@@ -34,7 +34,8 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .parallel import all_reduce_gradients_, broadcast_start_indices, current_shard, lr_scales, native_comm
+from .parallel import (all_reduce_gradients_, broadcast_start_indices, current_shard, forget_native_comm, lr_scales,
+                       native_comm)
 
 EPISODE_STEPS = 15  # mfg_ac2.py:478
 
@@ -45,13 +46,18 @@ def _as_np(x):
 
 def _with_ctx(method):
     """Public methods that reach the HIP library run with the instance's own context bound (ops.Context: its status word),
-    so that two instances on one device cannot stop each other (include/mfg_hip.h, mfg_ctx_bind)."""
+    so that two instances on one device cannot stop each other (include/mfg_hip.h, mfg_ctx_bind).  The binding the calling
+    thread had before is restored on the way out: free-function ops.* calls and other instances' unbound reads made afterwards
+    do not report into whichever instance happened to run last."""
     import functools
 
     @functools.wraps(method)
     def bound(self, *args, **kwargs):
-        self._ctx.bind()
-        return method(self, *args, **kwargs)
+        prev = self._ctx.bind_scoped()
+        try:
+            return method(self, *args, **kwargs)
+        finally:
+            self._ctx.restore(prev)
     return bound
 
 
@@ -69,7 +75,8 @@ class actor_critic:
         L.lib()
         ops.init()
         self.device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
-        self._ctx = ops.Context(self.device).bind()      # this instance's library state (status word), bound by its methods
+        self._ctx = ops.Context(self.device)             # this instance's library state (status word), bound by its methods
+        self._ctx_prev = self._ctx.bind_scoped()         # ... and for the rest of the constructor (_end_init restores)
         self.shift = shift
         self.alpha_scale = alpha_scale
         self.d = d
@@ -93,6 +100,7 @@ class actor_critic:
             raise ValueError('episode_steps must be >= 1')
         self._train_bufs = {}      # device buffers of train(), kept between calls (keyed by shape)
         self._force_collective = False   # debug (bench.py --force-dist): take the multi-rank update path with one rank
+        self._use_native_rccl = True     # bench.py sets it to False to time the torch.distributed per-episode loop as well
         self._pending = None             # multi-rank rollout mode: (G, lr_critic, lr_actor, reward_acc) of an update not applied yet
         self._w_alt = self._theta_alt = None
         # several GPUs over RCCL: a communicator owned by the HIP library, so that train() issues the one all-reduce per update
@@ -120,6 +128,8 @@ class actor_critic:
         self._theta_at_sample = self._theta.clone()   # theta the last sample_action ran with (mat_alpha attributes)
         self._rng_step = 0         # Philox step counter (advances once per env step)
         self.trace = None          # set to [] to record theta after every update (parity tests)
+        # hand the thread's previous context binding back (the subclasses' constructors launch nothing that reports)
+        self._ctx.restore(self.__dict__.pop('_ctx_prev', ops.Context.KEEP))
 
     # ------------------------------------------------------------------ state on the device
     @property
@@ -141,6 +151,10 @@ class actor_critic:
 
     @w.setter
     def w(self, value):
+        # a multi-rank rollout-mode update may still be pending (its increment belongs to the OLD weights): apply it before
+        # the assignment replaces them, like the theta setter -- otherwise the next flush would add it onto the new values
+        if getattr(self, '_pending', None) is not None:
+            self._flush_pending()
         v = np.ascontiguousarray(np.asarray(value, dtype=np.float64).reshape(-1))
         self._w = torch.as_tensor(v, device=self.device)
 
@@ -359,8 +373,43 @@ class actor_critic:
         g = g.cpu().numpy()
         return float(g[0]) if single else g
 
-    calc_gradient = calc_gradient_vectorized
-    calc_gradient_basic = calc_gradient_vectorized
+    def _gradient_inputs(self, P, pi):
+        """(alpha, alpha', ln P) as fp64 device tensors [B,d,d] for the two loop-form score variants below: mfg_alpha for
+        the concentrations of the LAST sample_action state (the reference's hidden mat_alpha / mat_alpha_deriv), the
+        stored probabilities widened from the fp32 the device holds; zeros of P -> 1e-100 like calc_gradient_vectorized
+        (the loop forms of the reference do not floor them and would return -inf)."""
+        pi_dev, single = self._pi_dev(pi)
+        pa = self._pi_alpha if (self._pi_alpha is not None and self._pi_alpha.shape == pi_dev.shape) else pi_dev
+        a, ad = ops.alpha(pa, self._theta, self.shift)
+        Pd = self._P_dev(P).double()
+        lnP = torch.log(torch.where(Pd == 0, torch.full_like(Pd, 1e-100), Pd))
+        return a, ad, lnP, single
+
+    def _gradient_out(self, g, pi, single):
+        if isinstance(pi, torch.Tensor):
+            return g[0] if single else g
+        g = g.cpu().numpy()
+        return float(g[0]) if single else g
+
+    @_with_ctx
+    def calc_gradient_basic(self, P, pi):
+        """The reference's first loop form (mfg_ac2.py:384-400): per row i THREE separate sums, added in this order --
+        -sum_j psi(alpha_ij) alpha'_ij, then psi(sum_j alpha_ij) sum_j alpha'_ij, then sum_j ln(P_ij) alpha'_ij.
+        An evaluation path of its OWN (mfg_alpha + torch.special.digamma + log on the device, fp64; no score kernel), so
+        that the reference's three-way self-check (test2.py:105-121) compares independent computations here too."""
+        a, ad, lnP, single = self._gradient_inputs(P, pi)
+        t1 = -(torch.special.digamma(a) * ad).sum(-1)
+        t2 = torch.special.digamma(a.sum(-1)) * ad.sum(-1)
+        t3 = (lnP * ad).sum(-1)
+        return self._gradient_out(((t1 + t2) + t3).sum(-1), pi, single)
+
+    @_with_ctx
+    def calc_gradient(self, P, pi):
+        """The reference's second loop form (mfg_ac2.py:402-438): per element (-psi(alpha_ij) + psi(sum_j alpha_ij) +
+        ln P_ij) alpha'_ij, summed over the matrix.  Its own device evaluation like calc_gradient_basic."""
+        a, ad, lnP, single = self._gradient_inputs(P, pi)
+        mult = torch.special.digamma(a.sum(-1, keepdim=True))
+        return self._gradient_out((((-torch.special.digamma(a) + mult) + lnP) * ad).sum((-2, -1)), pi, single)
 
     # ------------------------------------------------------------------ logging (mfg_ac2.py:441-445)
     def train_log(self, vector, filename, str_format):
@@ -416,7 +465,14 @@ class actor_critic:
         G, ws = bufs['G'], bufs['ws']
         # mean reward per update, one entry per episode (step mode: summed over the episode's T updates = the mean episode
         # return; rollout mode: the mean over the B*T transitions of the one update, times T below)
-        ep_reward = torch.zeros(max(num_episodes, 1), dtype=torch.float64, device=self.device)
+        # (kept per instance and re-zeroed: a fresh allocation per call is host time in front of the first launch; an update an
+        #  unwound call left pending books its reward into this buffer: apply it before the entries are reset)
+        self._flush_pending()
+        ep_reward = bufs.get('ep_reward')
+        if ep_reward is None or ep_reward.numel() < max(num_episodes, 1):
+            ep_reward = bufs['ep_reward'] = torch.zeros(max(num_episodes, 1), dtype=torch.float64, device=self.device)
+        else:
+            ep_reward.zero_()
         ep_base = ep_reward.data_ptr()
         # a pending multi-rank update (self._pending) carries a raw address into ep_reward: the tensor must outlive this call
         # if train() unwinds with the update still pending (flushed later by a read of theta / w / state_dict)
@@ -451,8 +507,8 @@ class actor_critic:
         # several GPUs, one update per episode: the same native loop with the all-reduce issued by the library (RCCL)
         dist_comm = None
         if multi and fused_rollout and device_draw and self.trace is None and not write_all and not self.check_finite:
-            dist_comm = self._dist_comm
-            if dist_comm is None and self._force_collective:      # debug (one rank): made on first use
+            dist_comm = self._dist_comm if self._use_native_rccl else None
+            if dist_comm is None and self._force_collective and self._use_native_rccl:      # debug (one rank): made on first use
                 dist_comm = native_comm(self.group, self.device, allow_single=True)
             if dist_comm is not None and (self._w_alt is None or self._w_alt.shape != self._w.shape):
                 self._w_alt, self._theta_alt = torch.empty_like(self._w), torch.empty_like(self._theta)
@@ -463,21 +519,33 @@ class actor_critic:
         # reports (every `consecutive` episodes): in the native loop their values are read back behind the NEXT chunk of
         # episodes; a subclass hook that reads the live parameters (mfg_synthetic logs w) keeps the immediate form
         defer_reports = (native_loop or dist_comm is not None) and type(self)._train_log_extra is actor_critic._train_log_extra
+        # nobody consumes the reports (nothing printed, nothing logged): no snapshot, no copy, no event, no pinned buffer --
+        # and the native loops need not stop at the reporting episodes: ONE native call issues the whole train() call
+        silent = not self.verbose and not write_file
         report = None
         episode = 0
         while episode < num_episodes:
             if native_loop or dist_comm is not None:
                 # episodes episode .. last, `last` = the next reporting episode (episode % consecutive == 0) or the final one
                 last = episode if episode % consecutive == 0 else (episode // consecutive + 1) * consecutive
-                last = min(last, num_episodes - 1)
+                last = num_episodes - 1 if silent else min(last, num_episodes - 1)
                 k = last - episode + 1
                 if dist_comm is not None:
                     self._flush_pending()
-                    ops.train_rollouts_dist(dist_comm, self._mat_pi0_dev, T, k, episode + first_episode, constant == 1, self._theta,
-                                            self._w, self._theta_alt, self._w_alt, self.shift, self.alpha_scale, gamma, G, ws, rbufs,
-                                            lr_critic, lr_actor, reward_kind=self.reward_kind, seed=self.seed,
-                                            first_step=self._rng_step, traj_offset=shard.traj_offset,
-                                            reward_acc=ep_base + 8 * episode, precision=self.precision)
+                    try:
+                        ops.train_rollouts_dist(dist_comm, self._mat_pi0_dev, T, k, episode + first_episode, constant == 1,
+                                                self._theta, self._w, self._theta_alt, self._w_alt, self.shift, self.alpha_scale,
+                                                gamma, G, ws, rbufs, lr_critic, lr_actor, reward_kind=self.reward_kind,
+                                                seed=self.seed, first_step=self._rng_step, traj_offset=shard.traj_offset,
+                                                reward_acc=ep_base + 8 * episode, precision=self.precision)
+                    except L.MfgError as exc:
+                        if exc.code == L.ECOMM:
+                            # the library aborted its communicator inside the call (a launch or collective failed): the handle
+                            # is dead -- forget it everywhere, so that a later train() falls back to torch.distributed instead
+                            # of calling into freed memory
+                            forget_native_comm(dist_comm)
+                            self._dist_comm = None
+                        raise
                     pi = rbufs['pi_last']
                 elif fused_rollout:
                     ops.train_rollouts(self._mat_pi0_dev, T, k, episode + first_episode, constant == 1, self._theta, self.shift,
@@ -509,7 +577,7 @@ class actor_critic:
                 # waiting for them does not drain the launch stream (the GPU keeps working on that chunk meanwhile)
                 self._emit_report(report, consecutive, write_file, file_theta, file_pi, file_reward)
                 report = None
-            if episode % consecutive == 0:
+            if episode % consecutive == 0 and not silent:
                 # the reference divides the sum over the window by `consecutive` even at episode 0 (:530-534)
                 report = self._snapshot_report(ep_reward, window_start, episode, pi, ret_scale)
                 window_start = episode + 1
@@ -525,7 +593,14 @@ class actor_critic:
     def _snapshot_report(self, ep_reward, window_start, episode, pi, ret_scale):
         """Values of a report (theta, the first trajectory's state, the window's reward sum) copied to pinned host memory
         without waiting: device-side snapshots, non-blocking copies, one event."""
-        host = torch.empty(self.d + 2, dtype=torch.float64, pin_memory=True)
+        # two pinned buffers per instance, used in turn (a deferred report is still unread when the next one is taken);
+        # allocating pinned memory per report costs a hipHostMalloc each time
+        pool = self.__dict__.setdefault('_report_host', [None, None, 0])
+        slot = pool[2] & 1
+        pool[2] += 1
+        if pool[slot] is None or pool[slot].numel() != self.d + 2:
+            pool[slot] = torch.empty(self.d + 2, dtype=torch.float64, pin_memory=True)
+        host = pool[slot]
         dev = torch.cat([self._theta, ep_reward[window_start:episode + 1].sum().reshape(1) * ret_scale, pi[0].double()])
         host.copy_(dev, non_blocking=True)
         ev = torch.cuda.Event()
@@ -553,7 +628,11 @@ class actor_critic:
         theta / w on the host, and after the last episode."""
         if self._pending is not None:
             G, lc, la, racc = self._pending
-            ops.apply_update(G, self.d, lc, la, self._w, self._theta, racc)
+            prev = self._ctx.bind_scoped()          # (reached from the unbound property reads of theta / w too)
+            try:
+                ops.apply_update(G, self.d, lc, la, self._w, self._theta, racc)
+            finally:
+                self._ctx.restore(prev)
             self._pending = None
 
     def _train_one_episode(self, episode, shard, device_draw, native_episode, fused_rollout, G, ws, ebufs, rbufs, reward_acc,

@@ -81,6 +81,29 @@ class Context:
     def unbind():
         L.check(L.lib().mfg_ctx_bind(None), 'mfg_ctx_bind')
 
+    KEEP = object()        # bind_scoped(): this context was bound already, restore() has nothing to do
+
+    def bind_scoped(self):
+        """bind() that returns what restore() needs to put the calling thread's previous binding back: KEEP if this context
+        was current already (nested public methods: one ctypes call), else the previous context's address (None = the
+        device's default context)."""
+        prev = L.lib().mfg_ctx_current()
+        if prev == self._ptr:
+            return Context.KEEP
+        with torch.cuda.device(self.device):
+            L.check(L.lib().mfg_ctx_bind(self._ptr), 'mfg_ctx_bind')
+        return prev
+
+    @staticmethod
+    def restore(prev):
+        if prev is Context.KEEP:
+            return
+        lib = L.lib()
+        # (the previous context may have been destroyed meanwhile, or belong to another device than the current one: then the
+        #  thread goes back to the default context -- never to a stale pointer)
+        if prev is None or lib.mfg_ctx_bind(prev) != 0:
+            lib.mfg_ctx_bind(None)
+
     def status(self, synchronize=True) -> int:
         import ctypes as C
         if synchronize:

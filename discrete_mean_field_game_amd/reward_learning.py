@@ -190,9 +190,32 @@ class RewardTrainer:
                                             _stream()), 'mfg_reward_net_adam')
 
     def state_dict(self):
-        return {'m': self.m.detach().cpu().clone(), 'v': self.v.detach().cpu().clone(), 'step': int(self.step_count)}
+        return {'m': self.m.detach().cpu().clone(), 'v': self.v.detach().cpu().clone(), 'step': int(self.step_count),
+                'stats': self.stats.detach().cpu().clone()}        # (loss / first / second term of the last update)
 
     def load_state_dict(self, st):
         self.m.copy_(st['m'].to(self.device))
         self.v.copy_(st['v'].to(self.device))
         self.step_count = int(st['step'])
+        if st.get('stats') is not None:
+            self.stats.copy_(st['stats'].to(self.device))
+
+    def seed_from_torch_adam(self, optimizer, params):
+        """Moments and step count from a torch.optim.Adam state over `params` (the module's parameters, in the flat buffer's
+        order): checkpoints written before the HIP training step existed carry only that.  Parameters the optimiser never
+        stepped keep zero moments; warns if there is nothing to take."""
+        import warnings
+        off, steps = 0, 0
+        self.m.zero_(); self.v.zero_()
+        for p in params:
+            n = p.numel()
+            st = optimizer.state.get(p)
+            if st:
+                self.m[off:off + n].copy_(st['exp_avg'].reshape(-1))
+                self.v[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+                steps = max(steps, int(st['step']))
+            off += n
+        self.step_count = steps
+        if steps == 0:
+            warnings.warn('checkpoint carries no reward-trainer state and an empty optimiser state: the resumed reward '
+                          'learning starts with zero Adam moments', RuntimeWarning, stacklevel=3)

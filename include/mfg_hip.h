@@ -39,7 +39,10 @@ enum {
   MFG_ELAUNCH = -2,      /* HIP reported a launch/runtime error */
   MFG_EUNSUPPORTED = -3, /* shape outside the supported range (d > MFG_MAX_D) */
   MFG_EWORKSPACE = -4,   /* workspace too small */
-  MFG_ERANGE = -5        /* an earlier launch reported a numeric-range condition (mfg_status); sticky until cleared */
+  MFG_ERANGE = -5,       /* an earlier launch reported a numeric-range condition (mfg_status); sticky until cleared */
+  MFG_ECOMM = -6         /* mfg_train_rollouts_dist: a launch / collective failed inside the episode loop and the RCCL communicator
+                            has been ABORTED (ncclCommAbort, so that the peers fail instead of waiting): the handle is dead -- forget
+                            it, do not destroy or use it again */
 };
 
 #define MFG_MAX_D 512
@@ -271,14 +274,18 @@ int mfg_train_rollout_deferred(const float* mat_pi0, int64_t num_start, const in
  *   mfg_dist_unique_id : ncclGetUniqueId on ONE rank; ship the 128 bytes to the others (e.g. torch.distributed.broadcast)
  *   mfg_dist_init      : ncclCommInitRank on EVERY rank (collective; the current device is the rank's GPU)
  *   mfg_dist_all_reduce: in-place SUM of n doubles (the exchange of a per-step update; test hook)
+ *   mfg_dist_abort     : ncclCommAbort -- frees the communicator WITHOUT the collective hand-shake of mfg_dist_destroy (a rank
+ *                        whose peers failed or timed out during set-up; ABI 17)
  *   mfg_train_rollouts_dist: arguments as mfg_train_rollouts (B = this rank's shard, traj_offset = its first global
  *     trajectory id, G / count summed over the ranks) plus the second parameter set (theta_alt, w_alt) the updates
- *     ping-pong through; on return the parameters are in (theta, w) and identical on every rank. */
+ *     ping-pong through; on return the parameters are in (theta, w) and identical on every rank.  MFG_ECOMM: the call
+ *     aborted the communicator (see the error codes). */
 typedef struct mfg_rccl_id { char bytes[128]; } mfg_rccl_id_t; /* ncclUniqueId */
 int mfg_dist_available(void); /* 1 if librccl's entry points resolve in this process, else 0 (no error recorded) */
 int mfg_dist_unique_id(mfg_rccl_id_t* id_host);
 int mfg_dist_init(const mfg_rccl_id_t* id_host, int nranks, int rank, void** comm_out);
 int mfg_dist_destroy(void* comm);
+int mfg_dist_abort(void* comm);
 int mfg_dist_all_reduce(void* comm, double* G, int64_t n, mfg_stream_t stream);
 int mfg_train_rollouts_dist(void* comm, const float* mat_pi0, int64_t num_start, int64_t B, int d, int T, int64_t episodes,
                             int64_t first_episode, int constant, double* theta, double* w, double* theta_alt, double* w_alt,

@@ -38,7 +38,7 @@ def test_host_only_helpers(lib):
     """Integer bookkeeping exported by the library is bit exact with the oracle (no GPU needed)."""
     from oracle import mfg_oracle as O
     h = lib.lib()
-    assert h.mfg_abi_version() == 16
+    assert h.mfg_abi_version() == 17
     for d in (1, 3, 4, 21, 47, 128, 256):
         assert h.mfg_num_features(d) == O.num_features(d)
         for i in range(0, d, max(1, d // 7)):

@@ -49,3 +49,5 @@ def test_bench_two_ranks_prints_one_valid_line():
     col = z['collective']
     assert col['world'] == 2 and col['payload_bytes'] == (21 * 22 // 2 + 21 + 1 + 3) * 8 and col['all_reduce_us'] > 0
     assert z['roofline']['bound'] == 'hbm' and 0 < z['roofline']['frac'] < 1.2
+    lp = z['loops']                                    # both episode loops timed in one run (gloo: the native RCCL loop cannot exist)
+    assert lp['headline_loop'] == 'torch_dist' and lp['native_rccl_ms_per_update'] is None and lp['torch_dist_ms_per_update'] > 0

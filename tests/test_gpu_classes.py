@@ -60,7 +60,19 @@ def test_call_surface_shapes_and_values(dev):
     assert np.allclose(ac.mat_alpha_deriv, k['grad_alpha_deriv'], rtol=1e-6, atol=1e-9)
     g = ac.calc_gradient_vectorized(P, pi)                            # test2.py:105-121
     assert isinstance(g, float) and abs(g - (-6.302201890992953)) < 1e-4
-    assert ac.calc_gradient(P, pi) == g and ac.calc_gradient_basic(P, pi) == g
+    # the reference's three-way self-check (test2.py:105-121): the two loop forms are evaluation paths of their own here
+    # (mfg_alpha + torch digamma / log in fp64, no score kernel), the vectorised one is the HIP score kernel
+    gb, gl = ac.calc_gradient_basic(P, pi), ac.calc_gradient(P, pi)
+    assert isinstance(gb, float) and isinstance(gl, float)
+    # (reference values of its own three variants on the fp64 P; the device holds P in fp32: 2e-6 relative on P)
+    assert abs(gb - float(k['grad_basic'])) < 1e-4 and abs(gl - float(k['grad_loop'])) < 1e-4
+    assert abs(gl - gb) < 1e-12 * abs(gb) + 1e-13
+    assert abs(g - gb) < 1e-5 * abs(gb)                               # mixed-precision kernel vs the fp64 loop forms
+    ac64 = AC(theta=10, shift=0.4, d=4, pi0=np.eye(4), rng='numpy', precision='f64')
+    np.random.seed(42)
+    P64 = ac64.sample_action(pi)
+    g64 = ac64.calc_gradient_vectorized(P64, pi)
+    assert abs(g64 - ac64.calc_gradient_basic(P64, pi)) < 1e-9 * abs(g64) and abs(g64 - ac64.calc_gradient(P64, pi)) < 1e-9 * abs(g64)
     r = ac.calc_reward(np.array([[1, 3, 3], [4, 5, 6], [7, 8, 9]]), np.array([0.1, 0.2, 0.7]), 3)   # test2.py:46-56
     assert r.shape == (1,) and abs(r[0] + 39.07) < 1e-4
     ac3 = AC(d=3, pi0=np.eye(3))
@@ -1251,10 +1263,60 @@ def test_contexts_isolate_the_status_word_between_instances(dev):
     a.clear_status()
     a.w = a.init_w(d)                                                     # (the diverged critic weights too)
     assert a.status() == 0 and np.all(np.isfinite(a.sample_action(mat[0])))
-    assert L.lib().mfg_ctx_current() == a._ctx._ptr                       # the method bound its instance's context
+    assert L.lib().mfg_ctx_current() is None         # the method bound its instance's context and put the caller's back
     # a context of its own for plain ops.* callers; destroying the bound context unbinds it
     c = ops.Context(dev).bind()
     assert L.lib().mfg_ctx_current() == c._ptr and c.status() == 0
+    assert np.all(np.isfinite(b.sample_action(mat[0]))) and L.lib().mfg_ctx_current() == c._ptr   # (restored after a method)
     c.close()
     assert L.lib().mfg_ctx_current() is None
-    assert L.lib().mfg_abi_version() >= 15
+    assert L.lib().mfg_abi_version() >= 17
+
+
+def test_context_destroyed_on_another_thread_leaves_no_dangling_binding(dev):
+    """a context may be destroyed by another thread than the one it is bound on (a garbage collector drops the last
+    reference wherever it runs).  The binding thread must then fall back to the device's default word at its next entry
+    point instead of dereferencing the freed object; binding / querying a destroyed context is refused; a younger context at
+    the same address is not mistaken for the old one."""
+    import threading
+    from discrete_mean_field_game_amd import ops, _lib as L
+    lib = L.lib()
+    ops.Context.unbind()
+    c = ops.Context(dev).bind()
+    ptr = c._ptr
+    assert lib.mfg_ctx_current() == ptr
+    t = threading.Thread(target=c.close)            # destroyed elsewhere while still bound HERE
+    t.start(); t.join()
+    assert lib.mfg_ctx_current() is None            # the stale binding is noticed, not followed
+    assert ops.status() == 0                        # entry points run on the default word
+    th = torch.tensor([8.86349], dtype=torch.float64, device=dev)
+    pi = torch.full((2, 21), 1.0 / 21, device=dev)
+    assert torch.isfinite(ops.sample_dirichlet(pi, th, 0.16, 12000.0, seed=3)).all()
+    assert lib.mfg_ctx_bind(ptr) == L.lib().mfg_ctx_bind(ptr) != 0          # a destroyed context cannot be bound ...
+    assert lib.mfg_ctx_status(ptr, None) != 0 and lib.mfg_ctx_destroy(ptr) != 0   # ... queried, or destroyed twice
+    # many create / destroy cycles: addresses get reused, a binding made to an OLD object never resolves to a younger one
+    olds = []
+    for _ in range(8):
+        k = ops.Context(dev).bind()
+        olds.append(k._ptr)
+        t = threading.Thread(target=k.close)
+        t.start(); t.join()
+        fresh = ops.Context(dev)                    # may land on the address just freed
+        assert lib.mfg_ctx_current() is None        # this thread's binding belonged to the destroyed one
+        fresh.close()
+    # an instance dropped by another thread while a second instance keeps working here
+    rs = np.random.RandomState(0)
+    mat = rs.dirichlet(np.ones(21), size=4)
+    a = AC(d=21, pi0=mat, batch=8, seed=1, update_every='rollout', verbose=0)
+    b = AC(d=21, pi0=mat, batch=8, seed=2, update_every='rollout', verbose=0)
+    a._ctx.bind()
+    box = [b]
+
+    def drop():
+        box.pop()._ctx.close()
+    del b
+    t = threading.Thread(target=drop)
+    t.start(); t.join()
+    a.train(num_episodes=2)
+    assert np.isfinite(np.ravel(a.theta)[0]) and a.status() == 0
+    ops.Context.unbind()

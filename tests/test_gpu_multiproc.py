@@ -171,3 +171,82 @@ def test_irl_reward_learning_two_ranks_stay_replicated(tmp_path):
     assert int(a['steps']) == int(b['steps']) == 24
     assert np.array_equal(a['flat'], b['flat']) and float(a['theta']) == float(b['theta'])
     assert np.all(np.isfinite(a['flat']))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Assigning the critic weights while a multi-rank update is still pending
+# ---------------------------------------------------------------------------------------------------------------------
+def _run_w_assignment(world):
+    """train() is cut short with the update of its last finished episode still PENDING (the deferred multi-rank update is
+    applied by the NEXT rollout kernel; here that rollout never starts), then `ac.w = ...` replaces the weights, then
+    training goes on.  The assignment must apply the pending increment to the OLD weights first (like the theta setter) --
+    otherwise the next flush adds the stale increment onto the user's values.  Returns (theta, w) at the end."""
+    sys.path.insert(0, ROOT)
+    from discrete_mean_field_game_amd import ops
+    from discrete_mean_field_game_amd.mfg_ac2 import actor_critic
+    d, B = 21, 50
+    np.random.seed(11)
+    ac = actor_critic(d=d, pi0=_mat(d), batch=B, rng='philox', seed=5, update_every='rollout', precision='f64', verbose=0)
+    new_w = np.random.RandomState(77).rand(ops.num_features(d))
+    if world == 1:
+        ac.train(num_episodes=2, gamma=0.9)
+        assert ac._pending is None
+    else:
+        real, calls = ops.train_rollout_deferred, {'n': 0}
+
+        def cut(*a, **k):
+            calls['n'] += 1
+            if calls['n'] == 3:
+                raise RuntimeError('interrupted')            # episode 2 never starts; the update of episode 1 stays pending
+            return real(*a, **k)
+        ops.train_rollout_deferred = cut
+        try:
+            with pytest.raises(RuntimeError, match='interrupted'):
+                ac.train(num_episodes=5, gamma=0.9)
+        finally:
+            ops.train_rollout_deferred = real
+        assert ac._pending is not None
+    ac.w = new_w
+    assert ac._pending is None and np.array_equal(ac.w[:, 0], new_w)       # nothing left to be added onto the new weights
+    ac.train(num_episodes=2, gamma=0.9, first_episode=2)
+    return float(np.ravel(ac.theta)[0]), ac.w[:, 0].copy()
+
+
+def _child_w(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        theta, w = _run_w_assignment(world)
+        np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), theta=theta, w=w)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_assigning_w_with_a_pending_multi_rank_update(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.fail('-m gpu tests need a GPU')
+    import torch.multiprocessing as mp
+    out_dir = str(tmp_path / 'wset')
+    os.makedirs(out_dir)
+    ctx = mp.get_context('spawn')
+    port = _free_port()
+    procs = [ctx.Process(target=_child_w, args=(r, 2, port, out_dir)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            pytest.fail('child rank did not finish')
+        assert p.exitcode == 0
+    a, b = [np.load(os.path.join(out_dir, 'rank%d.npz' % r)) for r in range(2)]
+    assert float(a['theta']) == float(b['theta']) and np.array_equal(a['w'], b['w'])
+    theta1, w1 = _run_w_assignment(1)
+    assert abs(float(a['theta']) - theta1) <= 1e-12 * abs(theta1)
+    assert np.max(np.abs(a['w'] - w1)) <= 1e-12 * np.max(np.abs(w1))

@@ -826,7 +826,8 @@ def test_diverging_training_run_stops_with_an_error(dev):
     ac.theta = 500.0
     with pytest.raises(L.MfgError, match='mfg_clear_status'):
         ac.train(num_episodes=3)
-    ops().clear_status()
+    assert ops().status() == 0                  # the condition sits in the INSTANCE's word, not in the caller's default context
+    ac.clear_status()
     ac.theta = 8.86349
     ac.w = np.zeros_like(ac.w)
     ac.train(num_episodes=1)

@@ -54,6 +54,9 @@ def test_bench_force_dist_runs_the_rccl_all_reduce():
     c = z['collective']
     assert c['backend'].startswith('rccl') and c['payload_bytes'] == (253 + 3) * 8
     assert 0 < c['all_reduce_us'] < 5e3 and 0 < c['all_reduce_plus_apply_update_us'] < 5e3
+    lp = z['loops']                                    # the native loop enabled itself behind its canary; both loops are timed
+    assert lp['headline_loop'] == 'native_rccl' and lp['canary']['native'] and lp['canary']['stage'] == 'ok'
+    assert lp['native_rccl_ms_per_update'] > 0 and lp['torch_dist_ms_per_update'] > 0 and c['native_all_reduce_us'] > 0
     print('RCCL 1-rank all-reduce of G: %.1f us; + mfg_apply_update: %.1f us' % (c['all_reduce_us'],
                                                                                  c['all_reduce_plus_apply_update_us']))
 
@@ -153,11 +156,71 @@ def test_native_rccl_episode_loop_equals_the_single_gpu_loop():
     Philox counter as the single-GPU run."""
     if not torch.cuda.is_available():
         pytest.fail('-m gpu tests need a GPU')
-    # (the native loop is opt-in since round 5: no run with more than one rank has happened yet, parallel.native_comm)
-    p = subprocess.run([sys.executable, '-c', _CHILD_NATIVE % {'root': ROOT}], cwd=ROOT, env=dict(_env(), MFG_NATIVE_RCCL='1'), stdout=subprocess.PIPE,
+    # (round 6: the native loop enables itself behind a canary, parallel.native_comm -- no environment switch)
+    p = subprocess.run([sys.executable, '-c', _CHILD_NATIVE % {'root': ROOT}], cwd=ROOT, env=_env(), stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     z = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
     assert z['comm'] and z['dist_calls'] == 3                      # chunks: episode 0 | 1..3 | 4..6 (reports at 0, 3, 6)
     assert z['same_theta'] and z['same_w'] and z['same_logs'] and z['steps'] == [105, 105]
     assert z['G'] == list(range(8)) and z['theta'] != 8.86349
+
+
+_CHILD_CANARY = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+from discrete_mean_field_game_amd import parallel, ops, _lib as L
+from discrete_mean_field_game_amd.mfg_ac2 import actor_critic
+mat = np.random.RandomState(3).dirichlet(np.ones(21), size=7)
+comm = parallel.native_comm(None, torch.device('cuda', 0), allow_single=True)
+log = dict(parallel.CANARY_LOG[-1])
+calls = {'dist': 0, 'all_reduce': 0}
+real_d, real_ar = ops.train_rollouts_dist, dist.all_reduce
+ops.train_rollouts_dist = lambda *a, **k: (calls.__setitem__('dist', calls['dist'] + 1), real_d(*a, **k))[1]
+dist.all_reduce = lambda *a, **k: (calls.__setitem__('all_reduce', calls['all_reduce'] + 1), real_ar(*a, **k))[1]
+res = {}
+for mode in ('forced', 'single'):
+    np.random.seed(11)
+    ac = actor_critic(d=21, pi0=mat, batch=500, rng='philox', seed=5, update_every='rollout', verbose=0)
+    ac._force_collective = mode == 'forced'
+    ac.train(num_episodes=5, gamma=0.9)
+    res[mode] = (float(np.ravel(ac.theta)[0]), ac.w[:, 0].tolist())
+torch.cuda.synchronize()
+print(json.dumps({'comm': bool(comm), 'log': log, 'calls': calls, 'cached_none': parallel.native_comm(None, torch.device('cuda', 0), allow_single=True) is None,
+                  'same': res['forced'] == res['single'], 'theta': res['forced'][0]}))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize('inject', ['', 'all', 'off'])
+def test_native_rccl_canary_enables_the_loop_or_falls_back_symmetrically(inject):
+    """VERDICT r5 next 3: the native RCCL loop is self-enabling behind a canary (parallel.native_comm: agreed ncclCommInitRank,
+    then one patterned all-reduce + a tiny mfg_train_rollouts_dist in a helper thread, then a final agreement).  1-rank `nccl`
+    communicator, fresh child: a healthy canary switches the class to the native loop (no torch.distributed call per episode);
+    an injected canary failure (MFG_NATIVE_RCCL_CANARY_FAIL) makes the rank abort its -- healthy -- communicator and stay on
+    torch.distributed, with the same trained parameters; MFG_NATIVE_RCCL=0 switches the attempt off."""
+    if not torch.cuda.is_available():
+        pytest.fail('-m gpu tests need a GPU')
+    env = _env()
+    if inject == 'all':
+        env['MFG_NATIVE_RCCL_CANARY_FAIL'] = 'all'
+    if inject == 'off':
+        env['MFG_NATIVE_RCCL'] = '0'
+    p = subprocess.run([sys.executable, '-c', _CHILD_CANARY % {'root': ROOT}], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    z = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert z['same'] and z['theta'] != 8.86349
+    if inject == '':
+        assert z['comm'] and z['log']['native'] and z['log']['stage'] == 'ok' and not z['cached_none']
+        assert z['calls']['dist'] >= 1                      # the class took the native loop ...
+    else:
+        assert not z['comm'] and not z['log']['native'] and z['cached_none']
+        assert z['log']['stage'] == ('canary' if inject == 'all' else 'resolve')
+        if inject == 'all':
+            assert 'injected' in z['log']['detail']
+        assert z['calls']['dist'] == 0 and z['calls']['all_reduce'] >= 5     # ... or one torch all-reduce per update
