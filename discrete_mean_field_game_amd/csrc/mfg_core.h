@@ -121,6 +121,10 @@ int reward_net_forward_sums(const float* state, const float* action, int64_t B, 
 
 // launchers defined in mfg_core_small.hip / mfg_core_large_*.hip; return 0 or MFG_EUNSUPPORTED
 int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st);
+// d = 21, mixed-precision sampling launches of batches that under-fill the machine: one trajectory per wavefront, three lanes
+// per matrix row (mfg_core_row3.hip).  core_row3_wanted: whether launch_core_small hands a launch of this shape to it.
+bool core_row3_wanted(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus);
+int launch_core_row3(const CoreArgs& a, bool td, int num_cus, hipStream_t st);
 int launch_core_large_f64(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st);
 int launch_core_large_mixed(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st);
 
@@ -239,14 +243,17 @@ __device__ __forceinline__ PolicyTerms<FAST> policy_terms(const PolicyElem<FAST>
 //   unless SEP), elem = its element id (Philox counter of its own continuation draws), valid = whether it exists
 //   (lanes past the last column compute on clamped inputs and are masked out).
 //   Out: y = gamma variate (0 when !valid); al / ad / gt = its alpha, alpha', score term (0 when !valid; TD only).
+//   qstep = the env step that keys the QUAD's block (block 0 of elem[0]); step = the env step that keys the elements' own
+//   continuation draws.  They differ only where a lane runs a row's trailing single element through the quad code
+//   (k_core_row3: the pair of sample_tail1 is keyed by the even step); sample_elems_g passes the same value twice.
 template <int NE, bool TD, bool FAST, bool SEP>
-__device__ __forceinline__ void sample_elems_g(const CoreArgs& a, double theta, const ThetaSplit& ts, const float* pj,
-                                               const float* ej, const float* pai, const float* Fi, const uint32_t* elem,
-                                               const bool* valid, uint32_t step, uint64_t traj, float* y,
-                                               typename PolicyTerms<FAST>::T* al, typename PolicyTerms<FAST>::T* ad,
-                                               typename PolicyTerms<FAST>::T* gt) {
+__device__ __forceinline__ void sample_elems_gq(const CoreArgs& a, double theta, const ThetaSplit& ts, const float* pj,
+                                                const float* ej, const float* pai, const float* Fi, const uint32_t* elem,
+                                                const bool* valid, uint32_t qstep, uint32_t step, uint64_t traj, float* y,
+                                                typename PolicyTerms<FAST>::T* al, typename PolicyTerms<FAST>::T* ad,
+                                                typename PolicyTerms<FAST>::T* gt) {
   QuadRand q;
-  quad_rand(q, a.seed, elem[0], step, traj);
+  quad_rand(q, a.seed, elem[0], qstep, traj);
   // the two Box-Muller pairs one after the other (two interleaved chains each; four at once cost 36 spilled VGPRs at
   // the 128-register cap of the small-d kernel and bought nothing at full occupancy)
 #ifndef MFG_QUAD_WIDTH
@@ -326,6 +333,15 @@ __device__ __forceinline__ void sample_elems_g(const CoreArgs& a, double theta, 
       }
     }
   }
+}
+
+template <int NE, bool TD, bool FAST, bool SEP>
+__device__ __forceinline__ void sample_elems_g(const CoreArgs& a, double theta, const ThetaSplit& ts, const float* pj,
+                                               const float* ej, const float* pai, const float* Fi, const uint32_t* elem,
+                                               const bool* valid, uint32_t step, uint64_t traj, float* y,
+                                               typename PolicyTerms<FAST>::T* al, typename PolicyTerms<FAST>::T* ad,
+                                               typename PolicyTerms<FAST>::T* gt) {
+  sample_elems_gq<NE, TD, FAST, SEP>(a, theta, ts, pj, ej, pai, Fi, elem, valid, step, step, traj, y, al, ad, gt);
 }
 
 // Small-d wrapper: NE neighbouring elements of ONE row (all valid); ys / as / ds / gs RETURN the sums of the NE elements in
@@ -823,6 +839,33 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
         double acc = 0.0, s1 = 0.0, s2 = 0.0;
         const float* tcol = tile + tlc * d * dp + i;
         const double2* q64 = reinterpret_cast<const double2*>(pis64) + tlc * d;
+#if !defined(MFG_ABL_COLT) && !defined(MFG_ABL_COLREW)
+        if constexpr (D == 21) {
+          // d = 21: three groups of seven rows, each summed from its own first row, folded in group order (col_group_rows,
+          // mfg_device.h): the summation tree the three-lanes-per-column kernel k_core_row3 shares
+          constexpr int GR = col_group_rows(D);
+#pragma unroll
+          for (int g0 = 0; g0 < D; g0 += GR) {
+            double pa, p1, p2;
+#pragma unroll
+            for (int r = 0; r < GR; ++r) {
+              const int k = g0 + r;
+              const double2 e = q64[k];  // {pi_k, 1 / S_k (fp32 bits in the low word of .y)}
+              const double p = (double)(tcol[k * dp] * __int_as_float(__double2loint(e.y)));
+              col_walk_row(r == 0, p * e.x, p, pa, p1, p2);
+            }
+            if (g0 == 0) {
+              acc = pa;
+              s1 = p1;
+              s2 = p2;
+            } else {
+              acc += pa;
+              s1 += p1;
+              s2 += p2;
+            }
+          }
+        } else
+#endif
 #ifdef MFG_ABL_COLT
         for (int k = 0; k < 0; ++k) {
 #else

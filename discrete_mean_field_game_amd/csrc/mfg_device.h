@@ -699,6 +699,26 @@ __device__ __forceinline__ double rows_column_sum(const double* __restrict__ row
   return wave_sum_dpp(s);
 }
 
+// Column walk of the transition / reward sums (pi'_j = sum_i pi_i P_ij and the two reward sums of column j): the d rows are added
+// in groups of col_group_rows(d) consecutive rows -- every group starts from its own first row, the group sums are folded in group
+// order.  d = 21: THREE groups of seven, so that the packed kernels (a lane walks all 21 rows of its column) and the
+// one-trajectory-per-wave kernel (k_core_row3: three lanes per column, seven rows each) share ONE summation tree -- the results
+// of a launch do not depend on which lane mapping it picked, i.e. on the batch a rank happens to hold (world-size invariance,
+// tests/test_gpu_fullsize.py).  Every other d: one group = the plain row order of rounds 1-5.
+__host__ __device__ constexpr int col_group_rows(int d) { return d == 21 ? 7 : (d > 0 ? d : 1); }
+// One row of the walk folded into the running sums of its group (first = the group's first row): u = pi_i P_ij is exact in fp64.
+__device__ __forceinline__ void col_walk_row(bool first, double u, double p, double& pa, double& p1, double& p2) {
+  if (first) {
+    pa = u;
+    p1 = u * p;
+    p2 = u * u;
+  } else {
+    pa += u;
+    p1 = fma(u, p, p1);
+    p2 = fma(u, u, p2);
+  }
+}
+
 // k(i,j) for i <= j: row-major upper triangle (mfg_ac2.py:333).
 __host__ __device__ __forceinline__ int feat_idx(int i, int j, int d) { return i * d - (i * (i - 1)) / 2 + (j - i); }
 

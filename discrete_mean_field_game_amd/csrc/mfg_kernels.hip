@@ -436,18 +436,26 @@ __global__ __launch_bounds__(BLOCK, (PER <= 6 ? MFG_STEP_WAVES : 4)) void k_step
     const float* colp = tP + tlc * dd + j;
     const float* qv = tQ + tlc * d;
     double acc = 0.0, s1 = 0.0, s2 = 0.0;
+    // rows in groups of col_group_rows(d) (mfg_device.h: three groups of seven at d = 21, the plain row order otherwise)
+    const int dr = D ? D : d, grp = col_group_rows(dr);
+    for (int g0 = 0; g0 < dr; g0 += grp) {
+      double pa = 0.0, p1 = 0.0, p2 = 0.0;
 #pragma unroll MFG_STEP_UNROLL
-    for (int i = 0; i < (D ? D : d); ++i) {
-      const double p = (double)colp[i * d];
-      const double qx = (double)qv[i];
-      // u = pi_i P_ij is exact in fp64 (two fp32 factors), so acc += u equals the fma, and pi_i P_ij^2 = u p,
-      // pi_i^2 P_ij^2 = u^2 are formed inside the fmas with the same single rounding as before: 4 fp64 ops, not 5
-      const double u = p * qx;
-      acc += u;
-      if (KIND != MFG_REWARD_EXTERNAL) {
-        s1 = fma(u, p, s1);
-        if (KIND == MFG_REWARD_MFG_AC2) s2 = fma(u, u, s2);
+      for (int i = g0; i < g0 + grp; ++i) {
+        const double p = (double)colp[i * d];
+        const double qx = (double)qv[i];
+        // u = pi_i P_ij is exact in fp64 (two fp32 factors), so acc += u equals the fma, and pi_i P_ij^2 = u p,
+        // pi_i^2 P_ij^2 = u^2 are formed inside the fmas with the same single rounding as before: 4 fp64 ops, not 5
+        const double u = p * qx;
+        pa += u;
+        if (KIND != MFG_REWARD_EXTERNAL) {
+          p1 = fma(u, p, p1);
+          if (KIND == MFG_REWARD_MFG_AC2) p2 = fma(u, u, p2);
+        }
       }
+      acc = g0 ? acc + pa : pa;
+      s1 = g0 ? s1 + p1 : p1;
+      s2 = g0 ? s2 + p2 : p2;
     }
     double racc = 0.0;
     if (KIND == MFG_REWARD_MFG_AC2) racc = fma((double)qv[j], s1, -s2);
@@ -558,16 +566,25 @@ __global__ __launch_bounds__(BLOCK, MFG_STEP_WAVES) void k_step_wave(const float
     const float* colp = wP + off + tc * DD + j;
     const float* qv = wQ + tc * D;
     double acc = 0.0, s1 = 0.0, s2 = 0.0;
+    // rows in groups of col_group_rows(D) (mfg_device.h: three groups of seven at d = 21; one group = the plain row order at 15)
+    constexpr int GR = col_group_rows(D);
+#pragma unroll
+    for (int g0 = 0; g0 < D; g0 += GR) {
+      double pa = 0.0, p1 = 0.0, p2 = 0.0;
 #pragma unroll MFG_STEP_UNROLL
-    for (int i = 0; i < D; ++i) {
-      const double p = (double)colp[i * D];
-      const double qx = (double)qv[i];
-      const double u = p * qx;
-      acc += u;
-      if (KIND != MFG_REWARD_EXTERNAL) {
-        s1 = fma(u, p, s1);
-        if (KIND == MFG_REWARD_MFG_AC2) s2 = fma(u, u, s2);
+      for (int i = g0; i < g0 + GR; ++i) {
+        const double p = (double)colp[i * D];
+        const double qx = (double)qv[i];
+        const double u = p * qx;
+        pa += u;
+        if (KIND != MFG_REWARD_EXTERNAL) {
+          p1 = fma(u, p, p1);
+          if (KIND == MFG_REWARD_MFG_AC2) p2 = fma(u, u, p2);
+        }
       }
+      acc = g0 ? acc + pa : pa;
+      s1 = g0 ? s1 + p1 : p1;
+      s2 = g0 ? s2 + p2 : p2;
     }
     double racc = 0.0;
     if (KIND == MFG_REWARD_MFG_AC2) racc = fma((double)qv[j], s1, -s2);
@@ -689,18 +706,27 @@ __global__ __launch_bounds__(BLOCK, 2) void k_step_wave_batched(const float* __r
       // the trajectory (broadcast reads; the VALU is idle anyway): the per-tile serial phase of k_step_wave -- two wave
       // barriers and 21 dependent adds on one lane -- disappears into the walk.  Same order: even terms, odd terms.
       double r0 = 0.0, r1 = 0.0;
+      // rows in groups of col_group_rows(D) (mfg_device.h: three groups of seven at d = 21; the plain row order at 15)
+      constexpr int GR = col_group_rows(D);
 #pragma unroll
-      for (int i = 0; i < D; ++i) {
-        const double p = (double)colp[i * D];
-        const double qx = (double)qv[i];
-        const double u = p * qx;
-        acc += u;
-        if (REW) {
-          s1 = fma(u, p, s1);
-          if (KIND == MFG_REWARD_MFG_AC2) s2 = fma(u, u, s2);
-          if (i & 1) r1 += line[i];
-          else r0 += line[i];
+      for (int g0 = 0; g0 < D; g0 += GR) {
+        double pa = 0.0, p1 = 0.0, p2 = 0.0;
+#pragma unroll
+        for (int i = g0; i < g0 + GR; ++i) {
+          const double p = (double)colp[i * D];
+          const double qx = (double)qv[i];
+          const double u = p * qx;
+          pa += u;
+          if (REW) {
+            p1 = fma(u, p, p1);
+            if (KIND == MFG_REWARD_MFG_AC2) p2 = fma(u, u, p2);
+            if (i & 1) r1 += line[i];
+            else r0 += line[i];
+          }
         }
+        acc = g0 ? acc + pa : pa;
+        s1 = g0 ? s1 + p1 : p1;
+        s2 = g0 ? s2 + p2 : p2;
       }
       double racc = 0.0;
       if (KIND == MFG_REWARD_MFG_AC2) racc = fma((double)qv[j], s1, -s2);
@@ -787,13 +813,20 @@ __global__ __launch_bounds__(BLOCK) void k_step_small_unaligned(const float* __r
     const float* colp = tP + tlc * dd + j;
     const double2* qv = tQ + tlc * d;
     double acc = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < d; ++i) {
-      const double p = (double)colp[i * d];
-      const double2 q = qv[i];
-      const double pp = p * p;
-      acc = fma(p, q.x, acc);
-      s1 = fma(q.x, pp, s1);
-      s2 = fma(q.y, pp, s2);
+    const int grp = col_group_rows(d);  // (mfg_device.h: pi' of the aligned kernels bit for bit, also at d = 21)
+    for (int g0 = 0; g0 < d; g0 += grp) {
+      double pa = 0.0, p1 = 0.0, p2 = 0.0;
+      for (int i = g0; i < g0 + grp; ++i) {
+        const double p = (double)colp[i * d];
+        const double2 q = qv[i];
+        const double pp = p * p;
+        pa = fma(p, q.x, pa);
+        p1 = fma(q.x, pp, p1);
+        p2 = fma(q.y, pp, p2);
+      }
+      acc = g0 ? acc + pa : pa;
+      s1 = g0 ? s1 + p1 : p1;
+      s2 = g0 ? s2 + p2 : p2;
     }
     double racc = 0.0;
     if (KIND == MFG_REWARD_MFG_AC2) racc = fma(qv[j].x, s1, -s2);
