@@ -43,6 +43,7 @@ _i64, _i32, _u64, _u32, _f64, _sz = C.c_int64, C.c_int, C.c_uint64, C.c_uint32, 
 SIGNATURES = {
     'mfg_last_error': (C.c_char_p, []),
     'mfg_abi_version': (_i32, []),
+    'mfg_set_core_mapping': (_i32, [_i32]),
     'mfg_init': (_i32, []),
     'mfg_status': (_i32, [C.POINTER(C.c_uint)]),
     'mfg_clear_status': (_i32, []),

@@ -125,6 +125,7 @@ int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int nu
 // per matrix row (mfg_core_row3.hip).  core_row3_wanted: whether launch_core_small hands a launch of this shape to it.
 bool core_row3_wanted(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus);
 int launch_core_row3(const CoreArgs& a, bool td, int num_cus, hipStream_t st);
+int core_mapping_set(int mode);  // 0 by batch size, 1 packed, 2 one trajectory per wave; returns the previous mode
 int launch_core_large_f64(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st);
 int launch_core_large_mixed(const CoreArgs& a, bool sample, bool td, int num_cus, hipStream_t st);
 
@@ -246,7 +247,9 @@ __device__ __forceinline__ PolicyTerms<FAST> policy_terms(const PolicyElem<FAST>
 //   qstep = the env step that keys the QUAD's block (block 0 of elem[0]); step = the env step that keys the elements' own
 //   continuation draws.  They differ only where a lane runs a row's trailing single element through the quad code
 //   (k_core_row3: the pair of sample_tail1 is keyed by the even step); sample_elems_g passes the same value twice.
-template <int NE, bool TD, bool FAST, bool SEP>
+//   ALLVALID: every element is treated as existing whatever `valid` says (no per-element selects / ballots); the caller
+//   discards what it does not want -- the continuation of a discarded element may still run (harmless, wave-uniform branch).
+template <int NE, bool TD, bool FAST, bool SEP, bool ALLVALID = false>
 __device__ __forceinline__ void sample_elems_gq(const CoreArgs& a, double theta, const ThetaSplit& ts, const float* pj,
                                                 const float* ej, const float* pai, const float* Fi, const uint32_t* elem,
                                                 const bool* valid, uint32_t qstep, uint32_t step, uint64_t traj, float* y,
@@ -301,7 +304,8 @@ __device__ __forceinline__ void sample_elems_gq(const CoreArgs& a, double theta,
         if (quad_kbits(e) == 16) v[u] = gamma_try_mask<16>(pe[u].gs, xn[u], q.kf[e], cm);
         else v[u] = gamma_try_mask<12>(pe[u].gs, xn[u], q.kf[e], cm);
         y[e] = pe[u].gs.dd * v[u];
-        coldm |= cm & __builtin_amdgcn_ballot_w64(valid[e]);
+        if constexpr (ALLVALID) coldm |= cm;
+        else coldm |= cm & __builtin_amdgcn_ballot_w64(valid[e]);
       }
     }
     const bool any_cold = coldm != 0;
@@ -309,7 +313,7 @@ __device__ __forceinline__ void sample_elems_gq(const CoreArgs& a, double theta,
 #pragma unroll
       for (int u = 0; u < PW; ++u) {
         const int e = PW * h + u;
-        if (u < n2 && valid[e]) {
+        if (u < n2 && (ALLVALID || valid[e])) {
           const bool k16 = quad_kbits(e) == 16;
           if (k16) (void)gamma_try<16>(pe[u].gs, xn[u], q.kf[e], sure[u]);   // (the per-lane flags, recomputed off the hot path)
           else (void)gamma_try<12>(pe[u].gs, xn[u], q.kf[e], sure[u]);
@@ -325,11 +329,11 @@ __device__ __forceinline__ void sample_elems_gq(const CoreArgs& a, double theta,
         const int e = PW * h + u;
         if (TD) {
           const PolicyTerms<FAST> t = policy_terms<true, FAST>(pe[u], a.htab, ts.th, y[e]);
-          al[e] = valid[e] ? t.al : 0;
-          ad[e] = valid[e] ? t.ad : 0;
-          gt[e] = valid[e] ? t.gt : 0;
+          al[e] = (ALLVALID || valid[e]) ? t.al : 0;
+          ad[e] = (ALLVALID || valid[e]) ? t.ad : 0;
+          gt[e] = (ALLVALID || valid[e]) ? t.gt : 0;
         }
-        if (!valid[e]) y[e] = 0.0f;
+        if (!ALLVALID && !valid[e]) y[e] = 0.0f;
       }
     }
   }

@@ -1,0 +1,434 @@
+// d = 21, mixed-precision SAMPLING launches of batches that under-fill the machine: ONE trajectory per wavefront, THREE lanes
+// per matrix row (round 6).
+//
+// The packed kernel k_core_small (mfg_core.h) puts G = 3 trajectories into a wave, lane = (trajectory, row): a wave walks the 21
+// elements of its rows one quad after the other -- a dependent chain of ~1 700 vector instructions per env step -- and a batch of
+// B trajectories is B / 3 waves.  Below ~12 000 trajectories those are fewer than the 3 x 1 024 waves the 1 024 SIMDs of an
+// MI355X hold, at 4 096 (BASELINE configs 2 and 4) 1 366 waves: a third of the SIMDs carries two chains, the others one, and the
+// launch lasts as long as two chains back to back (profiles/r05_shards.txt: 108.7 us at 4 096, 80 us for every B <= 2 048 -- the
+// length of ONE chain; profiles/r05_pmc_sq_irl_step.txt: the vector unit is active ~35 % of the launch).
+// Here lane = (row i, part k), k = 0, 1, 2 (63 lanes; lane 63 shadows lane 62 and writes nothing):
+//   * sampling: the row's six units of work -- the five quads at columns 4 q and the trailing single element -- go two to a lane:
+//     lane k draws quads 2 k and 2 k + 1, lane 2 quad 4 and the tail.  Every unit is keyed exactly as in the packed kernel (Philox
+//     block 0 of the quad's first element id i d + 4 q; the tail's Box-Muller pair by the EVEN step, cosine / first integer on even
+//     steps, sine / second integer on odd ones -- sample_tail1), so the SAME actions are drawn.  The tail runs through the quad
+//     code with per-lane element ids, step key and validity (sample_elems_gq): one instruction stream for all three lanes;
+//   * row sums S, A, D, g: the packed kernel folds the units' fp32 sums into fp64 in unit order; the same chain runs ACROSS the
+//     three lanes here (two DPP wave_shr:1 hand-overs), so the row totals have the same bits; they end up on lane k = 2, which runs
+//     the per-row epilogue (1 / S, ln S, digamma(A));
+//   * column pass (pi' = P^T pi, reward sums): lane (column j, k) walks rows 7 k .. 7 k + 6, lane k = 0 folds the three group
+//     sums in group order -- the tree col_group_rows (mfg_device.h) gives the packed kernels at d = 21;
+//   * value terms, per-trajectory sums, TD error: the packed kernel's code on the lanes k = 0 (and k = 1 for V of the start state,
+//     in the same pass), same association.
+// Every output (pi_traj, rewards, delta, g, P) is therefore bit for bit what k_core_small<SAMPLE, TD, MIXED, 21> writes for the
+// same trajectory: which mapping a launch takes is a function of the batch a rank holds and must not show in the results
+// (world-size invariance; tests/test_gpu_row3.py compares the two kernels with array_equal).
+// A wave's chain is ~2.2x shorter (two quads instead of five and a half); the wave count is 3x; the instruction work per
+// trajectory ~1.4x (the epilogue, the per-trajectory sums and the value terms are per wave, not per lane).  Selected by
+// launch_core_small while the batch fits one resident round at four waves per SIMD (core_row3_wanted).
+#include <atomic>
+#include <stdlib.h>
+
+#include "mfg_core.h"
+
+namespace mfg {
+
+namespace {
+constexpr int R3D = 21;                                   // d
+constexpr int R3H = (R3D + 1) / 2;                        // circulant value terms per state entry
+constexpr int R3Q = R3D * (R3D + 1) / 2, R3F = R3Q + R3D + 1;
+constexpr int R3DD = R3D * R3D;
+// LDS of one wave: nothing but the critic weights is shared by the block, so every barrier of a step is wave local
+struct alignas(16) R3Wave {
+  double2 q64[R3D];          // {pi_k as fp64, 1 / S_k of row k (fp32 bits in the low word of .y)}: one broadcast read per row
+  double red[4][R3D];        // per-entry terms of reward / score / V(next) / V(start), summed by eight lanes
+  double tot[8];             // even / odd partial sums of the four per-trajectory sums
+  float tile[R3DD + 3];      // gamma variates (P when it is written out) of the step, row-major, unpadded
+  float pis[R3D + 3];        // state; entries 21 .. 23 repeat entry 20: the lanes that draw a row's trailing element read "four
+  float pex[R3D + 3];        // columns" from 20 on like every other lane (one base address + immediates).  E_j = e^{theta (pi_j - 1/2)}
+  float pin[2 * R3D];        // next state, doubled (circulant value form: vec[i + m] needs no modulo)
+  float pst[2 * R3D];        // the rollout's start state, doubled
+};
+static_assert(sizeof(R3Wave) % 16 == 0, "wave regions must keep the 16-byte alignment of q64");
+constexpr size_t R3_WL_BYTES = (size_t)((R3F + 1) & ~1) * 8;   // critic weights (circulant layout), fp64
+}  // namespace
+
+inline size_t core_row3_lds() { return R3_WL_BYTES + (size_t)WAVES * sizeof(R3Wave); }
+
+// DPP wave shifts by one lane: shr -> lane l takes lane l - 1 (lane 0: zero), shl -> lane l takes lane l + 1 (lane 63: zero)
+__device__ __forceinline__ double r3_shr1(double v) { return dpp_mov_f64<0x138, 0xF>(v); }
+__device__ __forceinline__ double r3_shl1(double v) { return dpp_mov_f64<0x130, 0xF>(v); }
+__device__ __forceinline__ float r3_shr1(float v) { return dpp_mov_f32<0x138, 0xF>(v); }
+__device__ __forceinline__ float r3_shl1(float v) { return dpp_mov_f32<0x130, 0xF>(v); }
+
+#ifndef MFG_ROW3_WAVES
+#define MFG_ROW3_WAVES 4   // waves per SIMD the kernel is register-capped for (128 VGPRs): 4 096 trajectories = one resident round
+#endif
+template <bool TD>
+__global__ __launch_bounds__(BLOCK, MFG_ROW3_WAVES) void k_core_row3(CoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int D = R3D, H = R3H, Q = R3Q, F = R3F, DD = R3DD;
+  const int T = a.T;
+  const bool want_v = TD && a.w != nullptr;
+  double* wl = reinterpret_cast<double*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE);
+  R3Wave& W = *reinterpret_cast<R3Wave*>(smem_raw + R3_WL_BYTES + (size_t)wv * sizeof(R3Wave));
+  // lane = 3 i + k; lane 63 shadows lane 62 (row 20, part 2) and never writes
+  const int i3 = (lane * 43) >> 7;  // lane / 3 for lane < 64
+  const bool live = lane < 63;
+  const int i = live ? i3 : D - 1;
+  const int k = live ? lane - 3 * i3 : 2;
+  const bool k0 = live && k == 0;
+
+  // first trajectory's start state: issued before the weight staging (its L2 / HBM latency hides behind it)
+  const int64_t ntraj = a.B;
+  const int64_t wstride = (int64_t)gridDim.x * WAVES;
+  int64_t b = (int64_t)blockIdx.x * WAVES + wv;
+  float pi_first = 0.0f;
+  if (b < ntraj) pi_first = a.pi0[core_src_row(a, b) * D + i];
+  // deferred update of the previous episode (CoreArgs::pend_G), applied on the fly exactly as in k_core_small
+  const bool pend = a.pend_G != nullptr && a.pend_G[F + 2] > 0.0;
+  const double pinv = pend ? 1.0 / a.pend_G[F + 2] : 0.0;
+  const double theta = pend ? updated_param(*a.theta, a.pend_lr_a, a.pend_G[F], pinv) : *a.theta;
+  const ThetaSplit ts = theta_split(theta, a.shift);
+  report_sep_range(a.status, theta, a.shift);
+  auto w_now = [&](int kk) -> double { return pend ? updated_param(a.w[kk], a.pend_lr_c, a.pend_G[kk], pinv) : a.w[kk]; };
+  if (want_v) {
+    // circulant layout of the quadratic weights: wl[m d + i] = w[k(min, max)] of the pair {i, i + m mod d} (see k_core_small)
+    for (int kk = tid; kk < H * D; kk += BLOCK) {
+      const int m = kk / D, ii = kk - m * D;
+      int jj = ii + m;
+      if (jj >= D) jj -= D;
+      wl[kk] = w_now(feat_idx(ii < jj ? ii : jj, ii < jj ? jj : ii, D));
+    }
+    for (int kk = Q + tid; kk < F; kk += BLOCK) wl[kk] = w_now(kk);
+  }
+  if (a.pend_G != nullptr && blockIdx.x == 0) {
+    // block 0 publishes the updated parameters (out of place) and books the update's mean reward
+    if (a.w_out && a.w)
+      for (int kk = tid; kk < F; kk += BLOCK) a.w_out[kk] = w_now(kk);
+    if (tid == 0) {
+      if (a.theta_out) *a.theta_out = theta;
+      if (pend && a.pend_reward_acc) *a.pend_reward_acc += a.pend_G[F + 1] * pinv;
+    }
+  }
+  __syncthreads();  // the one block barrier of the launch: wl is staged block-wide and read by every wave
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  };
+  // value term of state entry i for the state in the doubled vector `vec` whose entry i is pi_e: k_core_small's circulant form
+  auto value_term = [&](const float* vec, float pi_e) -> double {
+    double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+    for (int m = 0; m + 1 < H; m += 2) {
+      c0 = fma(wl[m * D + i], (double)vec[i + m], c0);
+      c1 = fma(wl[(m + 1) * D + i], (double)vec[i + m + 1], c1);
+    }
+    if (H & 1) c0 = fma(wl[(H - 1) * D + i], (double)vec[i + H - 1], c0);
+    const double col = c0 + c1;
+    return (double)pi_e * (col + wl[Q + i]);
+  };
+  const bool ext = a.reward_kind == MFG_REWARD_EXTERNAL;
+
+  for (; b < ntraj; b += wstride) {
+    float pi_i = pi_first;
+    if (b + wstride < ntraj) pi_first = a.pi0[core_src_row(a, b + wstride) * D + i];  // the next trajectory's start state
+    if (k0 && a.pi_traj) a.pi_traj[b * (int64_t)(T + 1) * D + i] = pi_i;
+    double v_cur = 0.0, discount = 1.0;  // meaningful on lane 0 only
+    const uint64_t traj = a.traj_offset + (uint64_t)b;
+    const uint32_t erow = (uint32_t)(i * D);
+    for (int s = 0; s < T; ++s) {
+      wave_sync();  // everything of the previous step has been read
+      const uint32_t step = a.first_step + (uint32_t)s;
+      // ---- state of the step: every lane of a row keeps pi_i and forms F_i; the lane k = 0 publishes pi_i, E_i
+      const float Ei = exp_f64arg(theta * ((double)pi_i - SEP_CENTRE));
+      const float Fi = exp_f64arg(-theta * ((double)pi_i + (a.shift - SEP_CENTRE)));
+      if (i == D - 1 && lane != 60) {  // lanes 61, 62, 63 hold row 20's state too: the three copies behind the vector
+        const int c = lane - 40;       // 21, 22, 23
+        W.pis[c] = pi_i;
+        W.pex[c] = Ei;
+      }
+      if (k0) {
+        W.pis[i] = pi_i;
+        W.pex[i] = Ei;
+        W.q64[i].x = (double)pi_i;
+        if (want_v && s == 0) {
+          W.pst[i] = pi_i;
+          W.pst[D + i] = pi_i;
+        }
+      }
+      wave_sync();
+      // ---- sampling: two units per lane through the quad code
+      using TT = float;
+      const float pas = pi_i + ts.sh;  // row operand of the separable form (policy_setup_sep)
+      float pa[4], fi[4];
+      float yk[2][4];
+      float S1 = 0.0f, S2 = 0.0f;
+      TT A1 = 0, A2 = 0, D1 = 0, D2 = 0, G1 = 0, G2 = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pa[e] = pas;
+        fi[e] = Fi;
+      }
+      const bool wp = a.P_out != nullptr;
+      const uint32_t odd = step & 1u;
+      float* trow = W.tile + i * D;
+      // round 0: the quad at columns 8 k .. 8 k + 3 (quads 0, 2, 4 of the row); round 1: the quad at columns 8 k + 4 .. 8 k + 7
+      // (quads 1, 3) -- or, on the lanes k = 2, the row's trailing element: its pair is keyed by the EVEN step, element 0 of the
+      // pair (cosine, first 16-bit integer) is the draw of an even step, element 1 (sine, second integer) of an odd one; the
+      // other elements do not exist there (sample_tail1's arithmetic).  ONE copy of the quad code (a rolled loop: two copies
+      // interleaved by the scheduler cost 200 spilled registers at the 128-register cap).
+#pragma unroll 1
+      for (int r = 0; r < 2; ++r) {
+        float pj[4], ej[4], y[4];
+        TT al[4], ad[4], gt[4];
+        uint32_t el[4];
+        bool ok[4];
+        const bool tail = r == 1 && k == 2;
+        const uint32_t qstep = tail ? (step & ~1u) : step;
+        const int c0 = 8 * k + 4 * r;          // (tail: 20 -- the copies behind the state vector stand in for "columns" 21 .. 23)
+        const uint32_t elmax = erow + (uint32_t)(D - 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          pj[e] = W.pis[c0 + e];
+          ej[e] = W.pex[c0 + e];
+          const uint32_t id = erow + (uint32_t)(c0 + e);
+          el[e] = id < elmax ? id : elmax;     // the tail's elements all carry the tail's id (its continuation draws are keyed by it)
+          ok[e] = true;  // (ALLVALID: the tail lanes pick their element below; lane 63 mirrors lane 62 and writes nothing)
+        }
+        sample_elems_gq<4, TD, true, true, true>(a, theta, ts, pj, ej, pa, fi, el, ok, qstep, step, traj, y, al, ad, gt);
+        float Sr = y[0];
+        TT Ar = 0, Dr = 0, Gr = 0;
+        if (TD) Ar = al[0], Dr = ad[0], Gr = gt[0];
+#pragma unroll
+        for (int e = 1; e < 4; ++e) {
+          Sr += y[e];
+          if (TD) Ar += al[e], Dr += ad[e], Gr += gt[e];
+        }
+        if (r == 1) {
+          // tail lanes: the unit is ONE element -- element 0 of the pair on even steps, element 1 on odd ones (wave-uniform choice);
+          // elements 2, 3 (and the other one of the pair) do not exist: their draws are discarded
+          const float ys = odd ? y[1] : y[0];
+          Sr = tail ? ys : Sr;
+          if (TD) {
+            const TT as = odd ? al[1] : al[0], ds = odd ? ad[1] : ad[0], gs = odd ? gt[1] : gt[0];
+            Ar = tail ? as : Ar;
+            Dr = tail ? ds : Dr;
+            Gr = tail ? gs : Gr;
+          }
+          y[0] = tail ? ys : y[0];  // what the tail lanes store at column 20 (they store no other element)
+        }
+        if (r == 0) {
+          S1 = Sr;
+          if (TD) A1 = Ar, D1 = Dr, G1 = Gr;
+        } else {
+          S2 = Sr;
+          if (TD) A2 = Ar, D2 = Dr, G2 = Gr;
+        }
+        if (wp) {  // P is written out: the variates wait in registers for the row's normaliser
+#pragma unroll
+          for (int e = 0; e < 4; ++e) yk[r][e] = y[e];
+        } else if (live) {
+          trow[c0] = y[0];
+          if (!tail) {
+#pragma unroll
+            for (int e = 1; e < 4; ++e) trow[c0 + e] = y[e];
+          }
+        }
+      }
+      const bool tailk = k == 2;
+      // ---- row totals: the packed kernel's chain  ((((0 + q0) + q1) + q2) + q3) + q4) + tail  in fp64, across the three lanes
+      auto chain = [&](float r1, float r2) -> double {
+        const double x1 = (double)r1, x2 = (double)r2;
+        double c = x1 + x2;                       // k = 0: (0 + q0) + q1
+        c = (r3_shr1(c) + x1) + x2;               // k = 1: ((.. + q2) + q3)
+        c = (r3_shr1(c) + x1) + x2;               // k = 2: ((.. + q4) + tail)
+        return c;
+      };
+      const double Ssum = chain(S1, S2);
+      double A = 0.0, D_ = 0.0, gacc = 0.0;
+      if (TD) {
+        A = chain(A1, A2);
+        D_ = chain(D1, D2);
+        gacc = chain(G1, G2);
+        gacc *= LN2;  // the element terms were summed in log2 units (policy_terms)
+      }
+      // ---- per-row epilogue (meaningful on the lanes k = 2, which hold the totals)
+      const float inv32 = fast_rcp_f32_of_f64(Ssum);
+      if (TD) {
+        gacc -= fast_log_f64(Ssum) * D_;
+        gacc = fma(digamma_pos_mixed(A), D_, gacc);
+      }
+      if (wp) {  // P is written out: the tile itself is normalised (the copy-out reads it), the column pass multiplies by 1
+        const float t1 = r3_shl1(inv32);          // k = 1 takes k = 2's
+        const float t2 = r3_shl1(t1);             // k = 0 takes k = 2's
+        const float nrm = k == 2 ? inv32 : (k == 1 ? t1 : t2);
+        if (live) {
+#pragma unroll
+          for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int c = 8 * k + 4 * r + e;
+              if (c < D) trow[c] = yk[r][e] * nrm;   // (the tail lanes: element 0 of round 1 only)
+            }
+        }
+      }
+      if (live && tailk) {
+        *reinterpret_cast<float*>(&W.q64[i].y) = wp ? 1.0f : inv32;
+        if (TD) W.red[1][i] = gacc;
+      }
+      wave_sync();  // tile and row normalisers complete
+      // ---- column pass: lane (column i, part k) walks rows 7 k .. 7 k + 6; lane k = 0 folds the group sums in group order
+      double pa_ = 0.0, p1 = 0.0, p2 = 0.0;
+      {
+        const float* tcol = W.tile + i;
+        constexpr int GR = col_group_rows(D);
+        static_assert(GR * 3 == D, "three groups of seven rows");
+        const int r0 = GR * k;
+#pragma unroll
+        for (int r = 0; r < GR; ++r) {
+          const double2 e = W.q64[r0 + r];
+          const double p = (double)(tcol[(r0 + r) * D] * __int_as_float(__double2loint(e.y)));
+          col_walk_row(r == 0, p * e.x, p, pa_, p1, p2);
+        }
+      }
+      double acc = pa_, s1 = p1, s2 = p2;
+      {
+        const double a1 = r3_shl1(pa_), b1 = r3_shl1(p1), c1 = r3_shl1(p2);   // group 1 (lane + 1)
+        const double a2 = r3_shl1(a1), b2 = r3_shl1(b1), c2 = r3_shl1(c1);    // group 2 (lane + 2)
+        acc += a1;
+        s1 += b1;
+        s2 += c1;
+        acc += a2;
+        s1 += b2;
+        s2 += c2;
+      }
+      const double pid = (double)pi_i;
+      double rcol = 0.0;
+      if (a.reward_kind == MFG_REWARD_MFG_AC2) rcol = fma(pid, s1, -s2);
+      if (a.reward_kind == MFG_REWARD_SYNTHETIC) rcol = s1;
+      float pi_n = (float)acc;  // lanes k = 0
+      {
+        const float u1 = r3_shr1(pi_n), u2 = r3_shr1(u1);
+        pi_n = k == 0 ? pi_n : (k == 1 ? u1 : u2);
+      }
+      if (k0) {
+        W.pin[i] = pi_n;
+        W.pin[D + i] = pi_n;
+        if (!ext) W.red[0][i] = rcol;
+      }
+      if (wp) {
+        // copy-out of the trajectory's matrix (contiguous in LDS and in P_out); all LDS reads issued before the stores
+        wave_sync();
+        constexpr int NIT = (DD + WAVE - 1) / WAVE;
+        float* dst = a.P_out + (b * (int64_t)T + s) * DD;
+        float v[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+          const int kk = lane + u * WAVE;
+          v[u] = W.tile[kk < DD ? kk : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+          const int kk = lane + u * WAVE;
+          if (kk < DD) dst[kk] = v[u];
+        }
+      }
+      if (want_v) {
+        wave_sync();  // pin complete
+        // V(next) on the lanes k = 0 and -- at the rollout's first step -- V(start) on the lanes k = 1, in the same pass
+        const bool vs = k == 1 && s == 0;
+        if (live && (k == 0 || vs)) W.red[vs ? 3 : 2][i] = value_term(vs ? W.pst : W.pin, vs ? pi_i : pi_n);
+      }
+      wave_sync();
+      // ---- per-trajectory sums: EIGHT lanes (k = 0, i < 8) add the terms of parity p of quantity q -- k_core_small's association
+      if (k0 && i < 8) {
+        const int q = i >> 1, pp = i & 1;
+        const bool need = q == 0 ? !ext : (q == 1 ? want_v : (q == 2 ? (TD && a.g != nullptr) : (want_v && s == 0)));
+        double x = 0.0;
+        if (need) {
+          const double* src = W.red[q == 0 ? 0 : (q == 1 ? 2 : (q == 2 ? 1 : 3))];
+#pragma unroll
+          for (int kk0 = 0; kk0 < (D + 1) / 2; ++kk0) {
+            const int kk = 2 * kk0 + pp;
+            const double v = src[kk < D ? kk : 0];
+            x += kk < D ? v : 0.0;
+          }
+        }
+        W.tot[i] = x;
+      }
+      wave_sync();
+      if (lane == 0) {
+        double r0 = 0.0, r1 = 0.0;
+        if (ext) {
+          r0 = a.reward_in ? (double)a.reward_in[b * T + s] : 0.0;
+        } else {
+          r0 = W.tot[0];
+          r1 = W.tot[1];
+        }
+        double r = r0 + r1;
+        if (a.reward_kind == MFG_REWARD_SYNTHETIC) r *= -0.5;
+        if (a.reward_out) a.reward_out[b * T + s] = (float)r;
+        if (want_v) {
+          const double v0 = W.tot[2], v1 = W.tot[3];
+          const double v_next = (v0 + v1) + wl[Q + D];
+          if (s == 0) {
+            const double u0 = W.tot[6], u1 = W.tot[7];
+            v_cur = (u0 + u1) + wl[Q + D];
+          }
+          const double gd = a.discount_pow ? discount : a.gamma;
+          const double del = r + gd * v_next - v_cur;
+          if (a.delta) a.delta[b * T + s] = del;
+          v_cur = v_next;
+          discount *= a.gamma;
+        }
+      }
+      if (TD && lane == 3 && a.g) {  // (row 1, part 0): the lane that sums the score in the packed kernel
+        const double g0 = W.tot[4], g1 = W.tot[5];
+        a.g[b * T + s] = g0 + g1;
+      }
+      if (k0 && a.pi_traj) a.pi_traj[(b * (int64_t)(T + 1) + s + 1) * D + i] = pi_n;
+      pi_i = pi_n;
+    }
+    if (k0 && a.pi_next_out) a.pi_next_out[b * D + i] = pi_i;
+  }
+}
+
+// lane mapping of the d = 21 sampling launches (mfg_set_core_mapping, include/mfg_hip.h): 0 by batch size, 1 always the packed
+// kernel, 2 the one-trajectory-per-wave kernel wherever it supports the launch.  A measurement / test hook: both give the same bits.
+static std::atomic<int> g_core_mapping{0};
+int core_mapping_set(int mode) { return g_core_mapping.exchange(mode < 0 || mode > 2 ? 0 : mode); }
+
+bool core_row3_wanted(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus) {
+  (void)td;
+  // plain launches only: the per-step SUMS / STEP variants (k_core_small) keep the packed mapping
+  if (a.d != R3D || !sample || !fast || a.part_rows != nullptr || a.step_nrows != 0) return false;
+  const int mode = g_core_mapping.load();
+  if (mode) return mode == 2;
+  // one resident round at MFG_ROW3_WAVES waves per SIMD (4 SIMDs per CU): 4 096 trajectories on 256 CUs
+  return a.B <= (int64_t)num_cus * 4 * MFG_ROW3_WAVES;
+}
+
+int launch_core_row3(const CoreArgs& a, bool td, int num_cus, hipStream_t st) {
+  const size_t lds = core_row3_lds();
+  static std::atomic<int> cached_bpc[2][64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int bpc = cached_bpc[td ? 1 : 0][dev].load();
+  if (bpc == 0) {
+    int n = 0;
+    const hipError_t e = td ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<true>, BLOCK, lds)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<false>, BLOCK, lds);
+    if (e != hipSuccess || n < 1) n = 1;
+    bpc = n;
+    cached_bpc[td ? 1 : 0][dev].store(n);
+  }
+  const int grid = core_grid(a.B, WAVES, bpc * MFG_CORE_OVERSUBSCRIBE, num_cus);
+  if (td) hipLaunchKernelGGL((k_core_row3<true>), dim3(grid), dim3(BLOCK), lds, st, a);
+  else hipLaunchKernelGGL((k_core_row3<false>), dim3(grid), dim3(BLOCK), lds, st, a);
+  return MFG_OK;
+}
+
+}  // namespace mfg

@@ -67,6 +67,9 @@ static void dispatch(const CoreArgs& a, bool sample, bool td, bool fast, int num
 
 int launch_core_small(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus, hipStream_t st) {
   const int d = a.d;
+  // d = 21 batches that under-fill the machine: one trajectory per wave, three lanes per matrix row (mfg_core_row3.hip) --
+  // the same bits as the packed kernel below, a wave's serial chain ~2.2x shorter
+  if (core_row3_wanted(a, sample, td, fast, num_cus)) return launch_core_row3(a, td, num_cus, st);
   const bool want_v = td && a.w != nullptr;
   const size_t lds = core_small_lds(d, want_v, sample);
   if (d == 21) dispatch<21>(a, sample, td, fast, num_cus, lds, st);

@@ -2605,6 +2605,8 @@ int mfg_init(void) {
   return MFG_OK;
 }
 
+int mfg_set_core_mapping(int mode) { return core_mapping_set(mode); }
+
 int mfg_status(unsigned* bits_host) {
   const StatusWord sw = status_word();
   if (!sw.host) return fail(MFG_ELAUNCH, "%s", "status word allocation failed");

@@ -7,6 +7,9 @@ d, T, B = 21, 15, 65536
 if len(sys.argv) > 1:
     d, T, B = (int(x) for x in sys.argv[1].split(','))
 dev = torch.device('cuda:0')
+if os.environ.get('MFG_MAPPING'):   # 1 / 2: force the packed / the one-trajectory-per-wave lane mapping (A/B counter runs)
+    from discrete_mean_field_game_amd import _lib
+    _lib.lib().mfg_set_core_mapping(int(os.environ['MFG_MAPPING']))
 th = torch.tensor([8.86349], dtype=torch.float64, device=dev)
 rs = np.random.RandomState(0)
 pi0 = torch.as_tensor(rs.dirichlet(np.ones(d), size=B).astype(np.float32), device=dev)

@@ -9,6 +9,11 @@ import numpy as np, torch
 from discrete_mean_field_game_amd import ops
 
 dev = torch.device('cuda:0')
+# MFG_MAPPING = 1 / 2: force the packed / the one-trajectory-per-wave lane mapping of the d = 21 kernels (mfg_set_core_mapping) for A/B runs
+if os.environ.get('MFG_MAPPING'):
+    from discrete_mean_field_game_amd import _lib
+    _lib.lib().mfg_set_core_mapping(int(os.environ['MFG_MAPPING']))
+    print('# lane mapping forced to mode %s' % os.environ['MFG_MAPPING'], flush=True)
 
 
 def timeit(fn, n=30, warm=5):
