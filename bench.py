@@ -430,9 +430,12 @@ def main():
                 # the kernel the HEADLINE times, on both lines: its share of the HBM roofline (it never sends P through HBM, so this
                 # is small by construction) and of the VALU issue bound that actually limits it (committed SQ counters)
                 fused['headline_frac_of_hbm_line'] = value * bytes_per_step / 1e9 / HBM_PEAK_GBS
-                fused['headline_bound'] = ('VALU issue: valu_busy %.2f of the kernel time, priced issue work ~0.76-0.9 of the SIMD cycles '
-                                           '(profiles/r04_cycle_table_d21.txt); the roofline object above is the given-P kernel'
-                                           % fused.get('valu_busy', float('nan')))
+                import glob as _glob
+                _ct = sorted(_glob.glob(os.path.join(ROOT, 'profiles', 'r*_cycle_table_d%d.txt' % d)))
+                fused['headline_bound'] = ('VALU issue: valu_busy %.2f of the kernel time (4 cycles booked per instruction: an upper bound), priced '
+                                           'issue work ~0.75-0.9 of the SIMD cycles (%s); the roofline object above is the given-P kernel'
+                                           % (fused.get('valu_busy', float('nan')),
+                                              ('profiles/' + os.path.basename(_ct[-1])) if _ct else 'no cycle table committed for this d'))
                 # host-boundness of the class API: the same updates issued by one native call, GPU time from events
                 t_native = native_leg(d, T, B, args.steps, args.warmup)
                 fused['native_loop_ms_per_step'] = t_native / args.steps * 1e3
@@ -518,6 +521,30 @@ def other_configs(training_leg, native_leg, given_p_leg, d0, T0, B0, args):
                     'shards': sh})
     except Exception as exc:
         out.append({'config': 'shards', 'error': repr(exc)})
+    # round 6: the two lane mappings of the d = 21 sampling kernels at batches that under-fill the machine (mfg_set_core_mapping:
+    # the packed k_core_small vs k_core_row3, one trajectory per wave; same bits) -- native loop, event timed, same box, same run
+    try:
+        from discrete_mean_field_game_amd import _lib as _L
+        rows = []
+        for Bs in (4096, 2048, 1024):
+            e = {'batch': Bs}
+            for mode, name in ((1, 'packed'), (2, 'row3')):
+                _L.lib().mfg_set_core_mapping(mode)
+                e[name + '_ms_per_update'] = native_leg(21, 15, Bs, 60, 20) / 60 * 1e3
+            _L.lib().mfg_set_core_mapping(0)
+            e['row3_over_packed'] = e['packed_ms_per_update'] / e['row3_ms_per_update']
+            e['env_steps_per_s_row3'] = Bs * 15 / (e['row3_ms_per_update'] * 1e-3)
+            rows.append(e)
+        out.append({'config': 'd=21 lane mappings side by side: packed (3 trajectories per wave, a lane per matrix row) vs row3 (1 trajectory '
+                              'per wave, 3 lanes per row; taken automatically up to 16 trajectories per CU); rollout + batch sums + update per episode',
+                    'd': 21, 'T': 15, 'rows': rows})
+    except Exception as exc:
+        out.append({'config': 'lane mappings', 'error': repr(exc)})
+    finally:
+        try:
+            _L.lib().mfg_set_core_mapping(0)
+        except Exception:
+            pass
     # reference semantics: theta and w move after EVERY env step (mfg_ac2.py:505-522), batch-mean gradient; the 15-step
     # episode is issued natively (mfg_train_episode: 15 x [fused step kernel | batch sums + update])
     try:

@@ -843,10 +843,11 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
         double acc = 0.0, s1 = 0.0, s2 = 0.0;
         const float* tcol = tile + tlc * d * dp + i;
         const double2* q64 = reinterpret_cast<const double2*>(pis64) + tlc * d;
-#if !defined(MFG_ABL_COLT) && !defined(MFG_ABL_COLREW)
+#ifndef MFG_COLWALK
+#define MFG_COLWALK 2  // developer switch (A/B timing): 0 the plain row order of rounds 1-5 (other bits), 1 nested unrolled groups, 2 below
+#endif
+#if !defined(MFG_ABL_COLT) && !defined(MFG_ABL_COLREW) && MFG_COLWALK == 1
         if constexpr (D == 21) {
-          // d = 21: three groups of seven rows, each summed from its own first row, folded in group order (col_group_rows,
-          // mfg_device.h): the summation tree the three-lanes-per-column kernel k_core_row3 shares
           constexpr int GR = col_group_rows(D);
 #pragma unroll
           for (int g0 = 0; g0 < D; g0 += GR) {
@@ -854,7 +855,7 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
 #pragma unroll
             for (int r = 0; r < GR; ++r) {
               const int k = g0 + r;
-              const double2 e = q64[k];  // {pi_k, 1 / S_k (fp32 bits in the low word of .y)}
+              const double2 e = q64[k];
               const double p = (double)(tcol[k * dp] * __int_as_float(__double2loint(e.y)));
               col_walk_row(r == 0, p * e.x, p, pa, p1, p2);
             }
@@ -866,6 +867,29 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
               acc += pa;
               s1 += p1;
               s2 += p2;
+            }
+          }
+        } else
+#elif !defined(MFG_ABL_COLT) && !defined(MFG_ABL_COLREW) && MFG_COLWALK == 2
+        if constexpr (D == 21) {
+          // d = 21: three groups of seven rows, each summed from zero, folded in group order (col_group_rows, mfg_device.h): the
+          // summation tree the three-lanes-per-column kernel k_core_row3 shares.  Written as THE loop of rounds 2-5 (seven rows in
+          // flight) with the fold at the end of every unrolled body: 0 + u, fma(u, p, 0) and 0 + P0 are exact, so these are the bits
+          // of col_walk_row; the nested fully unrolled form of the first version cost the T = 1 step kernels 3 us per launch.
+          double pa = 0.0, p1 = 0.0, p2 = 0.0;
+#pragma unroll 7
+          for (int k = 0; k < D; ++k) {
+            const double2 e = q64[k];  // {pi_k, 1 / S_k (fp32 bits in the low word of .y)}
+            const double p = (double)(tcol[k * dp] * __int_as_float(__double2loint(e.y)));
+            const double u = p * e.x;
+            pa += u;
+            p1 = fma(u, p, p1);
+            p2 = fma(u, u, p2);
+            if (k % col_group_rows(D) == col_group_rows(D) - 1) {
+              acc += pa;
+              s1 += p1;
+              s2 += p2;
+              pa = p1 = p2 = 0.0;
             }
           }
         } else

@@ -705,7 +705,11 @@ __device__ __forceinline__ double rows_column_sum(const double* __restrict__ row
 // one-trajectory-per-wave kernel (k_core_row3: three lanes per column, seven rows each) share ONE summation tree -- the results
 // of a launch do not depend on which lane mapping it picked, i.e. on the batch a rank happens to hold (world-size invariance,
 // tests/test_gpu_fullsize.py).  Every other d: one group = the plain row order of rounds 1-5.
+#ifdef MFG_COLGROUP_OFF  // developer builds only (A/B timing against the plain row order of rounds 1-5; other bits at d = 21)
+__host__ __device__ constexpr int col_group_rows(int d) { return d > 0 ? d : 1; }
+#else
 __host__ __device__ constexpr int col_group_rows(int d) { return d == 21 ? 7 : (d > 0 ? d : 1); }
+#endif
 // One row of the walk folded into the running sums of its group (first = the group's first row): u = pi_i P_ij is exact in fp64.
 __device__ __forceinline__ void col_walk_row(bool first, double u, double p, double& pa, double& p1, double& p2) {
   if (first) {

@@ -566,25 +566,36 @@ __global__ __launch_bounds__(BLOCK, MFG_STEP_WAVES) void k_step_wave(const float
     const float* colp = wP + off + tc * DD + j;
     const float* qv = wQ + tc * D;
     double acc = 0.0, s1 = 0.0, s2 = 0.0;
-    // rows in groups of col_group_rows(D) (mfg_device.h: three groups of seven at d = 21; one group = the plain row order at 15)
+    // rows in groups of col_group_rows(D) (mfg_device.h: three groups of seven at d = 21; one group = the plain row order at 15):
+    // THE loop of rounds 2-5 with the running sums folded into the totals at the end of a group (all sums start from 0: 0 + u,
+    // fma(u, p, 0) and 0 + P0 are exact -- the bits of col_walk_row)
     constexpr int GR = col_group_rows(D);
-#pragma unroll
-    for (int g0 = 0; g0 < D; g0 += GR) {
-      double pa = 0.0, p1 = 0.0, p2 = 0.0;
-#pragma unroll MFG_STEP_UNROLL
-      for (int i = g0; i < g0 + GR; ++i) {
-        const double p = (double)colp[i * D];
-        const double qx = (double)qv[i];
-        const double u = p * qx;
-        pa += u;
-        if (KIND != MFG_REWARD_EXTERNAL) {
-          p1 = fma(u, p, p1);
-          if (KIND == MFG_REWARD_MFG_AC2) p2 = fma(u, u, p2);
-        }
+    double pa = 0.0, p1 = 0.0, p2 = 0.0;
+#ifndef MFG_COLWALK_STEP
+#define MFG_COLWALK_STEP 2  // developer switch: 2 seven rows per unrolled body (static folds), 3 MFG_STEP_UNROLL rows + a uniform test
+#endif
+    constexpr int UN = (MFG_COLWALK_STEP == 2 && GR < D) ? GR : MFG_STEP_UNROLL;  // (d = 15: the loop as it was)
+#pragma unroll UN
+    for (int i = 0; i < D; ++i) {
+      const double p = (double)colp[i * D];
+      const double qx = (double)qv[i];
+      const double u = p * qx;
+      pa += u;
+      if (KIND != MFG_REWARD_EXTERNAL) {
+        p1 = fma(u, p, p1);
+        if (KIND == MFG_REWARD_MFG_AC2) p2 = fma(u, u, p2);
       }
-      acc = g0 ? acc + pa : pa;
-      s1 = g0 ? s1 + p1 : p1;
-      s2 = g0 ? s2 + p2 : p2;
+      if (GR < D && i % GR == GR - 1) {
+        acc += pa;
+        s1 += p1;
+        s2 += p2;
+        pa = p1 = p2 = 0.0;
+      }
+    }
+    if (GR >= D) {
+      acc = pa;
+      s1 = p1;
+      s2 = p2;
     }
     double racc = 0.0;
     if (KIND == MFG_REWARD_MFG_AC2) racc = fma((double)qv[j], s1, -s2);
@@ -706,27 +717,33 @@ __global__ __launch_bounds__(BLOCK, 2) void k_step_wave_batched(const float* __r
       // the trajectory (broadcast reads; the VALU is idle anyway): the per-tile serial phase of k_step_wave -- two wave
       // barriers and 21 dependent adds on one lane -- disappears into the walk.  Same order: even terms, odd terms.
       double r0 = 0.0, r1 = 0.0;
-      // rows in groups of col_group_rows(D) (mfg_device.h: three groups of seven at d = 21; the plain row order at 15)
+      // rows in groups of col_group_rows(D) (mfg_device.h: three groups of seven at d = 21; the plain row order at 15): the fully
+      // unrolled walk of round 2 with the running sums folded at the end of a group (see k_step_wave)
       constexpr int GR = col_group_rows(D);
+      double pa = 0.0, p1 = 0.0, p2 = 0.0;
 #pragma unroll
-      for (int g0 = 0; g0 < D; g0 += GR) {
-        double pa = 0.0, p1 = 0.0, p2 = 0.0;
-#pragma unroll
-        for (int i = g0; i < g0 + GR; ++i) {
-          const double p = (double)colp[i * D];
-          const double qx = (double)qv[i];
-          const double u = p * qx;
-          pa += u;
-          if (REW) {
-            p1 = fma(u, p, p1);
-            if (KIND == MFG_REWARD_MFG_AC2) p2 = fma(u, u, p2);
-            if (i & 1) r1 += line[i];
-            else r0 += line[i];
-          }
+      for (int i = 0; i < D; ++i) {
+        const double p = (double)colp[i * D];
+        const double qx = (double)qv[i];
+        const double u = p * qx;
+        pa += u;
+        if (REW) {
+          p1 = fma(u, p, p1);
+          if (KIND == MFG_REWARD_MFG_AC2) p2 = fma(u, u, p2);
+          if (i & 1) r1 += line[i];
+          else r0 += line[i];
         }
-        acc = g0 ? acc + pa : pa;
-        s1 = g0 ? s1 + p1 : p1;
-        s2 = g0 ? s2 + p2 : p2;
+        if (GR < D && i % GR == GR - 1) {
+          acc += pa;
+          s1 += p1;
+          s2 += p2;
+          pa = p1 = p2 = 0.0;
+        }
+      }
+      if (GR >= D) {
+        acc = pa;
+        s1 = p1;
+        s2 = p2;
       }
       double racc = 0.0;
       if (KIND == MFG_REWARD_MFG_AC2) racc = fma((double)qv[j], s1, -s2);

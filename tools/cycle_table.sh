@@ -4,7 +4,7 @@
 # the per-class issue costs measured by tools/micro/valu_rates on the same chip, against the MEASURED VALU-active cycles
 # (SQ_ACTIVE_INST_VALU, quad-cycles x 4).  Optional ablation builds (tools/ablate.sh build) split the cycles by piece.
 # usage: bash tools/cycle_table.sh d,T,B > gpurun_out/<tag>/cycle_table_d<d>.txt
-R=$GRAFT_REPO_ROOT; SH=${1:-21,15,65536}; V=$R/discrete_mean_field_game_amd/csrc/variants
+R=$GRAFT_REPO_ROOT; SH=${1:-21,15,65536}; V=${MFG_VARIANT_DIR:-$R/discrete_mean_field_game_amd/csrc/variants}
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_BUSY_CYCLES"
 P2="SQ_WAVES SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64"

@@ -3,7 +3,7 @@
 # `bash tools/ablate.sh build` in the build container): SQ_INSTS_VALU / SQ_WAVES of the kernel with one piece at a
 # time replaced by a 1-4 instruction stand-in; baseline minus ablated = VALU instructions that piece executes per wave.
 # usage: bash tools/instr_table.sh [d,T,B] > gpurun_out/<tag>/instr_table.txt
-R=$GRAFT_REPO_ROOT; V=$R/discrete_mean_field_game_amd/csrc/variants; SH=${1:-21,15,65536}
+R=$GRAFT_REPO_ROOT; V=${MFG_VARIANT_DIR:-$R/discrete_mean_field_game_amd/csrc/variants}; SH=${1:-21,15,65536}
 cd /tmp && export TMPDIR=/tmp
 count() {  # $1 = library ('' = shipped build)
   rm -rf /tmp/it

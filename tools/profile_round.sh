@@ -3,12 +3,18 @@
 # kernels at d = 21 / 128 / 256, SQ issue counters of the fused rollout kernels at the bench shape, C3 and the C5 share).
 # Counters are collected in their own runs (never combined with the trace domains gpurun refuses).
 # usage: bash tools/profile_round.sh <tag>     (outputs under gpurun_out/<tag>/; copy the summaries into profiles/)
-R=$GRAFT_REPO_ROOT; TAG=${1:-r05}; O=$R/gpurun_out/$TAG; mkdir -p $O
+R=$GRAFT_REPO_ROOT; TAG=${1:-r06}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 # (the CPU-baseline leg forks one process per host core; it is left out of the traced run -- the kernels are the same)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/prof.err
 cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+# round 6: the same at EXACTLY the arguments the driver runs at round end (--steps 20 --warmup 5): the line, and the
+# rocprofv3 per-kernel table of that command
+python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_args.json 2> $O/bench_driver_args.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_drv -o bench -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_args_under_rocprof.json 2> $O/prof_drv.err
+cp $(find $O/prof_drv -name "*kernel_stats.csv" | head -1) $O/bench_driver_args_kernel_stats.csv
+rm -rf $O/prof_drv
 for SH in 21,15,65536 128,1,16384 256,1,16384; do
   N=${SH//,/_}
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$N -o p -- python3 $R/tools/pmc_step.py $SH > $O/pmc_fetch_$N.log 2>&1
@@ -35,7 +41,8 @@ python3 $R/tools/shard_table.py > $O/shards.txt 2>&1
 [ -x $R/tools/micro/mfma_valu_overlap ] && $R/tools/micro/mfma_valu_overlap > $O/mfma_valu_overlap.txt 2>&1
 # (cycle tables need the ablation variant libraries of tools/ablate.sh under csrc/variants, which no longer travel to the GPU box:
 #  built into MFG_VARIANT_DIR=csrc/ab when a round changes the fused kernels; round 5 did not)
-[ -d $R/discrete_mean_field_game_amd/csrc/variants/abl ] && for SH in 21,15,65536 128,40,16384 256,40,16384; do bash $R/tools/cycle_table.sh $SH > $O/cycle_table_d${SH%%,*}.txt 2>&1; done
+VD=${MFG_VARIANT_DIR:-$R/discrete_mean_field_game_amd/csrc/ab}
+[ -f $VD/libabl_PHILOX.so ] && for SH in 21,15,65536 128,40,16384 256,40,16384; do MFG_VARIANT_DIR=$VD bash $R/tools/cycle_table.sh $SH > $O/cycle_table_d${SH%%,*}.txt 2>&1; done
 bash $R/tools/trace_gaps.sh $R/tools/irl_mode_probe.py 4096 > $O/irl_step_mode_trace.txt 2>&1
 python3 $R/tools/perf_train.py 4096 > $O/perf_train_4096.txt 2>&1
 python3 $R/tools/perf_train.py 65536 > $O/perf_train_65536.txt 2>&1
@@ -58,3 +65,11 @@ for BB in 8192 65536; do
   MASTER_ADDR=127.0.0.1 MASTER_PORT=29541 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 python3 $R/bench.py --gpus 1 --force-dist --steps 50 --warmup 10 \
     --no-configs --no-cpu-baseline --no-roofline --batch $BB > $O/collective_1rank_$BB.json 2> $O/collective_1rank_$BB.err
 done
+# round 6: the two lane mappings of the d = 21 sampling launches side by side (mfg_set_core_mapping: 1 packed, 2 one trajectory
+# per wave): update times at the under-filled batch sizes, SQ counters of both kernels at 4 096 and 1 024 trajectories
+for m in 1 2; do
+  MFG_MAPPING=$m python3 $R/tools/shard_table.py 21 15 8192 6144 4096 3072 2048 1024 512 2>&1 | grep -v amdgpu.ids > $O/ab_shards_mapping$m.txt
+done
+( for m in 1 2; do export MFG_MAPPING=$m; for sh in 21,15,4096 21,15,1024; do echo "== lane mapping $m (1 packed k_core_small, 2 k_core_row3), shape d,T,B = $sh"; bash $R/tools/pmc_sq.sh k_core_ $R/tools/pmc_rollout.py $sh; done; done ) > $O/ab_pmc_sq.txt 2>&1
+unset MFG_MAPPING
+python3 $R/tools/hybrid_probe.py 3072 1024 2048 2048 > $O/hybrid_probe.txt 2>&1
