@@ -34,7 +34,7 @@ out = {'source': 'bench.py --gpus 1 --force-dist (1-rank RCCL communicator on on
        'collective': z['collective'],
        'multi_rank_cycle_ms_per_update': {'batch_8192': z['ms_per_step'], 'batch_65536': z2['ms_per_step']},
        'note': 'per update: rollout kernel (previous update applied in its weight staging) | batch sums | ONE all-reduce of G, '
-               'issued by the loop `loops.headline_loop` names (the native RCCL loop mfg_train_rollouts_dist once its canary passed, else torch.distributed); a 1-rank collective is a no-op floor, not a latency',
+               'issued by the loop that loops.headline_loop names (the native RCCL loop mfg_train_rollouts_dist once its canary passed, else torch.distributed); a 1-rank collective is a no-op floor, not a latency',
        'loops_8192': z.get('loops'), 'loops_65536': z2.get('loops')}
 json.dump(out, open('profiles/${P}_collective_1rank.json', 'w'), indent=1)
 print(out)
