@@ -362,3 +362,63 @@ def test_reference_harnesses_test_convergence_and_test_reward_network(dev, tmp_p
     import inspect
     sig = inspect.signature(ac.evaluate)
     assert sig.parameters['d'].default == 15 and sig.parameters['outfile'].default == 'eval_mfg_round2/validation.csv'
+
+
+def test_ragged_demonstrations_and_in_place_edits(dev):
+    """(a) the reference's update_reward flattens demonstrations of ANY length (ac_irl.py:816-821): a list with other
+    lengths than 15 pairs is accepted, stays on the host and trains through the autograd path; (b) replacing ONE trajectory of a
+    list view in place (same length: `ac.list_demonstrations[i] = traj`) is noticed (object fingerprint) and re-uploaded."""
+    from discrete_mean_field_game_amd.ac_irl import AC_IRL
+    d = 15
+    rs = np.random.RandomState(4)
+    mat = rs.dirichlet(np.ones(d), size=6)
+    traj = lambda n: [(rs.dirichlet(np.ones(d)), rs.dirichlet(np.ones(d), size=d)) for _ in range(n)]
+    np.random.seed(11); torch.manual_seed(11); random.seed(3)
+    ac = AC_IRL(d=d, pi0=mat, demonstrations=[traj(15), traj(9), traj(15), traj(20), traj(15), traj(15)], batch=8, seed=5, verbose=0)
+    assert ac._demo_ragged and len(ac._demo_store) == 0 and len(ac.list_demonstrations) == 6
+    ac.list_generated = [traj(15) for _ in range(5)]
+    before = ac._trainer.flat.clone()
+    steps0 = ac._trainer.step_count
+    ac.update_reward()
+    assert ac._trainer.step_count == steps0 + 1                      # ONE optimiser state: the autograd path stepped the trainer's Adam
+    assert not torch.equal(before, ac._trainer.flat) and torch.isfinite(ac._trainer.flat).all()
+    assert np.isfinite(ac.loss_val)
+    rd, rg = ac._eval_reward_averages()                              # the whole ragged list is evaluated (15+9+15+20+15+15 pairs)
+    assert np.isfinite(rd) and np.isfinite(rg)
+    # (b) same-length in-place replacement of one demonstration
+    ac2 = AC_IRL(d=d, pi0=mat, demonstrations=[traj(15) for _ in range(6)], batch=8, seed=5, verbose=0)
+    assert not ac2._demo_ragged and len(ac2._demo_store) == 6
+    new = traj(15)
+    ac2.list_demonstrations[2] = new
+    ac2._resync_stores()
+    s, a = ac2._demo_store.gather([2])
+    assert np.allclose(s[0, 0].cpu().numpy(), new[0][0].astype(np.float32)) and np.allclose(a[0, 14].cpu().numpy(), new[14][1].astype(np.float32))
+
+
+def test_checkpoint_without_trainer_state_takes_the_torch_adam_moments(dev):
+    """ADVICE r5: a checkpoint written before the HIP training step existed carries its Adam state in the torch optimiser only;
+    loading it seeds the trainer's moments and step count from there instead of silently starting from zero."""
+    from discrete_mean_field_game_amd.ac_irl import AC_IRL
+    d = 15
+    rs = np.random.RandomState(4)
+    mat = rs.dirichlet(np.ones(d), size=6)
+    demos = [[(rs.dirichlet(np.ones(d)), rs.dirichlet(np.ones(d), size=d)) for _ in range(15)] for _ in range(6)]
+    np.random.seed(11); torch.manual_seed(11)
+    ac = AC_IRL(d=d, pi0=mat, demonstrations=demos, batch=8, seed=5, verbose=0, reg='none')
+    # an "old" run: three torch-Adam steps on a dummy loss give the optimiser a state
+    for _ in range(3):
+        ac.optimizer.zero_grad()
+        loss = sum((p ** 2).sum() for p in ac.reward_net.parameters())
+        loss.backward()
+        ac.optimizer.step()
+    st = ac.state_dict()
+    st.pop('reward_trainer', None)
+    ac2 = AC_IRL(d=d, pi0=mat, demonstrations=demos, batch=8, seed=5, verbose=0, reg='none')
+    ac2.load_state_dict(st)
+    assert ac2._trainer.step_count == 3
+    off = 0
+    for p in ac.reward_net.parameters():
+        n = p.numel()
+        assert torch.allclose(ac2._trainer.m[off:off + n], ac.optimizer.state[p]['exp_avg'].reshape(-1))
+        assert torch.allclose(ac2._trainer.v[off:off + n], ac.optimizer.state[p]['exp_avg_sq'].reshape(-1))
+        off += n
