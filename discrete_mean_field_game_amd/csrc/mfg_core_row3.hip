@@ -7,7 +7,7 @@
 // MI355X hold, at 4 096 (BASELINE configs 2 and 4) 1 366 waves: a third of the SIMDs carries two chains, the others one, and the
 // launch lasts as long as two chains back to back (profiles/r05_shards.txt: 108.7 us at 4 096, 80 us for every B <= 2 048 -- the
 // length of ONE chain; profiles/r05_pmc_sq_irl_step.txt: the vector unit is active ~35 % of the launch).
-// Here lane = (row i, part k), k = 0, 1, 2 (63 lanes; lane 63 shadows lane 62 and writes nothing):
+// Here lane = (row i, part k), k = 0, 1, 2 (63 lanes; lane 63 shadows lane 62 and produces no output):
 //   * sampling: the row's six units of work -- the five quads at columns 4 q and the trailing single element -- go two to a lane:
 //     lane k draws quads 2 k and 2 k + 1, lane 2 quad 4 and the tail.  Every unit is keyed exactly as in the packed kernel (Philox
 //     block 0 of the quad's first element id i d + 4 q; the tail's Box-Muller pair by the EVEN step, cosine / first integer on even
@@ -23,9 +23,11 @@
 // Every output (pi_traj, rewards, delta, g, P) is therefore bit for bit what k_core_small<SAMPLE, TD, MIXED, 21> writes for the
 // same trajectory: which mapping a launch takes is a function of the batch a rank holds and must not show in the results
 // (world-size invariance; tests/test_gpu_row3.py compares the two kernels with array_equal).
-// A wave's chain is ~2.2x shorter (two quads instead of five and a half); the wave count is 3x; the instruction work per
-// trajectory ~1.4x (the epilogue, the per-trajectory sums and the value terms are per wave, not per lane).  Selected by
-// launch_core_small while the batch fits one resident round at four waves per SIMD (core_row3_wanted).
+// Measured (profiles/r06_ab_*): a wave's chain is 1.65x shorter (two quads instead of five and a half -- but the
+// epilogue, the cross-lane folds, the per-trajectory sums and the value terms are per wave, not per lane); the wave count is 3x; a
+// wave executes 878 vector instructions per env step against 568 per trajectory of the packed kernel.  Updates are 33-36 % shorter at
+// <= 1 024 trajectories, 17 % at 2 048, 5-10 % at 4 096; above that the packed kernel wins.  Selected by launch_core_small while the
+// batch fits one resident round at four waves per SIMD (core_row3_wanted).
 #include <atomic>
 #include <stdlib.h>
 
@@ -74,7 +76,8 @@ __global__ __launch_bounds__(BLOCK, MFG_ROW3_WAVES) void k_core_row3(CoreArgs a)
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE);
   R3Wave& W = *reinterpret_cast<R3Wave*>(smem_raw + R3_WL_BYTES + (size_t)wv * sizeof(R3Wave));
-  // lane = 3 i + k; lane 63 shadows lane 62 (row 20, part 2) and never writes
+  // lane = 3 i + k; lane 63 shadows lane 62 (row 20, part 2): it computes what lane 62 computes and stores nothing but the third
+  // copy of state entry 20 (below)
   const int i3 = (lane * 43) >> 7;  // lane / 3 for lane < 64
   const bool live = lane < 63;
   const int i = live ? i3 : D - 1;
