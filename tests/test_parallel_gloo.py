@@ -161,3 +161,17 @@ def test_all_reduce_is_noop_without_process_group():
     g = [torch.ones(3), torch.zeros(2, 2)]
     assert parallel.all_reduce_mean_flat_(g) == 0 and torch.equal(g[0], torch.ones(3))
     assert parallel.broadcast_seed(123) == 123
+
+
+def test_native_comm_bookkeeping_without_rccl(monkeypatch):
+    """parallel.native_comm / forget_native_comm off the GPU: no process group -> None (the class then keeps the exchange in
+    torch.distributed); a gloo group -> None without any hand-shake; a communicator the library aborted (MFG_ECOMM) is forgotten
+    for every group that cached it, so later calls answer None instead of a dead handle.  (The canary itself needs RCCL: the
+    -m gpu tests in tests/test_gpu_rccl.py run it on a 1-rank communicator, incl. an injected failure.)"""
+    assert parallel.native_comm(None, 'cpu') is None
+    monkeypatch.setitem(parallel._NATIVE_COMMS, (1234, 8), 0xDEAD)
+    monkeypatch.setitem(parallel._NATIVE_COMMS, (5678, 8), 0xDEAD)
+    monkeypatch.setitem(parallel._NATIVE_COMMS, (9, 2), 0xBEEF)
+    parallel.forget_native_comm(0xDEAD)
+    assert parallel._NATIVE_COMMS[(1234, 8)] is None and parallel._NATIVE_COMMS[(5678, 8)] is None
+    assert parallel._NATIVE_COMMS[(9, 2)] == 0xBEEF
