@@ -224,3 +224,51 @@ def test_native_rccl_canary_enables_the_loop_or_falls_back_symmetrically(inject)
         if inject == 'all':
             assert 'injected' in z['log']['detail']
         assert z['calls']['dist'] == 0 and z['calls']['all_reduce'] >= 5     # ... or one torch all-reduce per update
+
+
+_CHILD_NATIVE_LARGE = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+from discrete_mean_field_game_amd import parallel, ops
+from discrete_mean_field_game_amd.mfg_ac2 import actor_critic
+res = {}
+calls = {'n': 0}
+real_d = ops.train_rollouts_dist
+ops_patch = lambda *a, **k: (calls.__setitem__('n', calls['n'] + 1), real_d(*a, **k))[1]
+for d, B, T in ((128, 24, 3), (256, 10, 2), (100, 9, 2)):
+    mat = np.random.RandomState(3).dirichlet(np.ones(d), size=5)
+    out = []
+    for mode in ('native_dist', 'torch_dist', 'single'):
+        np.random.seed(11)
+        ac = actor_critic(d=d, pi0=mat, batch=B, rng='philox', seed=5, update_every='rollout', verbose=0, episode_steps=T)
+        ac._force_collective = mode != 'single'
+        ac._use_native_rccl = mode == 'native_dist'
+        ops.train_rollouts_dist = ops_patch
+        ac.train(num_episodes=4, gamma=0.9)
+        ops.train_rollouts_dist = real_d
+        out.append((float(np.ravel(ac.theta)[0]), ac.w[:, 0].tolist()))
+    res[d] = {'native_eq_single': out[0] == out[2], 'torch_eq_single': out[1] == out[2], 'theta': out[0][0]}
+torch.cuda.synchronize()
+print(json.dumps({'res': res, 'native_calls': calls['n']}))
+dist.destroy_process_group()
+'''
+
+
+def test_native_rccl_loop_at_large_d_equals_the_single_gpu_run():
+    """The c5_strong leg of bench.py (d = 256) takes the native RCCL loop on a multi-GPU node: mfg_train_rollouts_dist with the
+    wave-per-trajectory kernels (the deferred update is an out-of-place launch in front of the rollout there, DESIGN.md section 6).
+    1-rank `nccl` communicator, fresh child: d = 128 / 256 / 100 through the class, native loop and torch.distributed loop both
+    bit-equal to the single-GPU run."""
+    if not torch.cuda.is_available():
+        pytest.fail('-m gpu tests need a GPU')
+    p = subprocess.run([sys.executable, '-c', _CHILD_NATIVE_LARGE % {'root': ROOT}], cwd=ROOT, env=_env(), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    z = json.loads([l for l in p.stdout.decode().splitlines() if l.startswith('{')][-1])
+    assert z['native_calls'] in (3, 4)       # one native call per (silent) train() of the three shapes (+ the canary's own, made on first use)
+    for d, r in z['res'].items():
+        assert r['native_eq_single'] and r['torch_eq_single'] and r['theta'] != 8.86349, (d, r)
