@@ -66,7 +66,11 @@ __device__ __forceinline__ float r3_shl1(float v) { return dpp_mov_f32<0x130, 0x
 #ifndef MFG_ROW3_WAVES
 #define MFG_ROW3_WAVES 4   // waves per SIMD the kernel is register-capped for (128 VGPRs): 4 096 trajectories = one resident round
 #endif
-template <bool TD>
+// STEP: 0 plain; 1 IRL env step with the previous step's partial rows (CoreArgs::step_rows: every sampling wave forms theta from
+// their column F, the grid's last core_step_red_blocks(F + 3) blocks reduce all columns and publish the update -- the code of
+// k_core_small<..., STEP = 1>, the same functions: the same bits); 2 an IRL episode's FIRST env step (nothing to reduce; the start
+// states are also written to pi_start_out)
+template <bool TD, int STEP = 0>
 __global__ __launch_bounds__(BLOCK, MFG_ROW3_WAVES) void k_core_row3(CoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   constexpr int D = R3D, H = R3H, Q = R3Q, F = R3F, DD = R3DD;
@@ -84,16 +88,42 @@ __global__ __launch_bounds__(BLOCK, MFG_ROW3_WAVES) void k_core_row3(CoreArgs a)
   const int k = live ? lane - 3 * i3 : 2;
   const bool k0 = live && k == 0;
 
-  // first trajectory's start state: issued before the weight staging (its L2 / HBM latency hides behind it)
+  // blocks that run trajectories (STEP = 1: the grid's last blocks reduce the previous env step's partial rows instead)
+  const unsigned nblk = STEP == 1 ? gridDim.x - (unsigned)core_step_red_blocks(F + 3) : gridDim.x;
+  if constexpr (STEP == 1) {
+    if (blockIdx.x >= nblk) {
+      const int64_t kc = (int64_t)(blockIdx.x - nblk) * WAVES + wv;  // a wave per column
+      const int64_t FO = F + 3;
+      if (kc >= FO) return;
+      double old_val = 0.0;  // read first, under the row reads
+      if (lane == 0) {
+        if (kc < F) old_val = a.w_out[kc];
+        else if (kc == F) old_val = *a.theta;
+        else if (kc == F + 1 && a.pend_reward_acc) old_val = *a.pend_reward_acc;
+      }
+      const double gk = rows_column_sum(a.step_rows, a.step_nrows, FO, kc, lane);
+      if (lane == 0) {
+        const double inv = 1.0 / (double)a.B;
+        a.step_G[kc] = gk;
+        if (kc < F) a.w_out[kc] = updated_param(old_val, a.pend_lr_c, gk, inv);
+        else if (kc == F) *a.theta_out = updated_param(old_val, a.pend_lr_a, gk, inv);
+        else if (kc == F + 1 && a.pend_reward_acc) *a.pend_reward_acc = old_val + gk * inv;
+      }
+      return;
+    }
+  }
+  // first trajectory's start state: issued before the weight staging / theta's row reads (its L2 / HBM latency hides behind them)
   const int64_t ntraj = a.B;
-  const int64_t wstride = (int64_t)gridDim.x * WAVES;
+  const int64_t wstride = (int64_t)nblk * WAVES;
   int64_t b = (int64_t)blockIdx.x * WAVES + wv;
   float pi_first = 0.0f;
   if (b < ntraj) pi_first = a.pi0[core_src_row(a, b) * D + i];
   // deferred update of the previous episode (CoreArgs::pend_G), applied on the fly exactly as in k_core_small
-  const bool pend = a.pend_G != nullptr && a.pend_G[F + 2] > 0.0;
+  const bool pend = STEP != 1 && a.pend_G != nullptr && a.pend_G[F + 2] > 0.0;
   const double pinv = pend ? 1.0 / a.pend_G[F + 2] : 0.0;
-  const double theta = pend ? updated_param(*a.theta, a.pend_lr_a, a.pend_G[F], pinv) : *a.theta;
+  double theta = pend ? updated_param(*a.theta, a.pend_lr_a, a.pend_G[F], pinv) : *a.theta;
+  if constexpr (STEP == 1)  // the one parameter sampling needs: every wave adds up column F of the previous step's rows itself
+    theta = updated_param(theta, a.pend_lr_a, rows_column_sum(a.step_rows - a.step_nrows, a.step_nrows, 1, 0, lane), 1.0 / (double)a.B);
   const ThetaSplit ts = theta_split(theta, a.shift);
   report_sep_range(a.status, theta, a.shift);
   auto w_now = [&](int kk) -> double { return pend ? updated_param(a.w[kk], a.pend_lr_c, a.pend_G[kk], pinv) : a.w[kk]; };
@@ -107,7 +137,7 @@ __global__ __launch_bounds__(BLOCK, MFG_ROW3_WAVES) void k_core_row3(CoreArgs a)
     }
     for (int kk = Q + tid; kk < F; kk += BLOCK) wl[kk] = w_now(kk);
   }
-  if (a.pend_G != nullptr && blockIdx.x == 0) {
+  if (STEP != 1 && a.pend_G != nullptr && blockIdx.x == 0) {
     // block 0 publishes the updated parameters (out of place) and books the update's mean reward
     if (a.w_out && a.w)
       for (int kk = tid; kk < F; kk += BLOCK) a.w_out[kk] = w_now(kk);
@@ -139,6 +169,9 @@ __global__ __launch_bounds__(BLOCK, MFG_ROW3_WAVES) void k_core_row3(CoreArgs a)
     float pi_i = pi_first;
     if (b + wstride < ntraj) pi_first = a.pi0[core_src_row(a, b + wstride) * D + i];  // the next trajectory's start state
     if (k0 && a.pi_traj) a.pi_traj[b * (int64_t)(T + 1) * D + i] = pi_i;
+    if constexpr (STEP == 2) {
+      if (k0 && a.pi_start_out) a.pi_start_out[b * D + i] = pi_i;
+    }
     double v_cur = 0.0, discount = 1.0;  // meaningful on lane 0 only
     const uint64_t traj = a.traj_offset + (uint64_t)b;
     const uint32_t erow = (uint32_t)(i * D);
@@ -406,8 +439,11 @@ int core_mapping_set(int mode) { return g_core_mapping.exchange(mode < 0 || mode
 
 bool core_row3_wanted(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus) {
   (void)td;
-  // plain launches only: the per-step SUMS / STEP variants (k_core_small) keep the packed mapping
-  if (a.d != R3D || !sample || !fast || a.part_rows != nullptr || a.step_nrows != 0) return false;
+  // not the per-step SUMS variant (k_core_small<..., SUMS>: batch sums of 12-trajectory tiles on the matrix cores); the STEP
+  // variants (IRL env step) exist here too -- there part_rows aliases step_G
+  if (a.d != R3D || !sample || !fast) return false;
+  if (a.step_nrows == 0 && a.part_rows != nullptr) return false;
+  if (a.step_nrows != 0 && !td) return false;
   const int mode = g_core_mapping.load();
   if (mode) return mode == 2;
   // one resident round at MFG_ROW3_WAVES waves per SIMD (4 SIMDs per CU): 4 096 trajectories on 256 CUs
@@ -416,21 +452,29 @@ bool core_row3_wanted(const CoreArgs& a, bool sample, bool td, bool fast, int nu
 
 int launch_core_row3(const CoreArgs& a, bool td, int num_cus, hipStream_t st) {
   const size_t lds = core_row3_lds();
-  static std::atomic<int> cached_bpc[2][64];
+  const int step = a.step_nrows > 0 ? 1 : (a.step_nrows < 0 ? 2 : 0);
+  const int slot = step ? 1 + step : (td ? 1 : 0);   // 0: <false>, 1: <true>, 2: <true, 1>, 3: <true, 2>
+  static std::atomic<int> cached_bpc[4][64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  int bpc = cached_bpc[td ? 1 : 0][dev].load();
+  int bpc = cached_bpc[slot][dev].load();
   if (bpc == 0) {
     int n = 0;
-    const hipError_t e = td ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<true>, BLOCK, lds)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<false>, BLOCK, lds);
+    hipError_t e;
+    if (slot == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<false>, BLOCK, lds);
+    else if (slot == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<true>, BLOCK, lds);
+    else if (slot == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<true, 1>, BLOCK, lds);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<true, 2>, BLOCK, lds);
     if (e != hipSuccess || n < 1) n = 1;
     bpc = n;
-    cached_bpc[td ? 1 : 0][dev].store(n);
+    cached_bpc[slot][dev].store(n);
   }
   const int grid = core_grid(a.B, WAVES, bpc * MFG_CORE_OVERSUBSCRIBE, num_cus);
-  if (td) hipLaunchKernelGGL((k_core_row3<true>), dim3(grid), dim3(BLOCK), lds, st, a);
-  else hipLaunchKernelGGL((k_core_row3<false>), dim3(grid), dim3(BLOCK), lds, st, a);
+  if (slot == 0) hipLaunchKernelGGL((k_core_row3<false>), dim3(grid), dim3(BLOCK), lds, st, a);
+  else if (slot == 1) hipLaunchKernelGGL((k_core_row3<true>), dim3(grid), dim3(BLOCK), lds, st, a);
+  else if (slot == 2)  // (the blocks that reduce the previous env step's partial rows ride behind the sampling blocks)
+    hipLaunchKernelGGL((k_core_row3<true, 1>), dim3(grid + core_step_red_blocks(R3F + 3)), dim3(BLOCK), lds, st, a);
+  else hipLaunchKernelGGL((k_core_row3<true, 2>), dim3(grid), dim3(BLOCK), lds, st, a);
   return MFG_OK;
 }
 

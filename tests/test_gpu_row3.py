@@ -167,6 +167,30 @@ def test_irl_training_does_not_depend_on_the_mapping(dev):
     assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and res[0][0] != 8.64
 
 
+@pytest.mark.parametrize('B,T_odd', [(300, True), (4096, True), (50, False)])
+def test_irl_env_step_variants_do_not_depend_on_the_mapping(dev, B, T_odd):
+    """AC_IRL.train in step mode (the class default): mfg_train_episode_irl_draw = per env step [STEP variant of the sampling kernel:
+    theta from the previous step's partial rows, their reduction in the grid's last blocks | reward network + TD error + batch
+    sums].  The STEP variants exist in both lane mappings; parameters, returns and final states must not depend on which one runs.
+    (drawn start states: STEP = 2 at the first step, STEP = 1 afterwards; the native call itself with a given start state too)"""
+    from discrete_mean_field_game_amd import ops, _lib as L
+    from discrete_mean_field_game_amd.ac_irl import AC_IRL
+    rs = np.random.RandomState(0)
+    mat = rs.dirichlet(np.ones(21), size=16)
+    res = []
+    for m in (1, 2):
+        L.lib().mfg_set_core_mapping(m)
+        np.random.seed(5); torch.manual_seed(5)
+        ac = AC_IRL(theta=8.64, shift=0.0, alpha_scale=1e4, d=21, pi0=mat, demonstrations=[], batch=B, seed=3, update_every='step',
+                    verbose=0)
+        ac.train(max_episodes=2, stop_criteria=-1, gamma=0.95)
+        res.append((float(np.ravel(ac.theta)[0]), ac.w[:, 0].copy(), ac._last_pi.cpu().numpy().copy() if hasattr(ac, '_last_pi') and ac._last_pi is not None else None))
+    L.lib().mfg_set_core_mapping(0)
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and res[0][0] != 8.64
+    if res[0][2] is not None:
+        assert np.array_equal(res[0][2], res[1][2])
+
+
 def test_deferred_update_chain_in_both_mappings(dev):
     """mfg_train_rollout_deferred (the multi-rank cycle: the previous update applied while the weights are staged, block 0
     publishing the new parameters): three chained episodes, identical parameters / sums / outputs in either mapping."""
