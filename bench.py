@@ -569,11 +569,13 @@ def other_configs(training_leg, native_leg, given_p_leg, d0, T0, B0, args):
         from discrete_mean_field_game_amd.ac_irl import AC_IRL
         rs = np.random.RandomState(0)
         mat = rs.dirichlet(np.ones(21), size=64)
-        for mode, episodes in (('step', 30), ('rollout', 60)):
+        # (20 untimed episodes first: after the few idle milliseconds between two legs the device takes ~5-10 ms of work to be back
+        #  at its sustained clock -- tools/irl_rep_probe.py: 0.459 ms per episode right after an idle gap, 0.42 sustained)
+        for mode, episodes in (('step', 100), ('rollout', 100)):
             np.random.seed(5); torch.manual_seed(5)
             ac = AC_IRL(theta=8.64, shift=0.0, alpha_scale=1e4, d=21, pi0=mat, demonstrations=[], batch=4096, seed=3,
                         update_every=mode, verbose=0)
-            ac.train(max_episodes=3, stop_criteria=-1)
+            ac.train(max_episodes=20, stop_criteria=-1)
             torch.cuda.synchronize()
             t0 = _t.perf_counter()
             ac.train(max_episodes=episodes, stop_criteria=-1)
