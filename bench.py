@@ -548,8 +548,8 @@ def other_configs(training_leg, native_leg, given_p_leg, d0, T0, B0, args):
     # reference semantics: theta and w move after EVERY env step (mfg_ac2.py:505-522), batch-mean gradient; the 15-step
     # episode is issued natively (mfg_train_episode: 15 x [fused step kernel | batch sums + update])
     try:
-        for Bs, episodes in ((65536, 20), (4096, 60)):
-            e, _, st = training_leg(21, 15, Bs, episodes, 3, mode='step')
+        for Bs, episodes in ((65536, 20), (4096, 100)):
+            e, _, st = training_leg(21, 15, Bs, episodes, 3 if Bs > 4096 else 20, mode='step')
             del st
             out.append({'config': 'mfg_ac2.train, update per env step (reference semantics), class API', 'd': 21, 'T': 15,
                         'batch': Bs, 'episodes': episodes, 'env_steps_per_s': Bs * 15 * episodes / e,
