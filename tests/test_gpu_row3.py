@@ -228,6 +228,20 @@ def test_deferred_update_chain_in_both_mappings(dev):
     assert not torch.equal(a['theta'][0:1], a['theta'][2:3])
 
 
+def test_forced_new_mapping_beyond_one_resident_grid(dev):
+    """Forced onto a batch larger than the grid cap (8 x the resident blocks: 32 768 trajectories on 256 CUs) a wave of the new
+    kernel walks several trajectories (the prefetch of the next start state, the per-trajectory re-initialisation): same bits."""
+    from discrete_mean_field_game_amd import ops
+    d, B, T = 21, 70001, 2
+    rs = np.random.RandomState(9)
+    mat = torch.as_tensor(rs.dirichlet(np.ones(d), size=50).astype(np.float32), device=dev)
+    pi0 = mat[torch.as_tensor(rs.randint(50, size=B), device=dev)].contiguous()
+    th = torch.tensor([8.86349], dtype=torch.float64, device=dev)
+    w = torch.as_tensor(rs.rand(ops.num_features(d)), device=dev)
+    a, b = _both(lambda: ops.rollout(pi0, T, th, 0.16, 12000.0, w=w, gamma=0.9, seed=4, first_step=3, td=True))
+    _same(a, b, ['pi_traj', 'pi_last', 'reward', 'delta', 'g', 'G'])
+
+
 def test_automatic_choice_follows_the_batch_size(dev):
     """mode 0: batches up to one resident round of the new kernel (16 trajectories per CU) take it, larger ones the packed kernel --
     observable only through timing, so the check here is that results across the threshold stay those of the forced modes."""
