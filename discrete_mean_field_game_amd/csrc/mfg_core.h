@@ -871,13 +871,15 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
           }
         } else
 #elif !defined(MFG_ABL_COLT) && !defined(MFG_ABL_COLREW) && MFG_COLWALK == 2
-        if constexpr (D == 21) {
-          // d = 21: three groups of seven rows, each summed from zero, folded in group order (col_group_rows, mfg_device.h): the
-          // summation tree the three-lanes-per-column kernel k_core_row3 shares.  Written as THE loop of rounds 2-5 (seven rows in
-          // flight) with the fold at the end of every unrolled body: 0 + u, fma(u, p, 0) and 0 + P0 are exact, so these are the bits
-          // of col_walk_row; the nested fully unrolled form of the first version cost the T = 1 step kernels 3 us per launch.
+        if constexpr (D == 21 || D == 15) {
+          // d = 21: three groups of seven rows; d = 15: four groups of 4, 4, 4, 3 -- each summed from zero, folded in group order
+          // (col_group_rows, mfg_device.h): the summation tree the one-trajectory-per-wave kernel k_core_row3 shares.  Written as THE
+          // loop of rounds 2-5 (seven / eight rows in flight) with the folds at group ends, static in every unrolled body: 0 + u,
+          // fma(u, p, 0) and 0 + P0 are exact, so these are the bits of col_walk_row; the nested fully unrolled form of the first
+          // version cost the T = 1 step kernels 3 us per launch.
           double pa = 0.0, p1 = 0.0, p2 = 0.0;
-#pragma unroll 7
+          constexpr int UNR = D == 15 ? 8 : col_group_rows(D);  // a whole number of groups per body
+#pragma unroll UNR
           for (int k = 0; k < D; ++k) {
             const double2 e = q64[k];  // {pi_k, 1 / S_k (fp32 bits in the low word of .y)}
             const double p = (double)(tcol[k * dp] * __int_as_float(__double2loint(e.y)));
@@ -885,7 +887,7 @@ __global__ __launch_bounds__(BLOCK, SUMS ? 2 : (FAST ? MFG_CORE_SMALL_WAVES : MF
             pa += u;
             p1 = fma(u, p, p1);
             p2 = fma(u, u, p2);
-            if (k % col_group_rows(D) == col_group_rows(D) - 1) {
+            if (col_group_end(k, D)) {
               acc += pa;
               s1 += p1;
               s2 += p2;

@@ -1,5 +1,6 @@
-// d = 21, mixed-precision SAMPLING launches of batches that under-fill the machine: ONE trajectory per wavefront, THREE lanes
-// per matrix row (round 6).
+// d = 21 / 15, mixed-precision SAMPLING launches of batches that under-fill the machine: ONE trajectory per wavefront, THREE (d = 21) or
+// FOUR (d = 15) lanes per matrix row (round 6).  The description below is written for d = 21; d = 15 (the reference's AC_IRL default,
+// ac_irl.py:33) is the same with four lanes per row and ONE unit per lane: the three quads and the 3-element remainder of a row.
 //
 // The packed kernel k_core_small (mfg_core.h) puts G = 3 trajectories into a wave, lane = (trajectory, row): a wave walks the 21
 // elements of its rows one quad after the other -- a dependent chain of ~1 700 vector instructions per env step -- and a batch of
@@ -36,26 +37,29 @@
 namespace mfg {
 
 namespace {
-constexpr int R3D = 21;                                   // d
-constexpr int R3H = (R3D + 1) / 2;                        // circulant value terms per state entry
-constexpr int R3Q = R3D * (R3D + 1) / 2, R3F = R3Q + R3D + 1;
-constexpr int R3DD = R3D * R3D;
+// geometry of the mapping for a compile-time d: lanes per matrix row, quad rounds per lane, copies of the last state entry behind
+// the state vector (the lanes that draw a row's last unit read "four columns" from its first column on like every other lane)
+template <int D> struct R3Geo;
+template <> struct R3Geo<21> { static constexpr int LPR = 3, ROUNDS = 2, NCOPY = 3; };   // 5 quads + 1 trailing element = 6 units
+template <> struct R3Geo<15> { static constexpr int LPR = 4, ROUNDS = 1, NCOPY = 1; };   // 3 quads + a 3-element remainder = 4 units
 // LDS of one wave: nothing but the critic weights is shared by the block, so every barrier of a step is wave local
+template <int D>
 struct alignas(16) R3Wave {
-  double2 q64[R3D];          // {pi_k as fp64, 1 / S_k of row k (fp32 bits in the low word of .y)}: one broadcast read per row
-  double red[4][R3D];        // per-entry terms of reward / score / V(next) / V(start), summed by eight lanes
+  double2 q64[D];            // {pi_k as fp64, 1 / S_k of row k (fp32 bits in the low word of .y)}: one broadcast read per row
+  double red[4][D];          // per-entry terms of reward / score / V(next) / V(start), summed by eight lanes
   double tot[8];             // even / odd partial sums of the four per-trajectory sums
-  float tile[R3DD + 3];      // gamma variates (P when it is written out) of the step, row-major, unpadded
-  float pis[R3D + 3];        // state; entries 21 .. 23 repeat entry 20: the lanes that draw a row's trailing element read "four
-  float pex[R3D + 3];        // columns" from 20 on like every other lane (one base address + immediates).  E_j = e^{theta (pi_j - 1/2)}
-  float pin[2 * R3D];        // next state, doubled (circulant value form: vec[i + m] needs no modulo)
-  float pst[2 * R3D];        // the rollout's start state, doubled
+  float tile[D * D + 3];     // gamma variates (P when it is written out) of the step, row-major, unpadded
+  float pis[D + 3];          // state; the entries behind it repeat entry D - 1 (R3Geo::NCOPY of them are written)
+  float pex[D + 3];          // E_j = e^{theta (pi_j - 1/2)} (separable exponential, mfg_device.h), same layout
+  float pin[2 * D];          // next state, doubled (circulant value form: vec[i + m] needs no modulo)
+  float pst[2 * D];          // the rollout's start state, doubled
+  float pad[(4 - (D * D + 3 + 2 * (D + 3) + 4 * D) % 4) % 4 + 4];
 };
-static_assert(sizeof(R3Wave) % 16 == 0, "wave regions must keep the 16-byte alignment of q64");
-constexpr size_t R3_WL_BYTES = (size_t)((R3F + 1) & ~1) * 8;   // critic weights (circulant layout), fp64
+static_assert(sizeof(R3Wave<21>) % 16 == 0 && sizeof(R3Wave<15>) % 16 == 0, "wave regions must keep the 16-byte alignment of q64");
+template <int D> constexpr size_t r3_wl_bytes() { return (size_t)((D * (D + 1) / 2 + D + 1 + 1) & ~1) * 8; }   // critic weights, fp64
 }  // namespace
 
-inline size_t core_row3_lds() { return R3_WL_BYTES + (size_t)WAVES * sizeof(R3Wave); }
+template <int D> inline size_t core_row3_lds() { return r3_wl_bytes<D>() + (size_t)WAVES * sizeof(R3Wave<D>); }
 
 // DPP wave shifts by one lane: shr -> lane l takes lane l - 1 (lane 0: zero), shl -> lane l takes lane l + 1 (lane 63: zero)
 __device__ __forceinline__ double r3_shr1(double v) { return dpp_mov_f64<0x138, 0xF>(v); }
@@ -70,22 +74,24 @@ __device__ __forceinline__ float r3_shl1(float v) { return dpp_mov_f32<0x130, 0x
 // their column F, the grid's last core_step_red_blocks(F + 3) blocks reduce all columns and publish the update -- the code of
 // k_core_small<..., STEP = 1>, the same functions: the same bits); 2 an IRL episode's FIRST env step (nothing to reduce; the start
 // states are also written to pi_start_out)
-template <bool TD, int STEP = 0>
+template <int D, bool TD, int STEP = 0>
 __global__ __launch_bounds__(BLOCK, MFG_ROW3_WAVES) void k_core_row3(CoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int D = R3D, H = R3H, Q = R3Q, F = R3F, DD = R3DD;
+  constexpr int H = (D + 1) / 2, Q = D * (D + 1) / 2, F = Q + D + 1, DD = D * D;
+  constexpr int LPR = R3Geo<D>::LPR, ROUNDS = R3Geo<D>::ROUNDS, NCOPY = R3Geo<D>::NCOPY, NL = D * LPR;
+  static_assert(NL <= WAVE && 4 * ROUNDS * (LPR - 1) < D && 4 * ROUNDS * LPR >= D, "the row's units fit the lanes of a row");
   const int T = a.T;
   const bool want_v = TD && a.w != nullptr;
   double* wl = reinterpret_cast<double*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int wv = __builtin_amdgcn_readfirstlane(tid / WAVE);
-  R3Wave& W = *reinterpret_cast<R3Wave*>(smem_raw + R3_WL_BYTES + (size_t)wv * sizeof(R3Wave));
-  // lane = 3 i + k; lane 63 shadows lane 62 (row 20, part 2): it computes what lane 62 computes and stores nothing but the third
-  // copy of state entry 20 (below)
-  const int i3 = (lane * 43) >> 7;  // lane / 3 for lane < 64
-  const bool live = lane < 63;
+  R3Wave<D>& W = *reinterpret_cast<R3Wave<D>*>(smem_raw + r3_wl_bytes<D>() + (size_t)wv * sizeof(R3Wave<D>));
+  // lane = LPR i + k; the lanes behind the last row shadow its last lane (row D - 1, part LPR - 1): they compute what it computes
+  // and store nothing but copies of the last state entry (below)
+  const int i3 = LPR == 3 ? (lane * 43) >> 7 : lane >> 2;  // lane / LPR for lane < 64
+  const bool live = lane < NL;
   const int i = live ? i3 : D - 1;
-  const int k = live ? lane - 3 * i3 : 2;
+  const int k = live ? lane - LPR * i3 : LPR - 1;
   const bool k0 = live && k == 0;
 
   // blocks that run trajectories (STEP = 1: the grid's last blocks reduce the previous env step's partial rows instead)
@@ -181,8 +187,8 @@ __global__ __launch_bounds__(BLOCK, MFG_ROW3_WAVES) void k_core_row3(CoreArgs a)
       // ---- state of the step: every lane of a row keeps pi_i and forms F_i; the lane k = 0 publishes pi_i, E_i
       const float Ei = exp_f64arg(theta * ((double)pi_i - SEP_CENTRE));
       const float Fi = exp_f64arg(-theta * ((double)pi_i + (a.shift - SEP_CENTRE)));
-      if (i == D - 1 && lane != 60) {  // lanes 61, 62, 63 hold row 20's state too: the three copies behind the vector
-        const int c = lane - 40;       // 21, 22, 23
+      if (lane > (D - 1) * LPR && lane <= (D - 1) * LPR + NCOPY) {  // other lanes that hold the last row's state (i == D - 1):
+        const int c = D + lane - (D - 1) * LPR - 1;                 // the copies behind the vector (d = 21: lanes 61 .. 63 -> 21 .. 23)
         W.pis[c] = pi_i;
         W.pex[c] = Ei;
       }
@@ -196,150 +202,193 @@ __global__ __launch_bounds__(BLOCK, MFG_ROW3_WAVES) void k_core_row3(CoreArgs a)
         }
       }
       wave_sync();
-      // ---- sampling: two units per lane through the quad code
+      // ---- sampling: ROUNDS units per lane through the quad code
       using TT = float;
       const float pas = pi_i + ts.sh;  // row operand of the separable form (policy_setup_sep)
       float pa[4], fi[4];
-      float yk[2][4];
-      float S1 = 0.0f, S2 = 0.0f;
-      TT A1 = 0, A2 = 0, D1 = 0, D2 = 0, G1 = 0, G2 = 0;
+      float yk[ROUNDS][4];
+      float Sq[ROUNDS];
+      TT Aq[ROUNDS], Dq[ROUNDS], Gq[ROUNDS];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         pa[e] = pas;
         fi[e] = Fi;
       }
+#pragma unroll
+      for (int r = 0; r < ROUNDS; ++r) Sq[r] = 0.0f, Aq[r] = 0, Dq[r] = 0, Gq[r] = 0;
       const bool wp = a.P_out != nullptr;
       const uint32_t odd = step & 1u;
       float* trow = W.tile + i * D;
-      // round 0: the quad at columns 8 k .. 8 k + 3 (quads 0, 2, 4 of the row); round 1: the quad at columns 8 k + 4 .. 8 k + 7
-      // (quads 1, 3) -- or, on the lanes k = 2, the row's trailing element: its pair is keyed by the EVEN step, element 0 of the
-      // pair (cosine, first 16-bit integer) is the draw of an even step, element 1 (sine, second integer) of an odd one; the
-      // other elements do not exist there (sample_tail1's arithmetic).  ONE copy of the quad code (a rolled loop: two copies
-      // interleaved by the scheduler cost 200 spilled registers at the 128-register cap).
+      // d = 21 -- round 0: the quad at columns 8 k .. 8 k + 3 (quads 0, 2, 4 of the row); round 1: the quad at columns 8 k + 4 ..
+      // 8 k + 7 (quads 1, 3) -- or, on the lanes k = 2, the row's trailing element: its pair is keyed by the EVEN step, element 0 of
+      // the pair (cosine, first 16-bit integer) is the draw of an even step, element 1 (sine, second integer) of an odd one; the
+      // other elements do not exist there (sample_tail1's arithmetic).  d = 15 -- one round: the quad at columns 4 k, on the lanes
+      // k = 3 the 3-element remainder (sample_elems<3>'s arithmetic: the fourth draw is discarded).  ONE copy of the quad code (a
+      // rolled loop: two copies interleaved by the scheduler cost 200 spilled registers at the 128-register cap).
+      if constexpr (ROUNDS == 1) __builtin_amdgcn_sched_barrier(0);  // (one round is no loop: keep the scheduler from interleaving the
+                                                                      //  quad code with the staging before / the folds behind it)
 #pragma unroll 1
-      for (int r = 0; r < 2; ++r) {
+      for (int r = 0; r < ROUNDS; ++r) {
         float pj[4], ej[4], y[4];
         TT al[4], ad[4], gt[4];
         uint32_t el[4];
         bool ok[4];
-        const bool tail = r == 1 && k == 2;
-        const uint32_t qstep = tail ? (step & ~1u) : step;
-        const int c0 = 8 * k + 4 * r;          // (tail: 20 -- the copies behind the state vector stand in for "columns" 21 .. 23)
+        const bool last = r == ROUNDS - 1 && k == LPR - 1;   // the lane's unit is the row's LAST one (tail element / remainder)
+        const uint32_t qstep = (D == 21 && last) ? (step & ~1u) : step;
+        const int c0 = 4 * ROUNDS * k + 4 * r;  // (last unit: the copies behind the state vector stand in for the missing columns)
         const uint32_t elmax = erow + (uint32_t)(D - 1);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           pj[e] = W.pis[c0 + e];
           ej[e] = W.pex[c0 + e];
           const uint32_t id = erow + (uint32_t)(c0 + e);
-          el[e] = id < elmax ? id : elmax;     // the tail's elements all carry the tail's id (its continuation draws are keyed by it)
-          ok[e] = true;  // (ALLVALID: the tail lanes pick their element below; lane 63 mirrors lane 62 and writes nothing)
+          el[e] = id < elmax ? id : elmax;     // (d = 21: the tail's elements all carry the tail's id -- its continuation draws are keyed by it)
+          ok[e] = true;  // (ALLVALID: the last-unit lanes pick their elements below; the shadow lanes mirror one of them)
         }
         sample_elems_gq<4, TD, true, true, true>(a, theta, ts, pj, ej, pa, fi, el, ok, qstep, step, traj, y, al, ad, gt);
         float Sr = y[0];
         TT Ar = 0, Dr = 0, Gr = 0;
         if (TD) Ar = al[0], Dr = ad[0], Gr = gt[0];
+        float S3 = 0.0f;
+        TT A3 = 0, D3 = 0, G3 = 0;
 #pragma unroll
         for (int e = 1; e < 4; ++e) {
+          if (e == 3) S3 = Sr, A3 = Ar, D3 = Dr, G3 = Gr;  // the sums of the first three elements (the d = 15 remainder)
           Sr += y[e];
           if (TD) Ar += al[e], Dr += ad[e], Gr += gt[e];
         }
-        if (r == 1) {
-          // tail lanes: the unit is ONE element -- element 0 of the pair on even steps, element 1 on odd ones (wave-uniform choice);
-          // elements 2, 3 (and the other one of the pair) do not exist: their draws are discarded
-          const float ys = odd ? y[1] : y[0];
-          Sr = tail ? ys : Sr;
-          if (TD) {
-            const TT as = odd ? al[1] : al[0], ds = odd ? ad[1] : ad[0], gs = odd ? gt[1] : gt[0];
-            Ar = tail ? as : Ar;
-            Dr = tail ? ds : Dr;
-            Gr = tail ? gs : Gr;
+        if (r == ROUNDS - 1) {
+          if constexpr (D == 21) {
+            // tail lanes: the unit is ONE element -- element 0 of the pair on even steps, element 1 on odd ones (wave-uniform
+            // choice); elements 2, 3 (and the other one of the pair) do not exist: their draws are discarded
+            const float ys = odd ? y[1] : y[0];
+            Sr = last ? ys : Sr;
+            if (TD) {
+              const TT as = odd ? al[1] : al[0], ds = odd ? ad[1] : ad[0], gs = odd ? gt[1] : gt[0];
+              Ar = last ? as : Ar;
+              Dr = last ? ds : Dr;
+              Gr = last ? gs : Gr;
+            }
+            y[0] = last ? ys : y[0];  // what the tail lanes store at column 20 (they store no other element)
+          } else {
+            // remainder lanes: three elements, the fourth does not exist
+            Sr = last ? S3 : Sr;
+            if (TD) {
+              Ar = last ? A3 : Ar;
+              Dr = last ? D3 : Dr;
+              Gr = last ? G3 : Gr;
+            }
           }
-          y[0] = tail ? ys : y[0];  // what the tail lanes store at column 20 (they store no other element)
         }
-        if (r == 0) {
-          S1 = Sr;
-          if (TD) A1 = Ar, D1 = Dr, G1 = Gr;
+        // (r is the counter of a rolled loop: the per-round sums are parked under a wave-uniform branch with constant indices --
+        //  through selects they cost the d = 21 kernel 12 %; the variates of a written-out P go to yk[r]: with two rounds that
+        //  is scratch, used in that mode only -- as registers they cost 16 more spilled registers in every mode)
+        constexpr int NLAST = D == 21 ? 1 : 3;  // elements of the row's last unit
+        if (ROUNDS == 1 || r == 0) {
+          Sq[0] = Sr;
+          if (TD) Aq[0] = Ar, Dq[0] = Dr, Gq[0] = Gr;
         } else {
-          S2 = Sr;
-          if (TD) A2 = Ar, D2 = Dr, G2 = Gr;
+          Sq[ROUNDS - 1] = Sr;
+          if (TD) Aq[ROUNDS - 1] = Ar, Dq[ROUNDS - 1] = Dr, Gq[ROUNDS - 1] = Gr;
         }
-        if (wp) {  // P is written out: the variates wait in registers for the row's normaliser
+        if (wp) {  // P is written out: the variates wait for the row's normaliser
 #pragma unroll
-          for (int e = 0; e < 4; ++e) yk[r][e] = y[e];
-        } else if (live) {
-          trow[c0] = y[0];
-          if (!tail) {
+          for (int e = 0; e < 4; ++e) yk[ROUNDS == 1 ? 0 : r][e] = y[e];
+        }
+        if (!wp && live) {
 #pragma unroll
-            for (int e = 1; e < 4; ++e) trow[c0 + e] = y[e];
+          for (int e = 0; e < NLAST; ++e) trow[c0 + e] = y[e];
+          if (!last) {
+#pragma unroll
+            for (int e = NLAST; e < 4; ++e) trow[c0 + e] = y[e];
           }
         }
       }
-      const bool tailk = k == 2;
-      // ---- row totals: the packed kernel's chain  ((((0 + q0) + q1) + q2) + q3) + q4) + tail  in fp64, across the three lanes
-      auto chain = [&](float r1, float r2) -> double {
-        const double x1 = (double)r1, x2 = (double)r2;
-        double c = x1 + x2;                       // k = 0: (0 + q0) + q1
-        c = (r3_shr1(c) + x1) + x2;               // k = 1: ((.. + q2) + q3)
-        c = (r3_shr1(c) + x1) + x2;               // k = 2: ((.. + q4) + tail)
+      if constexpr (ROUNDS == 1) __builtin_amdgcn_sched_barrier(0);
+      const bool lastk = k == LPR - 1;
+      // ---- row totals: the packed kernel's chain over the row's units in unit order, in fp64 -- ((((0 + u0) + u1) + u2) + ..) --
+      // across the lanes of the row (LPR - 1 DPP hand-overs); the totals end up on the lane k = LPR - 1
+      auto chain = [&](const float* rr) -> double {
+        double x[ROUNDS];
+#pragma unroll
+        for (int q = 0; q < ROUNDS; ++q) x[q] = (double)rr[q];
+        double c = x[0];                          // k = 0: 0 + u0 (exact)
+#pragma unroll
+        for (int q = 1; q < ROUNDS; ++q) c += x[q];
+#pragma unroll
+        for (int j = 1; j < LPR; ++j) {           // k = j: the running sum of the lanes before it + its own units
+          c = r3_shr1(c) + x[0];
+#pragma unroll
+          for (int q = 1; q < ROUNDS; ++q) c += x[q];
+        }
         return c;
       };
-      const double Ssum = chain(S1, S2);
+      const double Ssum = chain(Sq);
       double A = 0.0, D_ = 0.0, gacc = 0.0;
       if (TD) {
-        A = chain(A1, A2);
-        D_ = chain(D1, D2);
-        gacc = chain(G1, G2);
+        A = chain(Aq);
+        D_ = chain(Dq);
+        gacc = chain(Gq);
         gacc *= LN2;  // the element terms were summed in log2 units (policy_terms)
       }
-      // ---- per-row epilogue (meaningful on the lanes k = 2, which hold the totals)
+      // ---- per-row epilogue (meaningful on the lanes k = LPR - 1, which hold the totals)
       const float inv32 = fast_rcp_f32_of_f64(Ssum);
       if (TD) {
         gacc -= fast_log_f64(Ssum) * D_;
         gacc = fma(digamma_pos_mixed(A), D_, gacc);
       }
       if (wp) {  // P is written out: the tile itself is normalised (the copy-out reads it), the column pass multiplies by 1
-        const float t1 = r3_shl1(inv32);          // k = 1 takes k = 2's
-        const float t2 = r3_shl1(t1);             // k = 0 takes k = 2's
-        const float nrm = k == 2 ? inv32 : (k == 1 ? t1 : t2);
+        float nrm = inv32, t = inv32;
+#pragma unroll
+        for (int j = 1; j < LPR; ++j) {           // lane k = LPR - 1 - j takes the value of the row's last lane
+          t = r3_shl1(t);
+          nrm = k == LPR - 1 - j ? t : nrm;
+        }
         if (live) {
 #pragma unroll
-          for (int r = 0; r < 2; ++r)
+          for (int r = 0; r < ROUNDS; ++r)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const int c = 8 * k + 4 * r + e;
-              if (c < D) trow[c] = yk[r][e] * nrm;   // (the tail lanes: element 0 of round 1 only)
+              const int c = 4 * ROUNDS * k + 4 * r + e;
+              if (c < D) trow[c] = yk[r][e] * nrm;   // (the last unit's lanes: its existing elements only)
             }
         }
       }
-      if (live && tailk) {
+      if (live && lastk) {
         *reinterpret_cast<float*>(&W.q64[i].y) = wp ? 1.0f : inv32;
         if (TD) W.red[1][i] = gacc;
       }
       wave_sync();  // tile and row normalisers complete
-      // ---- column pass: lane (column i, part k) walks rows 7 k .. 7 k + 6; lane k = 0 folds the group sums in group order
+      // ---- column pass: lane (column i, part k) walks the rows of group k (col_group_rows: 7 k .. 7 k + 6 at d = 21; 4 k .. 4 k + 3 at
+      // d = 15, the last group one row short); lane k = 0 folds the group sums in group order
       double pa_ = 0.0, p1 = 0.0, p2 = 0.0;
       {
         const float* tcol = W.tile + i;
         constexpr int GR = col_group_rows(D);
-        static_assert(GR * 3 == D, "three groups of seven rows");
+        static_assert(GR * LPR >= D && GR * (LPR - 1) < D, "one group of rows per lane of a column");
+        constexpr int LASTN = D - GR * (LPR - 1);  // rows of the last group
         const int r0 = GR * k;
 #pragma unroll
         for (int r = 0; r < GR; ++r) {
-          const double2 e = W.q64[r0 + r];
-          const double p = (double)(tcol[(r0 + r) * D] * __int_as_float(__double2loint(e.y)));
-          col_walk_row(r == 0, p * e.x, p, pa_, p1, p2);
+          if (r < LASTN || k < LPR - 1) {          // (a row beyond the matrix: the last group's lanes skip it)
+            const double2 e = W.q64[r0 + r];
+            const double p = (double)(tcol[(r0 + r) * D] * __int_as_float(__double2loint(e.y)));
+            col_walk_row(r == 0, p * e.x, p, pa_, p1, p2);
+          }
         }
       }
       double acc = pa_, s1 = p1, s2 = p2;
       {
-        const double a1 = r3_shl1(pa_), b1 = r3_shl1(p1), c1 = r3_shl1(p2);   // group 1 (lane + 1)
-        const double a2 = r3_shl1(a1), b2 = r3_shl1(b1), c2 = r3_shl1(c1);    // group 2 (lane + 2)
-        acc += a1;
-        s1 += b1;
-        s2 += c1;
-        acc += a2;
-        s1 += b2;
-        s2 += c2;
+        double ta = pa_, tb = p1, tc = p2;
+#pragma unroll
+        for (int j = 1; j < LPR; ++j) {            // group j arrives from lane + j
+          ta = r3_shl1(ta);
+          tb = r3_shl1(tb);
+          tc = r3_shl1(tc);
+          acc += ta;
+          s1 += tb;
+          s2 += tc;
+        }
       }
       const double pid = (double)pi_i;
       double rcol = 0.0;
@@ -347,8 +396,12 @@ __global__ __launch_bounds__(BLOCK, MFG_ROW3_WAVES) void k_core_row3(CoreArgs a)
       if (a.reward_kind == MFG_REWARD_SYNTHETIC) rcol = s1;
       float pi_n = (float)acc;  // lanes k = 0
       {
-        const float u1 = r3_shr1(pi_n), u2 = r3_shr1(u1);
-        pi_n = k == 0 ? pi_n : (k == 1 ? u1 : u2);
+        float u = pi_n;
+#pragma unroll
+        for (int j = 1; j < LPR; ++j) {            // lane k = j takes the value of the row's first lane
+          u = r3_shr1(u);
+          pi_n = k == j ? u : pi_n;
+        }
       }
       if (k0) {
         W.pin[i] = pi_n;
@@ -421,7 +474,7 @@ __global__ __launch_bounds__(BLOCK, MFG_ROW3_WAVES) void k_core_row3(CoreArgs a)
           discount *= a.gamma;
         }
       }
-      if (TD && lane == 3 && a.g) {  // (row 1, part 0): the lane that sums the score in the packed kernel
+      if (TD && lane == LPR && a.g) {  // (row 1, part 0): the lane that sums the score in the packed kernel
         const double g0 = W.tot[4], g1 = W.tot[5];
         a.g[b * T + s] = g0 + g1;
       }
@@ -438,22 +491,27 @@ static std::atomic<int> g_core_mapping{0};
 int core_mapping_set(int mode) { return g_core_mapping.exchange(mode < 0 || mode > 2 ? 0 : mode); }
 
 bool core_row3_wanted(const CoreArgs& a, bool sample, bool td, bool fast, int num_cus) {
-  (void)td;
-  // not the per-step SUMS variant (k_core_small<..., SUMS>: batch sums of 12-trajectory tiles on the matrix cores); the STEP
+  // not the per-step SUMS variant (k_core_small<..., SUMS>: batch sums of 12- / 16-trajectory tiles on the matrix cores); the STEP
   // variants (IRL env step) exist here too -- there part_rows aliases step_G
-  if (a.d != R3D || !sample || !fast) return false;
+  if ((a.d != 21 && a.d != 15) || !sample || !fast) return false;
   if (a.step_nrows == 0 && a.part_rows != nullptr) return false;
   if (a.step_nrows != 0 && !td) return false;
   const int mode = g_core_mapping.load();
   if (mode) return mode == 2;
-  // one resident round at MFG_ROW3_WAVES waves per SIMD (4 SIMDs per CU): 4 096 trajectories on 256 CUs
-  return a.B <= (int64_t)num_cus * 4 * MFG_ROW3_WAVES;
+  // d = 21: one resident round at MFG_ROW3_WAVES waves per SIMD (4 SIMDs per CU): 4 096 trajectories on 256 CUs -- rollouts, single
+  // steps and the IRL step variants alike (profiles/r06_ab_shards_mapping*.txt, r06_t1_mapping_probe.txt).
+  // d = 15 (profiles/r06_ab_shards_d15.txt, r06_irl_d15_probe.txt): the packed kernel holds FOUR trajectories per wave and its chain
+  // is short where the policy's shapes stay large (the IRL workload), so the new mapping pays later: single-step launches only
+  // while a SIMD holds one wave (4 per CU), rollouts that write their actions out up to three waves per SIMD, others up to four.
+  const int64_t per_cu = a.d == 21 ? 4 * MFG_ROW3_WAVES : (a.T == 1 ? 4 : (a.P_out ? 12 : 16));
+  return a.B <= (int64_t)num_cus * per_cu;
 }
 
-int launch_core_row3(const CoreArgs& a, bool td, int num_cus, hipStream_t st) {
-  const size_t lds = core_row3_lds();
+template <int D>
+static int launch_core_row3_d(const CoreArgs& a, bool td, int num_cus, hipStream_t st) {
+  const size_t lds = core_row3_lds<D>();
   const int step = a.step_nrows > 0 ? 1 : (a.step_nrows < 0 ? 2 : 0);
-  const int slot = step ? 1 + step : (td ? 1 : 0);   // 0: <false>, 1: <true>, 2: <true, 1>, 3: <true, 2>
+  const int slot = step ? 1 + step : (td ? 1 : 0);   // 0: <D, false>, 1: <D, true>, 2: <D, true, 1>, 3: <D, true, 2>
   static std::atomic<int> cached_bpc[4][64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -461,21 +519,25 @@ int launch_core_row3(const CoreArgs& a, bool td, int num_cus, hipStream_t st) {
   if (bpc == 0) {
     int n = 0;
     hipError_t e;
-    if (slot == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<false>, BLOCK, lds);
-    else if (slot == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<true>, BLOCK, lds);
-    else if (slot == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<true, 1>, BLOCK, lds);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<true, 2>, BLOCK, lds);
+    if (slot == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<D, false>, BLOCK, lds);
+    else if (slot == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<D, true>, BLOCK, lds);
+    else if (slot == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<D, true, 1>, BLOCK, lds);
+    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_core_row3<D, true, 2>, BLOCK, lds);
     if (e != hipSuccess || n < 1) n = 1;
     bpc = n;
     cached_bpc[slot][dev].store(n);
   }
   const int grid = core_grid(a.B, WAVES, bpc * MFG_CORE_OVERSUBSCRIBE, num_cus);
-  if (slot == 0) hipLaunchKernelGGL((k_core_row3<false>), dim3(grid), dim3(BLOCK), lds, st, a);
-  else if (slot == 1) hipLaunchKernelGGL((k_core_row3<true>), dim3(grid), dim3(BLOCK), lds, st, a);
+  if (slot == 0) hipLaunchKernelGGL((k_core_row3<D, false>), dim3(grid), dim3(BLOCK), lds, st, a);
+  else if (slot == 1) hipLaunchKernelGGL((k_core_row3<D, true>), dim3(grid), dim3(BLOCK), lds, st, a);
   else if (slot == 2)  // (the blocks that reduce the previous env step's partial rows ride behind the sampling blocks)
-    hipLaunchKernelGGL((k_core_row3<true, 1>), dim3(grid + core_step_red_blocks(R3F + 3)), dim3(BLOCK), lds, st, a);
-  else hipLaunchKernelGGL((k_core_row3<true, 2>), dim3(grid), dim3(BLOCK), lds, st, a);
+    hipLaunchKernelGGL((k_core_row3<D, true, 1>), dim3(grid + core_step_red_blocks(D * (D + 1) / 2 + D + 1 + 3)), dim3(BLOCK), lds, st, a);
+  else hipLaunchKernelGGL((k_core_row3<D, true, 2>), dim3(grid), dim3(BLOCK), lds, st, a);
   return MFG_OK;
+}
+
+int launch_core_row3(const CoreArgs& a, bool td, int num_cus, hipStream_t st) {
+  return a.d == 21 ? launch_core_row3_d<21>(a, td, num_cus, st) : launch_core_row3_d<15>(a, td, num_cus, st);
 }
 
 }  // namespace mfg

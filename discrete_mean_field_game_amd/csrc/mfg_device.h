@@ -700,16 +700,19 @@ __device__ __forceinline__ double rows_column_sum(const double* __restrict__ row
 }
 
 // Column walk of the transition / reward sums (pi'_j = sum_i pi_i P_ij and the two reward sums of column j): the d rows are added
-// in groups of col_group_rows(d) consecutive rows -- every group starts from its own first row, the group sums are folded in group
-// order.  d = 21: THREE groups of seven, so that the packed kernels (a lane walks all 21 rows of its column) and the
-// one-trajectory-per-wave kernel (k_core_row3: three lanes per column, seven rows each) share ONE summation tree -- the results
-// of a launch do not depend on which lane mapping it picked, i.e. on the batch a rank happens to hold (world-size invariance,
-// tests/test_gpu_fullsize.py).  Every other d: one group = the plain row order of rounds 1-5.
-#ifdef MFG_COLGROUP_OFF  // developer builds only (A/B timing against the plain row order of rounds 1-5; other bits at d = 21)
+// in groups of col_group_rows(d) consecutive rows (the last group may be shorter) -- every group starts from its own first row,
+// the group sums are folded in group order.  d = 21: THREE groups of seven; d = 15: FOUR groups of 4, 4, 4, 3 -- so that the
+// packed kernels (a lane walks all rows of its column) and the one-trajectory-per-wave kernel (k_core_row3: three / four lanes
+// per column, one group each) share ONE summation tree: the results of a launch do not depend on which lane mapping it picked,
+// i.e. on the batch a rank happens to hold (world-size invariance, tests/test_gpu_fullsize.py, tests/test_gpu_row3.py).
+// Every other d: one group = the plain row order of rounds 1-5.
+#ifdef MFG_COLGROUP_OFF  // developer builds only (A/B timing against the plain row order of rounds 1-5; other bits at d = 21 / 15)
 __host__ __device__ constexpr int col_group_rows(int d) { return d > 0 ? d : 1; }
 #else
-__host__ __device__ constexpr int col_group_rows(int d) { return d == 21 ? 7 : (d > 0 ? d : 1); }
+__host__ __device__ constexpr int col_group_rows(int d) { return d == 21 ? 7 : (d == 15 ? 4 : (d > 0 ? d : 1)); }
 #endif
+// last row of a group: where the running sums of the walk are folded into the totals
+__host__ __device__ constexpr bool col_group_end(int k, int d) { return k % col_group_rows(d) == col_group_rows(d) - 1 || k == d - 1; }
 // One row of the walk folded into the running sums of its group (first = the group's first row): u = pi_i P_ij is exact in fp64.
 __device__ __forceinline__ void col_walk_row(bool first, double u, double p, double& pa, double& p1, double& p2) {
   if (first) {

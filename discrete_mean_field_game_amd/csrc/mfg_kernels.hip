@@ -441,7 +441,7 @@ __global__ __launch_bounds__(BLOCK, (PER <= 6 ? MFG_STEP_WAVES : 4)) void k_step
     for (int g0 = 0; g0 < dr; g0 += grp) {
       double pa = 0.0, p1 = 0.0, p2 = 0.0;
 #pragma unroll MFG_STEP_UNROLL
-      for (int i = g0; i < g0 + grp; ++i) {
+      for (int i = g0; i < g0 + grp && i < (D ? D : d); ++i) {
         const double p = (double)colp[i * d];
         const double qx = (double)qv[i];
         // u = pi_i P_ij is exact in fp64 (two fp32 factors), so acc += u equals the fma, and pi_i P_ij^2 = u p,
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(BLOCK, MFG_STEP_WAVES) void k_step_wave(const float
 #ifndef MFG_COLWALK_STEP
 #define MFG_COLWALK_STEP 2  // developer switch: 2 seven rows per unrolled body (static folds), 3 MFG_STEP_UNROLL rows + a uniform test
 #endif
-    constexpr int UN = (MFG_COLWALK_STEP == 2 && GR < D) ? GR : MFG_STEP_UNROLL;  // (d = 15: the loop as it was)
+    constexpr int UN = (MFG_COLWALK_STEP == 2 && GR < D) ? (D == 15 ? 8 : GR) : MFG_STEP_UNROLL;  // a whole number of groups per body
 #pragma unroll UN
     for (int i = 0; i < D; ++i) {
       const double p = (double)colp[i * D];
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(BLOCK, MFG_STEP_WAVES) void k_step_wave(const float
         p1 = fma(u, p, p1);
         if (KIND == MFG_REWARD_MFG_AC2) p2 = fma(u, u, p2);
       }
-      if (GR < D && i % GR == GR - 1) {
+      if (GR < D && col_group_end(i, D)) {
         acc += pa;
         s1 += p1;
         s2 += p2;
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(BLOCK, 2) void k_step_wave_batched(const float* __r
           if (i & 1) r1 += line[i];
           else r0 += line[i];
         }
-        if (GR < D && i % GR == GR - 1) {
+        if (GR < D && col_group_end(i, D)) {
           acc += pa;
           s1 += p1;
           s2 += p2;
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(BLOCK) void k_step_small_unaligned(const float* __r
     const int grp = col_group_rows(d);  // (mfg_device.h: pi' of the aligned kernels bit for bit, also at d = 21)
     for (int g0 = 0; g0 < d; g0 += grp) {
       double pa = 0.0, p1 = 0.0, p2 = 0.0;
-      for (int i = g0; i < g0 + grp; ++i) {
+      for (int i = g0; i < g0 + grp && i < d; ++i) {
         const double p = (double)colp[i * d];
         const double2 q = qv[i];
         const double pp = p * p;

@@ -71,11 +71,12 @@ enum {
 const char* mfg_last_error(void);
 int mfg_abi_version(void);
 
-/* Lane mapping of the d = 21 mixed-precision sampling launches (mfg_rollout, mfg_sample_dirichlet, the mfg_train_rollout*
- * family; hot loop of mfg_ac2.py:478-526).  Two kernels produce the SAME bits: the packed one (three trajectories per
- * wavefront, a lane per matrix row) and -- round 6, ABI 17 -- one trajectory per wavefront with three lanes per matrix row,
- * whose serial chain per wave is ~2.2x shorter; the library takes the second while the batch fits one resident round of it
- * (<= 16 trajectories per CU: 4 096 on an MI355X), i.e. where the packed kernel leaves the SIMDs under-occupied.
+/* Lane mapping of the d = 21 / 15 mixed-precision sampling launches (mfg_rollout, mfg_sample_dirichlet, the mfg_train_rollout*
+ * and mfg_train_episode_irl* families; hot loop of mfg_ac2.py:478-526, ac_irl.py:664-712).  Two kernels produce the SAME bits:
+ * the packed one (three / four trajectories per wavefront, a lane per matrix row) and -- round 6, ABI 17 -- one trajectory per
+ * wavefront with three / four lanes per matrix row, whose serial chain per wave is 1.65x / 2.2x shorter; the library takes the
+ * second where the packed kernel leaves the SIMDs under-occupied (d = 21: <= 16 trajectories per CU = 4 096 on an MI355X;
+ * d = 15: <= 16 per CU, <= 12 with MFG_ROLLOUT_WRITE_P, <= 4 for single-step launches -- measured).
  * mode: 0 by batch size (default), 1 always packed, 2 one trajectory per wave wherever it supports the launch.  Process-wide;
  * returns the previous mode.  A measurement / test hook (A/B timing, bit-identity tests): results never depend on it. */
 int mfg_set_core_mapping(int mode);

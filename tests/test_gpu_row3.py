@@ -62,9 +62,9 @@ def _same(a, b, keys):
                                             (257, 6, 11), (1000, 15, 2), (4096, 15, 5)])
 @pytest.mark.parametrize('td,write_P,discount_pow,reward_kind', [(True, False, False, 0), (True, True, True, 0), (False, True, False, 0),
                                                                   (False, False, False, 0), (True, False, False, 1)])
-def test_rollout_is_bit_identical_in_both_mappings(dev, B, T, first_step, td, write_P, discount_pow, reward_kind):
+@pytest.mark.parametrize('d', [21, 15])
+def test_rollout_is_bit_identical_in_both_mappings(dev, d, B, T, first_step, td, write_P, discount_pow, reward_kind):
     from discrete_mean_field_game_amd import ops
-    d = 21
     rs = np.random.RandomState(1000 + B + T)
     pi0 = torch.as_tensor(rs.dirichlet(np.ones(d), size=B).astype(np.float32), device=dev)
     th = torch.tensor([8.86349], dtype=torch.float64, device=dev)
@@ -113,11 +113,12 @@ def test_row3_kernel_vs_the_oracle_directly(dev):
         assert np.array_equal(P0.cpu().numpy(), P[:, 0])
 
 
-def test_small_shapes_and_cold_paths_in_both_mappings(dev):
+@pytest.mark.parametrize('d', [21, 15])
+def test_small_shapes_and_cold_paths_in_both_mappings(dev, d):
     """Policies whose concentrations fall below 1 (the U^(1/a) boost) and whose acceptance tests go to the exact path: the
     continuation draws are keyed by the ELEMENT, so the trailing element that runs through the quad code must find its own."""
     from discrete_mean_field_game_amd import ops
-    d, B, T = 21, 300, 4
+    B, T = 300, 4
     rs = np.random.RandomState(5)
     pi0 = torch.as_tensor(rs.dirichlet(0.3 * np.ones(d), size=B).astype(np.float32), device=dev)
     for theta, scale in ((8.86349, 0.7), (2.0, 3.0), (20.0, 40.0), (8.86349, 1.0e5)):
@@ -130,18 +131,19 @@ def test_small_shapes_and_cold_paths_in_both_mappings(dev):
 
 
 @pytest.mark.parametrize('mode', ['rollout', 'step'])
-def test_class_training_does_not_depend_on_the_mapping(dev, mode):
+@pytest.mark.parametrize('d', [21, 15])
+def test_class_training_does_not_depend_on_the_mapping(dev, d, mode):
     """actor_critic.train over a batch the automatic choice gives to the new kernel: parameters, returns and final states equal
     the run with the packed kernel forced, bit for bit (native episode loops, in-kernel start draw, deferred nothing)."""
     from discrete_mean_field_game_amd import _lib as L
     from discrete_mean_field_game_amd.mfg_ac2 import actor_critic
     rs = np.random.RandomState(0)
-    mat = rs.dirichlet(np.ones(21), size=16)
+    mat = rs.dirichlet(np.ones(d), size=16)
     res = []
     for m in (1, 0):
         L.lib().mfg_set_core_mapping(m)
         np.random.seed(7)
-        ac = actor_critic(d=21, pi0=mat, batch=700, rng='philox', seed=5, update_every=mode, verbose=0)
+        ac = actor_critic(d=d, pi0=mat, batch=700, rng='philox', seed=5, update_every=mode, verbose=0)
         ac.train(num_episodes=4, gamma=0.9)
         res.append((float(np.ravel(ac.theta)[0]), ac.w[:, 0].copy(), ac._last_pi.cpu().numpy().copy()))
     L.lib().mfg_set_core_mapping(0)
@@ -149,17 +151,18 @@ def test_class_training_does_not_depend_on_the_mapping(dev, mode):
     assert res[0][0] != 8.86349
 
 
-def test_irl_training_does_not_depend_on_the_mapping(dev):
+@pytest.mark.parametrize('d', [21, 15])
+def test_irl_training_does_not_depend_on_the_mapping(dev, d):
     """AC_IRL.train in rollout mode (mfg_train_rollout_irl: rollout with the actions written out | reward network | sums)."""
     from discrete_mean_field_game_amd import _lib as L
     from discrete_mean_field_game_amd.ac_irl import AC_IRL
     rs = np.random.RandomState(0)
-    mat = rs.dirichlet(np.ones(21), size=16)
+    mat = rs.dirichlet(np.ones(d), size=16)
     res = []
     for m in (1, 2):
         L.lib().mfg_set_core_mapping(m)
         np.random.seed(5); torch.manual_seed(5)
-        ac = AC_IRL(theta=8.64, shift=0.0, alpha_scale=1e4, d=21, pi0=mat, demonstrations=[], batch=300, seed=3,
+        ac = AC_IRL(theta=8.64, shift=0.0, alpha_scale=1e4, d=d, pi0=mat, demonstrations=[], batch=300, seed=3,
                     update_every='rollout', verbose=0)
         ac.train(max_episodes=3, stop_criteria=-1)
         res.append((float(np.ravel(ac.theta)[0]), ac.w[:, 0].copy()))
@@ -168,7 +171,8 @@ def test_irl_training_does_not_depend_on_the_mapping(dev):
 
 
 @pytest.mark.parametrize('B,T_odd', [(300, True), (4096, True), (50, False)])
-def test_irl_env_step_variants_do_not_depend_on_the_mapping(dev, B, T_odd):
+@pytest.mark.parametrize('d', [21, 15])
+def test_irl_env_step_variants_do_not_depend_on_the_mapping(dev, d, B, T_odd):
     """AC_IRL.train in step mode (the class default): mfg_train_episode_irl_draw = per env step [STEP variant of the sampling kernel:
     theta from the previous step's partial rows, their reduction in the grid's last blocks | reward network + TD error + batch
     sums].  The STEP variants exist in both lane mappings; parameters, returns and final states must not depend on which one runs.
@@ -176,12 +180,12 @@ def test_irl_env_step_variants_do_not_depend_on_the_mapping(dev, B, T_odd):
     from discrete_mean_field_game_amd import ops, _lib as L
     from discrete_mean_field_game_amd.ac_irl import AC_IRL
     rs = np.random.RandomState(0)
-    mat = rs.dirichlet(np.ones(21), size=16)
+    mat = rs.dirichlet(np.ones(d), size=16)
     res = []
     for m in (1, 2):
         L.lib().mfg_set_core_mapping(m)
         np.random.seed(5); torch.manual_seed(5)
-        ac = AC_IRL(theta=8.64, shift=0.0, alpha_scale=1e4, d=21, pi0=mat, demonstrations=[], batch=B, seed=3, update_every='step',
+        ac = AC_IRL(theta=8.64, shift=0.0, alpha_scale=1e4, d=d, pi0=mat, demonstrations=[], batch=B, seed=3, update_every='step',
                     verbose=0)
         ac.train(max_episodes=2, stop_criteria=-1, gamma=0.95)
         res.append((float(np.ravel(ac.theta)[0]), ac.w[:, 0].copy(), ac._last_pi.cpu().numpy().copy() if hasattr(ac, '_last_pi') and ac._last_pi is not None else None))
@@ -191,11 +195,12 @@ def test_irl_env_step_variants_do_not_depend_on_the_mapping(dev, B, T_odd):
         assert np.array_equal(res[0][2], res[1][2])
 
 
-def test_deferred_update_chain_in_both_mappings(dev):
+@pytest.mark.parametrize('d', [21, 15])
+def test_deferred_update_chain_in_both_mappings(dev, d):
     """mfg_train_rollout_deferred (the multi-rank cycle: the previous update applied while the weights are staged, block 0
     publishing the new parameters): three chained episodes, identical parameters / sums / outputs in either mapping."""
     from discrete_mean_field_game_amd import ops
-    d, B, T = 21, 500, 15
+    B, T = 500, 15
     rs = np.random.RandomState(2)
     mat = torch.as_tensor(rs.dirichlet(np.ones(d), size=9).astype(np.float32), device=dev)
     F = ops.num_features(d)

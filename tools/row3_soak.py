@@ -1,4 +1,4 @@
-"""Randomised soak of the two lane mappings of the d = 21 sampling launches (developer tool; the claim of tests/test_gpu_row3.py
+"""Randomised soak of the two lane mappings of the d = 21 (or, ROW3_SOAK_D=15, d = 15) sampling launches (developer tool; the claim of tests/test_gpu_row3.py
 over many more shapes): the packed kernel k_core_small (three trajectories per wavefront, a lane per matrix row) and k_core_row3
 (one trajectory per wavefront, three lanes per row) must write the SAME BITS -- pi trajectory, rewards, TD errors, scores, actions,
 batch sums -- whatever the policy, the batch, the rollout length and the Philox keys are.
@@ -15,7 +15,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 dev = torch.device('cuda:0')
 lib = L.lib()
 rs = np.random.RandomState(20261006)
-d = 21
+d = int(os.environ.get("ROW3_SOAK_D", "21"))
 F = ops.num_features(d)
 t0 = time.time()
 n = n_roll = n_def = 0
